@@ -1,0 +1,221 @@
+"""Generate the golden fixtures in this directory from the REFERENCE's own classes.
+
+Run in the build container only (needs /root/reference; the GPU box never runs this):
+
+    python tests/golden/make_golden.py
+
+The reference's model code (T = nnUNetTrainer_MLAgg_2D_dt_MS.py, M = MambaSkip.py) is
+imported unmodified with stand-ins registered in ``sys.modules`` for the third-party
+packages that are absent offline: timm (DropPath, ...),
+MONAI (Unetr blocks), mamba-ssm (``selective_scan_fn``), flash-attn (``flash_attn_func``),
+dynamic_network_architectures and three nnunetv2 modules T only needs as names.  The
+stand-ins for the *arithmetic* of those packages are the oracle's restatements, so the
+fixtures pin everything the reference itself defines and leave those four third-party
+boundaries unpinned (stated in every consumer of these files).
+
+Weights are not stored: both sides call ``oracle.mlagg_oracle.deterministic_fill_`` on the
+ABI-named state_dict.  Stored: inputs' seeds, outputs, loss values, gradient summaries.
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/mlagg"
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from oracle import mlagg_oracle as O  # noqa: E402
+
+FLASH_SCALE = {"value": None}  # None -> flash default (variant A); 1.0 -> variant B
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def register_standins():
+    def to_2tuple(x):
+        return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+    _mod("timm")
+    _mod("timm.optim")
+    _mod("timm.scheduler")
+    _mod("timm.models")
+    _mod("timm.models.layers", DropPath=O.DropPath, to_2tuple=to_2tuple, trunc_normal_=nn.init.trunc_normal_)
+    sys.modules["timm"].optim = sys.modules["timm.optim"]
+    sys.modules["timm"].scheduler = sys.modules["timm.scheduler"]
+
+    class UnetrBasicBlock(O.UnetrBasicBlock):
+        def __init__(self, spatial_dims, in_channels, out_channels, kernel_size, stride, norm_name, res_block):
+            assert spatial_dims == 2 and kernel_size == 3 and stride == 1 and norm_name == "instance" and res_block
+            super().__init__(in_channels, out_channels)
+
+    class UnetrUpBlock(O.UnetrUpBlock):
+        def __init__(self, spatial_dims, in_channels, out_channels, kernel_size, upsample_kernel_size,
+                     norm_name, res_block):
+            assert spatial_dims == 2 and kernel_size == 3 and upsample_kernel_size == 2 and res_block
+            super().__init__(in_channels, out_channels)
+
+    _mod("monai")
+    _mod("monai.networks")
+    _mod("monai.networks.blocks", UnetOutBlock=object, UnetrBasicBlock=UnetrBasicBlock, UnetrUpBlock=UnetrUpBlock)
+    _mod("monai.networks.layers")
+    _mod("monai.networks.layers.utils", get_norm_layer=None)
+    _mod("monai.networks.blocks.dynunet_block", get_conv_layer=None)
+
+    _mod("mamba_ssm")
+    _mod("mamba_ssm.ops")
+    _mod("mamba_ssm.ops.selective_scan_interface",
+         selective_scan_fn=O.selective_scan_oracle, selective_scan_ref=O.selective_scan_oracle)
+
+    def flash_attn_func(q, k, v, causal=False):
+        assert not causal
+        return O.softmax_attention_oracle(q, k, v, softmax_scale=FLASH_SCALE["value"])
+
+    _mod("flash_attn", flash_attn_func=flash_attn_func)
+
+    _mod("dynamic_network_architectures")
+    _mod("dynamic_network_architectures.initialization")
+    _mod("dynamic_network_architectures.initialization.weight_init",
+         init_last_bn_before_add_to_0=None, InitWeights_He=None)
+    _mod("nnunetv2.training.nnUNetTrainer.nnUNetTrainer", nnUNetTrainer=type("nnUNetTrainer", (), {}))
+    _mod("nnunetv2.training.nnUNetTrainer.variants.network_architecture.nnUNetTrainerNoDeepSupervision",
+         nnUNetTrainerNoDeepSupervision=type("nnUNetTrainerNoDeepSupervision", (), {}))
+    _mod("nnunetv2.utilities.plans_handling.plans_handler", ConfigurationManager=object, PlansManager=object)
+
+
+def import_reference():
+    register_standins()
+    M = importlib.import_module("nnunetv2.training.nnUNetTrainer.variants.mamba.MambaSkip")
+    T = importlib.import_module("nnunetv2.training.nnUNetTrainer.nnUNetTrainer_MLAgg_2D_dt_MS")
+    return T, M
+
+
+def ref_model(T, img, n_cls=14):
+    m = T.MLLA_Uper(img_size=list(img), patch_size=2, in_channels=1, out_channels=n_cls, embed_dim=96,
+                    depths=[2, 2, 2, 2], num_heads=[2, 4, 8, 16], mlp_ratio=2, qkv_bias=True, drop_rate=0.,
+                    dropout_path_rate=0.1, sr_ratio=[16, 8, 4, 2], norm_layer=nn.LayerNorm, ape=False,
+                    use_checkpoint=False, deep_supervision=True)
+    O.deterministic_fill_(m.state_dict())
+    return m
+
+
+def grad_summary(model):
+    names, norms = [], []
+    for n, p in sorted(model.named_parameters()):
+        if p.grad is not None:
+            names.append(n)
+            norms.append(float(p.grad.double().norm()))
+    return names, np.asarray(norms, dtype=np.float64)
+
+
+def golden_full_model(T, variant):
+    FLASH_SCALE["value"] = None if variant == "A" else 1.0
+    img = (64, 64)
+    m = ref_model(T, img).eval()
+    data, target = O.synthetic_batch(1, 1, *img, 14, seed=1234)
+    out = m(data)
+    from nnunetv2.training.loss.compound_losses import DC_and_CE_loss
+    from nnunetv2.training.loss.deep_supervision import DeepSupervisionWrapper
+    from nnunetv2.training.loss.dice import MemoryEfficientSoftDiceLoss
+    base = DC_and_CE_loss({'batch_dice': True, 'smooth': 1e-5, 'do_bg': False, 'ddp': False}, {}, weight_ce=1,
+                          weight_dice=1, ignore_label=None, dice_class=MemoryEfficientSoftDiceLoss)
+    w = np.array([1 / (2 ** i) for i in range(5)])
+    loss = DeepSupervisionWrapper(base, w / w.sum())(out, target)
+    loss.backward()
+    names, norms = grad_summary(m)
+    small = {}
+    for n, p in m.named_parameters():
+        if p.grad is not None and (("lambda_" in n) or n.endswith(("dt_projs_bias", "Ds", "x_proj_weight",
+                                                                    "dt_projs_weight", "subln.weight"))):
+            small["grad/" + n] = p.grad.numpy().copy()
+    small["grad/A_logs"] = m.mambaskip.blocks[0].self_attention.A_logs.grad.numpy().copy()
+    np.savez_compressed(
+        os.path.join(HERE, f"full_model_64_variant{variant}.npz"),
+        img=np.asarray(img), batch=1, n_cls=14, data_seed=1234, weight_seed=0,
+        loss=float(loss), grad_names=np.asarray(names), grad_norms=norms,
+        **{f"out{i}": o.detach().numpy() for i, o in enumerate(out)}, **small)
+    print("full model", variant, float(loss), [tuple(o.shape) for o in out])
+
+
+def golden_mllablock(T, variant):
+    FLASH_SCALE["value"] = None if variant == "A" else 1.0
+    for tag, dim, res, heads, sr in (("s0", 96, (16, 16), 2, 4), ("s2", 384, (6, 8), 8, 2)):
+        blk = T.MLLABlock(dim=dim, input_resolution=res, num_heads=heads, mlp_ratio=2, qkv_bias=True, drop=0.,
+                          drop_path=0.0, sr_ratio=sr, norm_layer=nn.LayerNorm).eval()
+        O.deterministic_fill_(blk.state_dict(), seed=7)
+        g = torch.Generator().manual_seed(99)
+        x = torch.randn(2, dim, *res, generator=g).requires_grad_(True)
+        y = blk(x)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        names, norms = grad_summary(blk)
+        np.savez_compressed(os.path.join(HERE, f"mllablock_{tag}_variant{variant}.npz"), dim=dim, res=np.asarray(res),
+                            heads=heads, sr=sr, x=x.detach().numpy(), gy=gy.numpy(), y=y.detach().numpy(),
+                            gx=x.grad.numpy(), grad_names=np.asarray(names), grad_norms=norms)
+        print("mllablock", tag, variant, float(y.abs().mean()))
+
+
+def golden_msmm(M):
+    dims, hid = [96, 192, 384, 768], 48
+    shapes = [(12, 16), (6, 8), (3, 4), (2, 2)]
+    layer = M.VSS_Conv_Layer(dims, hid, depth=1, drop_path=0.1, use_checkpoint=False).eval()
+    O.deterministic_fill_(layer.state_dict(), seed=3)
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(2, c, h, w, generator=g).requires_grad_(True) for c, (h, w) in zip(dims, shapes)]
+    ys = layer(xs)
+    gys = [torch.randn(y.shape, generator=g) for y in ys]
+    torch.autograd.backward(ys, gys)
+    names, norms = grad_summary(layer)
+    sa = layer.blocks[0].self_attention
+    np.savez_compressed(
+        os.path.join(HERE, "msmm_nonsquare.npz"), shapes=np.asarray(shapes), grad_names=np.asarray(names),
+        grad_norms=norms,
+        **{f"x{i}": x.detach().numpy() for i, x in enumerate(xs)},
+        **{f"y{i}": y.detach().numpy() for i, y in enumerate(ys)},
+        **{f"gy{i}": t.numpy() for i, t in enumerate(gys)},
+        **{f"gx{i}": x.grad.numpy() for i, x in enumerate(xs)},
+        g_A_logs=sa.A_logs.grad.numpy(), g_Ds=sa.Ds.grad.numpy(), g_dt_bias=sa.dt_projs_bias.grad.numpy(),
+        g_x_proj=sa.x_proj_weight.grad.numpy(), g_dt_w=sa.dt_projs_weight.grad.numpy())
+    print("msmm", [float(y.abs().mean()) for y in ys])
+
+
+def golden_loss():
+    from nnunetv2.training.loss.compound_losses import DC_and_CE_loss
+    from nnunetv2.training.loss.deep_supervision import DeepSupervisionWrapper
+    from nnunetv2.training.loss.dice import MemoryEfficientSoftDiceLoss
+    g = torch.Generator().manual_seed(11)
+    vals = {}
+    for bd in (True, False):
+        base = DC_and_CE_loss({'batch_dice': bd, 'smooth': 1e-5, 'do_bg': False, 'ddp': False}, {}, weight_ce=1,
+                              weight_dice=1, ignore_label=None, dice_class=MemoryEfficientSoftDiceLoss)
+        w = np.array([1 / (2 ** i) for i in range(5)])
+        wrap = DeepSupervisionWrapper(base, w / w.sum())
+        g.manual_seed(11)
+        outs = [torch.randn(3, 5, 32 >> s, 32 >> s, generator=g) for s in range(5)]
+        tg = [torch.round(torch.rand(3, 1, 32 >> s, 32 >> s, generator=g) * 4) for s in range(5)]
+        vals[f"loss_batch_dice_{int(bd)}"] = float(wrap(outs, tg))
+    np.savez_compressed(os.path.join(HERE, "loss.npz"), seed=11, **vals)
+    print("loss", vals)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    T, M = import_reference()
+    golden_loss()
+    golden_msmm(M)
+    for v in ("B", "A"):
+        golden_mllablock(T, v)
+        golden_full_model(T, v)
