@@ -1,0 +1,125 @@
+/*
+ * mlagg_hip.h -- C ABI of libmlagg_hip.so (MI355X / gfx950 kernels for the MLAgg-UNet 2D hot path).
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + sizes, no torch types; every buffer is owned by the caller, the
+ *     library never allocates, frees or synchronises (safe inside hipGraph capture);
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream);
+ *   - return 0 on success, a negative MLAGG_E_* code for a rejected argument, or a positive
+ *     hipError_t from the launch.  The Python host turns any non-zero return into RuntimeError,
+ *     the only exception type nnU-Net handles
+ *     (mlagg/nnunetv2/training/nnUNetTrainer/variants/benchmarking/nnUNetTrainerBenchmark_5epochs.py:25-29);
+ *   - all tensors fp32, contiguous in the stated layout; re-entrant; callable from autograd's
+ *     backward thread.
+ */
+#ifndef MLAGG_HIP_H
+#define MLAGG_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLAGG_E_UNSUPPORTED (-1) /* shape outside what the kernels are built for */
+#define MLAGG_E_NULLPTR     (-2)
+#define MLAGG_E_WORKSPACE   (-3)
+
+const char *mlagg_version(void);
+const char *mlagg_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * K1: selective scan.  Replaces mamba-ssm's `selective_scan_cuda.fwd/bwd` behind
+ * `selective_scan_fn(u, delta, A, B, C, D, z=None, delta_bias, delta_softplus=True)` as called at
+ * mlagg/nnunetv2/training/nnUNetTrainer/variants/mamba/MambaSkip.py:445-451 (ABI mirrored at
+ * .../variants/mamba/vmamba/csms6s.py:224,235-238).
+ *   u, delta, out      (batch, dim, L)        dim = G * H, channel d uses group d / H
+ *   A                  (dim, N)               N must be 16
+ *   B, C               (batch, G, N, L)
+ *   D, delta_bias      (dim) or NULL
+ *   chunk_state        workspace AND saved-for-backward tensor, mlagg_selscan_state_floats() floats:
+ *                      [batch][nchunks][dim][N] states entering each 64-step chunk, followed by
+ *                      [batch][nchunks][dim] per-chunk sums of softplus'd delta.
+ * ------------------------------------------------------------------------------------------ */
+size_t mlagg_selscan_state_floats(int batch, int dim, int L, int N);
+int mlagg_selscan_fwd(const float *u, const float *delta, const float *A, const float *B, const float *C,
+                      const float *D, const float *delta_bias, float *out, float *chunk_state,
+                      int batch, int dim, int L, int N, int G, int delta_softplus, void *stream);
+
+/* Backward.  `workspace` needs mlagg_selscan_bwd_workspace_floats() floats (reverse chunk carries and
+ * per-chunk partial sums of dA / dD / ddelta_bias, reduced deterministically inside the call).
+ * dD / ddelta_bias may be NULL when D / delta_bias are NULL. */
+size_t mlagg_selscan_bwd_workspace_floats(int batch, int dim, int L, int N);
+int mlagg_selscan_bwd(const float *u, const float *delta, const float *A, const float *B, const float *C,
+                      const float *D, const float *delta_bias, const float *dout, const float *chunk_state,
+                      float *du, float *ddelta, float *dA, float *dB, float *dC, float *dD,
+                      float *ddelta_bias, float *workspace,
+                      int batch, int dim, int L, int N, int G, int delta_softplus, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3: 3x3-window differential attention + RMSNorm + LePE, the `local=True` branch of
+ * AggregatedAttention.forward (mlagg/.../nnUNetTrainer_MLAgg_2D_dt_MS.py:693-717, 779-782).
+ * Token-major inputs: q (batch, H*W, d) and kv (batch, H*W, 2d) straight out of the q / kv
+ * Linear layers (row strides in floats given explicitly, so strided views need no copy).
+ *   d = nh * 48, head h: q1 = q[.., 48h .. 48h+23], q2 = q[.., 48h+24 .. 48h+47]   (T:687, 712-713)
+ *   k likewise in kv[.., 0 .. d), v = kv[.., d + 48h .. d + 48h + 47]               (T:690, 702-703)
+ *   out[t, 48h+e] = 0.2 * w_subln[e] * rmsnorm_e( sum_j (s1_j - lam * s2_j) v_j[e] )
+ *                   + lepe_b[48h+e] + sum_j lepe_w[48h+e][j] v_j[48h+e]
+ *   s1 = softmax_j(scale * q1.k1_j), s2 = softmax_j(scale * q2.k2_j) over the in-image 3x3 window.
+ *   `lam` is read from device memory (1 float) so the call stays graph-capturable.
+ * ------------------------------------------------------------------------------------------ */
+int mlagg_local_attn_fwd(const float *q, int q_stride, const float *kv, int kv_stride,
+                         const float *lam, const float *subln_w, const float *lepe_w, const float *lepe_b,
+                         float *out, int out_stride, int batch, int H, int W, int nh, float scale,
+                         void *stream);
+/* Backward: gather form, no atomics on dq/dkv.  `workspace` = mlagg_local_attn_bwd_workspace_floats().
+ * dlam / dsubln_w / dlepe_w / dlepe_b are ACCUMULATED into (caller zero-fills). */
+size_t mlagg_local_attn_bwd_workspace_floats(int batch, int H, int W, int nh);
+int mlagg_local_attn_bwd(const float *q, int q_stride, const float *kv, int kv_stride,
+                         const float *lam, const float *subln_w, const float *lepe_w,
+                         const float *dout, int dout_stride,
+                         float *dq, int dq_stride, float *dkv, int dkv_stride,
+                         float *dlam, float *dsubln_w, float *dlepe_w, float *dlepe_b, float *workspace,
+                         int batch, int H, int W, int nh, float scale, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K4: pooled differential attention + RMSNorm, the `local=False` branch (T:733-760 variant A via
+ * flash_attn_func, T:762-777 variant B); supersedes the four `flash_attn_func(q_j, k_j, v_i)` calls.
+ *   q (batch, N, d) unscaled projection; kp, vp (batch, P, d) pooled keys / values (kv(x_) halves);
+ *   `scale` is the total logit scale: head_dim^-0.5 for variant B, 1/head_dim for variant A.
+ *   out[t, 48h+e] = 0.2 * w_subln[e] * rmsnorm_e( sum_p (s1_p - lam * s2_p) vp[p, 48h+e] )
+ * ------------------------------------------------------------------------------------------ */
+int mlagg_pooled_attn_fwd(const float *q, int q_stride, const float *kp, int kp_stride,
+                          const float *vp, int vp_stride, const float *lam, const float *subln_w,
+                          float *out, int out_stride,
+                          float *lse,   /* (batch, N, nh, 2) log-sum-exp of both maps, or NULL (inference) */
+                          float *o_pre, /* (batch, N, d) output before the RMSNorm, or NULL (inference) */
+                          int batch, int N, int P, int nh, float scale, void *stream);
+/* Backward needs the forward's lse / o_pre and mlagg_pooled_attn_bwd_workspace_floats() of scratch.
+ * dkp / dvp / dlam / dsubln_w are ACCUMULATED into (caller zero-fills). */
+size_t mlagg_pooled_attn_bwd_workspace_floats(int batch, int N, int nh);
+int mlagg_pooled_attn_bwd(const float *q, int q_stride, const float *kp, int kp_stride,
+                          const float *vp, int vp_stride, const float *lam, const float *subln_w,
+                          const float *dout, int dout_stride, const float *lse, const float *o_pre,
+                          float *dq, int dq_stride, float *dkp, int dkp_stride, float *dvp, int dvp_stride,
+                          float *dlam, float *dsubln_w, float *workspace,
+                          int batch, int N, int P, int nh, float scale, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2: depthwise 3x3 convolution (zero padding 1, stride 1) + bias (+ SiLU when `silu`), token-major
+ * x, y (batch, H*W, C) with row strides in floats; w (C, 9) = Conv2d weight (C, 1, 3, 3) flattened.
+ * Replaces nn.Conv2d(groups=C) at nnUNetTrainer_MLAgg_2D_dt_MS.py:890 (dwc + SiLU), T:781-782 (LePE of
+ * the pooled branch), MambaSkip.py:521-523 (conv2d + SiLU) and M:553 (ConvolutionalGLU.dwconv).
+ *   pre: (batch, H*W, C) contiguous pre-activation saved for backward when silu (NULL otherwise /
+ *        inference).  Backward ACCUMULATES into dw (C, 9) and dbias (C) (caller zero-fills).
+ * ------------------------------------------------------------------------------------------ */
+int mlagg_dwconv3x3_fwd(const float *x, int x_stride, const float *w, const float *bias, float *y,
+                        int y_stride, float *pre, int batch, int H, int W, int C, int silu, void *stream);
+int mlagg_dwconv3x3_bwd(const float *x, int x_stride, const float *w, const float *dy, int dy_stride,
+                        const float *pre, float *dx, int dx_stride, float *dw, float *dbias,
+                        int batch, int H, int W, int C, int silu, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLAGG_HIP_H */

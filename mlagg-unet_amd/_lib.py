@@ -1,0 +1,68 @@
+"""ctypes binding of libmlagg_hip.so (C ABI: include/mlagg_hip.h).
+
+There is no fallback: if the shared library is absent or a symbol is missing the import of any op
+raises, and every non-zero return code of an entry point becomes RuntimeError (the exception type
+nnU-Net's trainers handle, reference nnUNetTrainerBenchmark_5epochs.py:25-29)."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libmlagg_hip.so")
+
+_F = ctypes.c_void_p      # device pointer
+_I = ctypes.c_int
+_S = ctypes.c_void_p      # hipStream_t
+_SZ = ctypes.c_size_t
+_FL = ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/mlagg_hip.h one to one
+SIGNATURES = {
+    "mlagg_version": (ctypes.c_char_p, []),
+    "mlagg_error_string": (ctypes.c_char_p, [_I]),
+    "mlagg_selscan_state_floats": (_SZ, [_I, _I, _I, _I]),
+    "mlagg_selscan_fwd": (_I, [_F] * 9 + [_I] * 6 + [_S]),
+    "mlagg_selscan_bwd_workspace_floats": (_SZ, [_I, _I, _I, _I]),
+    "mlagg_selscan_bwd": (_I, [_F] * 17 + [_I] * 6 + [_S]),
+    "mlagg_local_attn_fwd": (_I, [_F, _I, _F, _I, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _FL, _S]),
+    "mlagg_local_attn_bwd_workspace_floats": (_SZ, [_I, _I, _I, _I]),
+    "mlagg_local_attn_bwd": (_I, [_F, _I, _F, _I, _F, _F, _F, _F, _I, _F, _I, _F, _I, _F, _F, _F, _F, _F,
+                                  _I, _I, _I, _I, _FL, _S]),
+    "mlagg_pooled_attn_fwd": (_I, [_F, _I, _F, _I, _F, _I, _F, _F, _F, _I, _F, _F, _I, _I, _I, _I, _FL, _S]),
+    "mlagg_pooled_attn_bwd_workspace_floats": (_SZ, [_I, _I, _I]),
+    "mlagg_pooled_attn_bwd": (_I, [_F, _I, _F, _I, _F, _I, _F, _F, _F, _I, _F, _F, _F, _I, _F, _I, _F, _I, _F, _F,
+                                   _F, _I, _I, _I, _I, _FL, _S]),
+    "mlagg_dwconv3x3_fwd": (_I, [_F, _I, _F, _F, _F, _I, _F, _I, _I, _I, _I, _I, _S]),
+    "mlagg_dwconv3x3_bwd": (_I, [_F, _I, _F, _F, _I, _F, _F, _I, _F, _F, _I, _I, _I, _I, _I, _S]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into csrc/libmlagg_hip.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j4"] + ([] if verbose else ["-s"])
+    subprocess.check_call(cmd)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(the MI355X ops have no CPU or eager fallback)")
+        handle = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().mlagg_error_string(int(code)).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {code})")

@@ -1,0 +1,175 @@
+// K2 -- depthwise 3x3 convolution (+ bias, optional fused SiLU) on token-major (B, H*W, C) maps.
+//
+// Replaces the NCHW depthwise Conv2d calls on the path, each of which the reference wraps in
+// permute/contiguous pairs because its token mixers live in (B, N, C): MLLABlock.dwc + SiLU
+// (nnUNetTrainer_MLAgg_2D_dt_MS.py:890), the pooled branch's LePE (T:781-782), SS2D_skip.conv2d + SiLU
+// (MambaSkip.py:521-523) and ConvolutionalGLU.dwconv (M:553).  Lane = channel, so every load and
+// store is a contiguous run of channels of one token (coalesced for any C that is a multiple of 4);
+// the 3x3 halo is re-read through L1/L2, never through HBM.
+//
+// HBM-bound: algorithmic bytes 8 * C * N per image forward (read x, write y).
+#include <hip/hip_runtime.h>
+
+#include "mlagg_hip.h"
+
+namespace {
+
+struct Geom {
+    int batch, H, W, C, x_stride, y_stride;
+};
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float dsilu_f(float x)
+{
+    const float s = 1.f / (1.f + __expf(-x));
+    return s * (1.f + x * (1.f - s));
+}
+
+// one thread: 4 consecutive channels of one token
+template <bool SILU>
+__global__ void __launch_bounds__(256)
+dwconv_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                  float *__restrict__ y, float *__restrict__ pre, Geom g)
+{
+    const int C4 = g.C >> 2;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = g.H * g.W;
+    if (idx >= (size_t)N * C4) return;
+    const int t = (int)(idx / C4), c = (int)(idx - (size_t)t * C4) * 4;
+    const int b = blockIdx.y;
+    const int yy0 = t / g.W, xx0 = t - yy0 * g.W;
+    float4 acc = bias ? *reinterpret_cast<const float4 *>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float wr[4][9];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) wr[e][j] = w[(c + e) * 9 + j];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int yy = yy0 + j / 3 - 1, xx = xx0 + j % 3 - 1;
+        if (yy < 0 || yy >= g.H || xx < 0 || xx >= g.W) continue;
+        const float4 v = *reinterpret_cast<const float4 *>(x + ((size_t)b * N + (size_t)yy * g.W + xx) * g.x_stride + c);
+        acc.x += wr[0][j] * v.x; acc.y += wr[1][j] * v.y; acc.z += wr[2][j] * v.z; acc.w += wr[3][j] * v.w;
+    }
+    const size_t o = ((size_t)b * N + t) * g.y_stride + c;
+    if (SILU) {
+        if (pre) *reinterpret_cast<float4 *>(pre + ((size_t)b * N + t) * g.C + c) = acc;
+        acc = make_float4(silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w));
+    }
+    *reinterpret_cast<float4 *>(y + o) = acc;
+}
+
+// dx[t] = sum_j w[8 - j] * g[t + off_j],  g = dy (* silu'(pre) when fused)
+template <bool SILU>
+__global__ void __launch_bounds__(256)
+dwconv_bwd_data_kernel(const float *__restrict__ dy, int dy_stride, const float *__restrict__ pre,
+                       const float *__restrict__ w, float *__restrict__ dx, int dx_stride, Geom g)
+{
+    const int C4 = g.C >> 2;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = g.H * g.W;
+    if (idx >= (size_t)N * C4) return;
+    const int t = (int)(idx / C4), c = (int)(idx - (size_t)t * C4) * 4;
+    const int b = blockIdx.y;
+    const int yy0 = t / g.W, xx0 = t - yy0 * g.W;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int yy = yy0 + j / 3 - 1, xx = xx0 + j % 3 - 1;
+        if (yy < 0 || yy >= g.H || xx < 0 || xx >= g.W) continue;
+        const size_t ti = (size_t)b * N + (size_t)yy * g.W + xx;
+        float4 gv = *reinterpret_cast<const float4 *>(dy + ti * dy_stride + c);
+        if (SILU) {
+            const float4 p = *reinterpret_cast<const float4 *>(pre + ti * g.C + c);
+            gv.x *= dsilu_f(p.x); gv.y *= dsilu_f(p.y); gv.z *= dsilu_f(p.z); gv.w *= dsilu_f(p.w);
+        }
+        const int jw = 8 - j;
+        acc.x += w[(c + 0) * 9 + jw] * gv.x; acc.y += w[(c + 1) * 9 + jw] * gv.y;
+        acc.z += w[(c + 2) * 9 + jw] * gv.z; acc.w += w[(c + 3) * 9 + jw] * gv.w;
+    }
+    *reinterpret_cast<float4 *>(dx + ((size_t)b * N + t) * dx_stride + c) = acc;
+}
+
+// dw[c][j] = sum_{b,t} g[t] x[t + off_j], dbias[c] = sum g[t]; lane = channel, a workgroup sweeps a
+// token chunk and finishes with 10 atomics per channel.
+constexpr int WG_TOK = 256;
+template <bool SILU>
+__global__ void dwconv_bwd_weight_kernel(const float *__restrict__ x, const float *__restrict__ dy, int dy_stride,
+                                         const float *__restrict__ pre, float *__restrict__ dw,
+                                         float *__restrict__ dbias, Geom g)
+{
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= g.C) return;
+    const int N = g.H * g.W, b = blockIdx.z;
+    const int t_begin = blockIdx.x * WG_TOK, t_end = min(t_begin + WG_TOK, N);
+    float gw[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float gb = 0.f;
+    for (int t = t_begin; t < t_end; ++t) {
+        const int yy0 = t / g.W, xx0 = t - yy0 * g.W;
+        float gv = dy[((size_t)b * N + t) * dy_stride + c];
+        if (SILU) gv *= dsilu_f(pre[((size_t)b * N + t) * g.C + c]);
+        gb += gv;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int yy = yy0 + j / 3 - 1, xx = xx0 + j % 3 - 1;
+            if (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W)
+                gw[j] += gv * x[((size_t)b * N + (size_t)yy * g.W + xx) * g.x_stride + c];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) atomicAdd(dw + c * 9 + j, gw[j]);
+    if (dbias) atomicAdd(dbias + c, gb);
+}
+
+int make_geom(Geom &g, int batch, int H, int W, int C, int xs, int ys)
+{
+    if (batch <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || batch > 65535) return MLAGG_E_UNSUPPORTED;
+    if (xs < C || ys < C || (xs & 3) || (ys & 3)) return MLAGG_E_UNSUPPORTED;
+    g.batch = batch; g.H = H; g.W = W; g.C = C; g.x_stride = xs; g.y_stride = ys;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mlagg_dwconv3x3_fwd(const float *x, int x_stride, const float *w, const float *bias, float *y,
+                                   int y_stride, float *pre, int batch, int H, int W, int C, int silu,
+                                   void *stream)
+{
+    if (!x || !w || !y) return MLAGG_E_NULLPTR;
+    Geom g;
+    if (int rc = make_geom(g, batch, H, W, C, x_stride, y_stride)) return rc;
+    const size_t total = (size_t)H * W * (C / 4);
+    const dim3 grid((unsigned)((total + 255) / 256), batch), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (silu)
+        hipLaunchKernelGGL(dwconv_fwd_kernel<true>, grid, block, 0, st, x, w, bias, y, pre, g);
+    else
+        hipLaunchKernelGGL(dwconv_fwd_kernel<false>, grid, block, 0, st, x, w, bias, y, pre, g);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mlagg_dwconv3x3_bwd(const float *x, int x_stride, const float *w, const float *dy, int dy_stride,
+                                   const float *pre, float *dx, int dx_stride, float *dw, float *dbias, int batch,
+                                   int H, int W, int C, int silu, void *stream)
+{
+    if (!x || !w || !dy || !dx || !dw || (silu && !pre)) return MLAGG_E_NULLPTR;
+    Geom g;
+    if (int rc = make_geom(g, batch, H, W, C, x_stride, dx_stride)) return rc;
+    if (dy_stride < C || (dy_stride & 3)) return MLAGG_E_UNSUPPORTED;
+    const size_t total = (size_t)H * W * (C / 4);
+    const dim3 grid((unsigned)((total + 255) / 256), batch), block(256);
+    const int cthreads = C < 256 ? ((C + 63) / 64) * 64 : 256;
+    const dim3 wgrid((H * W + WG_TOK - 1) / WG_TOK, (C + cthreads - 1) / cthreads, batch);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (silu) {
+        hipLaunchKernelGGL(dwconv_bwd_data_kernel<true>, grid, block, 0, st, dy, dy_stride, pre, w, dx, dx_stride, g);
+        hipLaunchKernelGGL(dwconv_bwd_weight_kernel<true>, wgrid, dim3(cthreads), 0, st, x, dy, dy_stride, pre, dw,
+                           dbias, g);
+    } else {
+        hipLaunchKernelGGL(dwconv_bwd_data_kernel<false>, grid, block, 0, st, dy, dy_stride, pre, w, dx, dx_stride,
+                           g);
+        hipLaunchKernelGGL(dwconv_bwd_weight_kernel<false>, wgrid, dim3(cthreads), 0, st, x, dy, dy_stride, pre, dw,
+                           dbias, g);
+    }
+    return (int)hipGetLastError();
+}

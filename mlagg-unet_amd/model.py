@@ -1,0 +1,515 @@
+"""MLAgg-UNet 2D network for MI355X: the module tree behind
+``nnUNetTrainer_MLAgg_2D_dt_MS.build_network_architecture`` (reference
+nnUNetTrainer_MLAgg_2D_dt_MS.py:62-92, 1183-1407) with the token mixers on hand-written HIP kernels.
+
+What runs where:
+  * HIP (libmlagg_hip.so): K1 selective scan of the MSMM skip module, K2 depthwise 3x3 (+SiLU) on
+    token-major maps, K3 3x3-window differential attention (+RMSNorm+LePE), K4 pooled differential
+    attention (+RMSNorm);
+  * PyTorch-ROCm (rocBLAS / MIOpen / ATen): Linear layers, full convolutions of the stem, the
+    down/up blocks, the decoder and the heads, LayerNorm/GroupNorm/InstanceNorm.
+Module and parameter names equal the reference's, so checkpoints (525 state_dict keys) load either
+way.  There is no eager fallback for the HIP ops: on a machine without the library the forward raises.
+
+Layout choice: the encoder keeps activations token-major (B, N, C) across both MLLA blocks of a
+stage (the reference flips NCHW <-> NLC per block and again around every depthwise conv); NCHW is
+produced once per stage for the MIOpen convolutions that consume the stage output.
+"""
+import math
+from typing import List, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+LAMBDA_INIT = 0.8
+
+
+class DropPath(nn.Module):
+    """Per-sample stochastic depth (timm semantics; reference T:868, M:688)."""
+
+    def __init__(self, p: float = 0.0):
+        super().__init__()
+        self.drop_prob = float(p)
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = torch.empty((x.shape[0],) + (1,) * (x.dim() - 1), device=x.device, dtype=x.dtype).bernoulli_(keep)
+        return x * (mask / keep)
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x)))
+
+
+class RMSNormWeight(nn.Module):
+    """Holds ``subln.weight`` (the normalisation itself is fused into K3 / K4)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+
+
+class AggregatedAttention(nn.Module):
+    """Reference T:625-784 on token-major input.  ``variant`` "B": logit scale head_dim^-0.5 (fp32 path,
+    T:762-777); "A": 1/head_dim, the shipped flash path's double scaling (T:688 + T:745-750)."""
+
+    def __init__(self, dim, input_resolution, num_heads, local, sr_ratio, variant="B"):
+        super().__init__()
+        self.dim, self.num_heads, self.local, self.variant = dim, num_heads, local, variant
+        self.head_dim = dim // num_heads // 2
+        if self.head_dim != 24:
+            raise RuntimeError("the gfx950 attention kernels are built for head_dim 24 (every MLAgg-UNet stage)")
+        self.scale = self.head_dim ** -0.5
+        for nm in ("lambda_q1", "lambda_k1", "lambda_q2", "lambda_k2"):
+            setattr(self, nm, nn.Parameter(torch.zeros(self.head_dim).normal_(0, 0.1)))
+        self.subln = RMSNormWeight(2 * self.head_dim)
+        self.H, self.W = input_resolution
+        if not local:
+            self.sr_ratio = sr_ratio
+            self.pool_H, self.pool_W = self.H // sr_ratio, self.W // sr_ratio
+            self.sr = nn.Conv2d(dim, dim, 1)
+            self.norm = nn.LayerNorm(dim)
+        self.q = nn.Linear(dim, dim)
+        self.kv = nn.Linear(dim, 2 * dim)
+        self.lepe = nn.Conv2d(dim, dim, 3, padding=1, groups=dim)
+
+    def lambda_full(self):
+        l1 = torch.exp(torch.sum(self.lambda_q1 * self.lambda_k1))
+        l2 = torch.exp(torch.sum(self.lambda_q2 * self.lambda_k2))
+        return l1 - l2 + LAMBDA_INIT
+
+    def forward(self, x):
+        """x: (B, N, dim) (may be a channel slice of a wider row) -> (B, N, dim)."""
+        B, N, d = x.shape
+        lam = self.lambda_full()
+        q = self.q(x)
+        if self.local:
+            kv = self.kv(x)
+            return ops.local_diff_attn(q, kv, lam, self.subln.weight, self.lepe.weight, self.lepe.bias,
+                                       self.H, self.W, self.num_heads, self.scale)
+        # only the value half of kv(x) is used at full resolution (LePE); k is discarded at T:719
+        v_full = F.linear(x, self.kv.weight[d:], self.kv.bias[d:])
+        s = F.gelu(F.linear(x, self.sr.weight.view(d, d), self.sr.bias))
+        if self.H % self.sr_ratio == 0 and self.W % self.sr_ratio == 0:
+            r = self.sr_ratio
+            pooled = s.view(B, self.pool_H, r, self.pool_W, r, d).mean(dim=(2, 4)).reshape(B, -1, d)
+        else:
+            img = s.view(B, self.H, self.W, d).permute(0, 3, 1, 2)
+            pooled = F.adaptive_avg_pool2d(img, (self.pool_H, self.pool_W)).flatten(2).transpose(1, 2)
+        kvp = self.kv(self.norm(pooled))
+        scale = self.scale if self.variant == "B" else self.scale * self.scale
+        o = ops.pooled_diff_attn(q, kvp[..., :d], kvp[..., d:], lam, self.subln.weight, self.num_heads, scale)
+        return o + ops.dwconv3x3_nlc(v_full, self.lepe.weight, self.lepe.bias, self.H, self.W, silu=False)
+
+
+class MLLABlock(nn.Module):
+    """Reference T:824-915.  ``forward`` keeps the reference's NCHW contract; stages call ``forward_tokens``."""
+
+    def __init__(self, dim, input_resolution, num_heads, mlp_ratio, drop_path, sr_ratio, variant="B"):
+        super().__init__()
+        self.dim, self.input_resolution = dim, tuple(input_resolution)
+        self.norm1 = nn.LayerNorm(dim)
+        self.in_proj = nn.Linear(dim, dim)
+        self.act_proj = nn.Linear(dim, dim)
+        self.dwc = nn.Conv2d(dim, dim, 3, padding=1, groups=dim)
+        self.attn = nn.ModuleList([
+            AggregatedAttention(dim // 2, input_resolution, num_heads // 2, True, sr_ratio, variant),
+            AggregatedAttention(dim // 2, input_resolution, num_heads // 2, False, sr_ratio, variant)])
+        self.out_proj = nn.Linear(dim, dim)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+    def forward_tokens(self, x):
+        H, W = self.input_resolution
+        C = self.dim
+        xn = self.norm1(x)
+        act_res = F.silu(self.act_proj(xn))
+        xc = ops.dwconv3x3_nlc(self.in_proj(xn), self.dwc.weight, self.dwc.bias, H, W, silu=True)
+        mixed = torch.cat([self.attn[0](xc[..., :C // 2]), self.attn[1](xc[..., C // 2:])], dim=-1)
+        x = x + self.drop_path(self.out_proj(mixed * act_res))
+        return x + self.drop_path(self.mlp(self.norm2(x)))
+
+    def forward(self, x):
+        B, C, h, w = x.shape
+        if (h, w) != self.input_resolution:
+            raise RuntimeError("input feature has wrong size")
+        y = self.forward_tokens(x.flatten(2).transpose(1, 2))
+        return y.transpose(1, 2).reshape(B, C, h, w)
+
+
+class BasicLayer(nn.Module):
+    def __init__(self, dim, input_resolution, depth, num_heads, mlp_ratio, drop_path, sr_ratio, variant):
+        super().__init__()
+        self.blocks = nn.ModuleList([
+            MLLABlock(dim, input_resolution, num_heads, mlp_ratio, drop_path[i], sr_ratio, variant)
+            for i in range(depth)])
+
+    def forward(self, x):
+        B, C, h, w = x.shape
+        t = x.flatten(2).transpose(1, 2)          # one NCHW -> NLC per stage
+        for blk in self.blocks:
+            t = blk.forward_tokens(t)
+        return t.transpose(1, 2).reshape(B, C, h, w).contiguous()
+
+
+class Project(nn.Module):  # reference T:972-1001
+    def __init__(self, cin, cout, stride, last):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride=stride, padding=1)
+        self.conv2 = nn.Conv2d(cout, cout, 3, stride=1, padding=1)
+        self.norm1 = nn.LayerNorm(cout)
+        self.last = last
+        if not last:
+            self.norm2 = nn.LayerNorm(cout)
+
+    @staticmethod
+    def _ln(norm, x):
+        return norm(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2).contiguous()
+
+    def forward(self, x):
+        x = self.conv2(self._ln(self.norm1, F.gelu(self.conv1(x))))
+        return x if self.last else self._ln(self.norm2, F.gelu(x))
+
+
+class PatchEmbed(nn.Module):  # reference T:1004-1043
+    def __init__(self, patch_size, in_chans, embed_dim):
+        super().__init__()
+        self.proj1 = Project(in_chans, embed_dim // 2, (2, 2), last=False)
+        self.proj2 = Project(embed_dim // 2, embed_dim, (patch_size // 2, patch_size // 2), last=True)
+
+    def forward(self, x):
+        return self.proj2(self.proj1(x))
+
+
+class MedNeXtBlock(nn.Module):  # reference T:230-324
+    def __init__(self, cin, cout, exp_r, k=3, do_res=True, stride=1):
+        super().__init__()
+        self.do_res = do_res
+        self.conv1 = nn.Conv2d(cin, cin, k, stride=stride, padding=k // 2, groups=cin)
+        self.norm = nn.GroupNorm(cin, cin)
+        self.conv2 = nn.Conv2d(cin, exp_r * cin, 1)
+        self.conv3 = nn.Conv2d(exp_r * cin, cout, 1)
+
+    def body(self, x):
+        return self.conv3(F.gelu(self.conv2(self.norm(self.conv1(x)))))
+
+    def forward(self, x):
+        y = self.body(x)
+        return x + y if self.do_res else y
+
+
+class MedNeXtDownBlock(MedNeXtBlock):  # reference T:327-366
+    def __init__(self, cin, cout, exp_r, k=3):
+        super().__init__(cin, cout, exp_r, k, do_res=False, stride=2)
+        self.res_conv = nn.Conv2d(cin, cout, 1, stride=2)
+
+    def forward(self, x):
+        return self.body(x) + self.res_conv(x)
+
+
+class PatchExpand(nn.Module):  # reference T:479-546
+    def __init__(self, cin, cout, k=3):
+        super().__init__()
+        self.res_conv = nn.ConvTranspose2d(cin, cout, 1, stride=2)
+        self.conv1 = nn.ConvTranspose2d(cin, cout, k, stride=2, padding=k // 2)
+        self.norm = nn.GroupNorm(cin, cin)
+
+    def forward(self, x):
+        return F.pad(self.conv1(self.norm(x)) , (1, 0, 1, 0)) + F.pad(self.res_conv(x), (1, 0, 1, 0))
+
+
+class OutBlock(nn.Module):  # reference T:549-561
+    def __init__(self, cin, n_classes):
+        super().__init__()
+        self.conv_out = nn.ConvTranspose2d(cin, n_classes, 1)
+
+    def forward(self, x):
+        return self.conv_out(x)
+
+
+class _ConvOnly(nn.Module):
+    def __init__(self, cin, cout, k, stride=1, transposed=False):
+        super().__init__()
+        if transposed:
+            self.conv = nn.ConvTranspose2d(cin, cout, k, stride=stride, bias=False)
+        else:
+            self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class UnetResBlock(nn.Module):
+    """MONAI 1.3.0 UnetResBlock semantics (structure vendored in the reference at M:581-667)."""
+
+    def __init__(self, cin, cout, k=3):
+        super().__init__()
+        self.conv1 = _ConvOnly(cin, cout, k)
+        self.conv2 = _ConvOnly(cout, cout, k)
+        self.norm1 = nn.InstanceNorm2d(cout)
+        self.norm2 = nn.InstanceNorm2d(cout)
+        if cin != cout:
+            self.conv3 = _ConvOnly(cin, cout, 1)
+            self.norm3 = nn.InstanceNorm2d(cout)
+
+    def forward(self, x):
+        out = F.leaky_relu(self.norm1(self.conv1(x)), 0.01)
+        out = self.norm2(self.conv2(out))
+        res = self.norm3(self.conv3(x)) if hasattr(self, "conv3") else x
+        return F.leaky_relu(out + res, 0.01)
+
+
+class UnetrBasicBlock(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.layer = UnetResBlock(cin, cout)
+
+    def forward(self, x):
+        return self.layer(x)
+
+
+class UnetrUpBlock(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.transp_conv = _ConvOnly(cin, cout, 2, stride=2, transposed=True)
+        self.conv_block = UnetResBlock(2 * cout, cout)
+
+    def forward(self, x, skip):
+        return self.conv_block(torch.cat([self.transp_conv(x), skip], dim=1))
+
+
+class MLLA_Enc(nn.Module):  # reference T:1046-1179
+    def __init__(self, img_size, patch_size, in_chans, embed_dim, depths, num_heads, mlp_ratio, drop_path_rate,
+                 sr_ratio, variant):
+        super().__init__()
+        self.num_layers = len(depths)
+        res = [s // patch_size for s in img_size]
+        self.patch_embed = PatchEmbed(patch_size, in_chans, embed_dim)
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.layers = nn.ModuleList([
+            BasicLayer(embed_dim * 2 ** i, (res[0] // 2 ** i, res[1] // 2 ** i), depths[i], num_heads[i], mlp_ratio,
+                       dpr[sum(depths[:i]):sum(depths[:i + 1])], sr_ratio[i], variant)
+            for i in range(self.num_layers)])
+        self.downs = nn.ModuleList([
+            MedNeXtDownBlock(embed_dim * 2 ** i, embed_dim * 2 ** (i + 1), mlp_ratio)
+            for i in range(self.num_layers - 1)])
+
+    def forward(self, x):
+        outs = [x]
+        x = self.patch_embed(x)
+        for i, layer in enumerate(self.layers):
+            x = layer(x)
+            outs.append(x)
+            if i < self.num_layers - 1:
+                x = self.downs[i](x)
+        return outs
+
+
+# ------------------------------------------------------------------------------------------------
+# MSMM skip module (reference MambaSkip.py:266-577, 669-804)
+# ------------------------------------------------------------------------------------------------
+def _dt_init(dt_rank, d_inner, dt_min=0.001, dt_max=0.1, floor=1e-4):
+    proj = nn.Linear(dt_rank, d_inner, bias=True)
+    std = dt_rank ** -0.5
+    nn.init.uniform_(proj.weight, -std, std)
+    dt = torch.exp(torch.rand(d_inner) * (math.log(dt_max) - math.log(dt_min)) + math.log(dt_min)).clamp(min=floor)
+    with torch.no_grad():
+        proj.bias.copy_(dt + torch.log(-torch.expm1(-dt)))
+    return proj
+
+
+class SS2D_skip(nn.Module):
+    def __init__(self, stage_num, d_model, d_state=16, expand=2):
+        super().__init__()
+        self.d_model, self.d_state = d_model, d_state
+        self.d_inner = int(expand * d_model)
+        self.dt_rank = math.ceil(d_model / 16)
+        self.in_proj = nn.Linear(d_model, self.d_inner, bias=False)
+        self.conv2d = nn.ModuleList([
+            nn.Conv2d(self.d_inner, self.d_inner, 3, padding=1, groups=self.d_inner) for _ in range(stage_num)])
+        xp = [nn.Linear(self.d_inner, self.dt_rank + 2 * d_state, bias=False) for _ in range(4)]
+        self.x_proj_weight = nn.Parameter(torch.stack([t.weight for t in xp], 0))
+        dts = [_dt_init(self.dt_rank, self.d_inner) for _ in range(4)]
+        self.dt_projs_weight = nn.Parameter(torch.stack([t.weight for t in dts], 0))
+        self.dt_projs_bias = nn.Parameter(torch.stack([t.bias for t in dts], 0))
+        A = torch.arange(1, d_state + 1, dtype=torch.float32).repeat(4 * self.d_inner, 1)
+        self.A_logs = nn.Parameter(torch.log(A))
+        self.Ds = nn.Parameter(torch.ones(4 * self.d_inner))
+        self.out_norm = nn.LayerNorm(self.d_inner)
+        self.out_proj = nn.Linear(self.d_inner, d_model, bias=False)
+
+    def core(self, xs_tok: List[torch.Tensor], HW):
+        """xs_tok[i]: (B, H_i*W_i, d_inner) token-major conv outputs -> (B, L_cat, d_inner) sum of the four
+        re-ordered scan directions (reference M:405-473, 534)."""
+        B = xs_tok[0].shape[0]
+        K, dI = 4, self.d_inner
+        seqs, Ls = [], []
+        for xi, (H, W) in zip(xs_tok, HW):
+            L = H * W
+            row = xi.transpose(1, 2)                                              # (B, d, L) row-major order
+            col = xi.view(B, H, W, dI).permute(0, 3, 2, 1).reshape(B, dI, L)      # column-major order
+            both = torch.stack([row, col], dim=1)
+            seqs.append(torch.cat([both, both.flip(-1)], dim=1))                  # (B, 4, d, L)
+            Ls.append(L)
+        xs = torch.cat(seqs, dim=-1).contiguous()
+        Lc = xs.shape[-1]
+        x_dbl = torch.einsum("bkdl,kcd->bkcl", xs, self.x_proj_weight)
+        dts, Bs, Cs = torch.split(x_dbl, [self.dt_rank, self.d_state, self.d_state], dim=2)
+        dts = torch.einsum("bkrl,kdr->bkdl", dts, self.dt_projs_weight)
+        out = ops.selective_scan_fn(
+            xs.view(B, K * dI, Lc), dts.reshape(B, K * dI, Lc), -torch.exp(self.A_logs), Bs.contiguous(),
+            Cs.contiguous(), self.Ds, z=None, delta_bias=self.dt_projs_bias.reshape(-1), delta_softplus=True,
+            return_last_state=False).view(B, K, dI, Lc)
+        merged = []
+        off = 0
+        for (H, W), L in zip(HW, Ls):
+            o = out[..., off:off + L]
+            off += L
+            y = o[:, 0] + o[:, 2].flip(-1)                                         # row-major pair
+            yc = o[:, 1] + o[:, 3].flip(-1)                                        # column-major pair
+            y = y + yc.view(B, dI, W, H).transpose(2, 3).reshape(B, dI, L)
+            merged.append(y)
+        return torch.cat(merged, dim=-1).transpose(1, 2)                           # (B, L_cat, d) view
+
+    def forward(self, x, HW, L_split):
+        """x: (B, L_cat, d_model) -> (B, L_cat, d_model)."""
+        x = self.in_proj(x)
+        toks = []
+        off = 0
+        for i, ((H, W), L) in enumerate(zip(HW, L_split)):
+            toks.append(ops.dwconv3x3_nlc(x[:, off:off + L], self.conv2d[i].weight, self.conv2d[i].bias, H, W,
+                                          silu=True))
+            off += L
+        return self.out_proj(self.out_norm(self.core(toks, HW)))
+
+
+class _DWConv(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.dwconv = nn.Conv2d(dim, dim, 3, padding=1, groups=dim)
+
+
+class ConvolutionalGLU(nn.Module):  # reference M:559-577
+    def __init__(self, dim, hidden):
+        super().__init__()
+        hidden = int(2 * hidden / 3)
+        self.hidden = hidden
+        self.fc1 = nn.Linear(dim, hidden * 2)
+        self.dwconv = _DWConv(hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x, H, W):
+        xv = self.fc1(x)
+        g = ops.dwconv3x3_nlc(xv[..., :self.hidden], self.dwconv.dwconv.weight, self.dwconv.dwconv.bias, H, W,
+                              silu=True)
+        return self.fc2(g * xv[..., self.hidden:])
+
+
+class VSS_Conv_Block(nn.Module):  # reference M:669-753
+    def __init__(self, feature_dims, hidden_dim, drop_path):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.conv_dims = [c - hidden_dim for c in feature_dims]
+        self.ln_1 = nn.LayerNorm(hidden_dim)
+        self.self_attention = SS2D_skip(len(feature_dims), hidden_dim)
+        self.drop_path = DropPath(drop_path)
+        self.norm2 = nn.LayerNorm(hidden_dim)
+        self.mlps = nn.ModuleList([ConvolutionalGLU(hidden_dim, hidden_dim * 4) for _ in feature_dims])
+        self.conv_branches = nn.ModuleList([
+            nn.Sequential(nn.Conv2d(c, c, 3, padding=1), nn.InstanceNorm2d(c, affine=True), nn.SiLU())
+            for c in self.conv_dims])
+
+    def forward(self, inputs):
+        B = inputs[0].shape[0]
+        HW = [(t.shape[2], t.shape[3]) for t in inputs]
+        Ls = [h * w for h, w in HW]
+        hd = self.hidden_dim
+        m = torch.cat([t[:, :hd].flatten(2) for t in inputs], dim=-1).transpose(1, 2)    # (B, L_cat, 48)
+        m = m + self.drop_path(self.self_attention(self.ln_1(m), HW, Ls))
+        m = self.norm2(m)
+        outs = []
+        off = 0
+        for i, ((H, W), L) in enumerate(zip(HW, Ls)):
+            mi = m[:, off:off + L]
+            off += L
+            mi = mi + self.drop_path(self.mlps[i](mi, H, W))
+            mi = mi.transpose(1, 2).reshape(B, hd, H, W)
+            outs.append(torch.cat([mi, self.conv_branches[i](inputs[i][:, hd:])], dim=1))
+        return outs
+
+
+class VSS_Conv_Layer(nn.Module):  # reference M:756-804
+    def __init__(self, feature_dims, hidden_dim, depth=1, drop_path=0.0):
+        super().__init__()
+        self.blocks = nn.ModuleList([VSS_Conv_Block(feature_dims, hidden_dim, drop_path) for _ in range(depth)])
+
+    def forward(self, x):
+        for blk in self.blocks:
+            x = blk(x)
+        return x
+
+
+class MLLA_Uper(nn.Module):  # reference T:1183-1407
+    def __init__(self, img_size: Sequence[int], patch_size=2, in_channels=1, out_channels=14, embed_dim=96,
+                 depths=(2, 2, 2, 2), num_heads=(2, 4, 8, 16), mlp_ratio=2, dropout_path_rate=0.1,
+                 sr_ratio=(16, 8, 4, 2), deep_supervision=True, variant="B"):
+        super().__init__()
+        self.deep_supervision = deep_supervision
+        E = embed_dim
+        self.mlla = MLLA_Enc(list(img_size), patch_size, in_channels, E, list(depths), list(num_heads), mlp_ratio,
+                             dropout_path_rate, list(sr_ratio), variant)
+        self.mambaskip = VSS_Conv_Layer([E, 2 * E, 4 * E, 8 * E], E // 2, depth=1, drop_path=0.1)
+        self.up_2 = PatchExpand(8 * E, 4 * E)
+        self.dec_block_2 = nn.Sequential(*[MedNeXtBlock(4 * E, 4 * E, mlp_ratio) for _ in range(depths[-2])])
+        self.up_1 = PatchExpand(4 * E, 2 * E)
+        self.dec_block_1 = nn.Sequential(*[MedNeXtBlock(2 * E, 2 * E, mlp_ratio) for _ in range(depths[-3])])
+        self.up_0 = PatchExpand(2 * E, E)
+        self.dec_block_0 = nn.Sequential(*[MedNeXtBlock(E, E, mlp_ratio) for _ in range(depths[-4])])
+        self.encoder0 = UnetrBasicBlock(in_channels, E // 2)
+        self.decoder0 = UnetrUpBlock(E, E // 2)
+        self.out_0 = OutBlock(E // 2, out_channels)
+        # unused in forward (reference T:1362); excluded from DDP reduction, see trainer.wrap_ddp
+        self.dummy_tensor = nn.Parameter(torch.tensor([1.0]))
+        if deep_supervision:
+            self.out_1 = OutBlock(E, out_channels)
+            self.out_2 = OutBlock(2 * E, out_channels)
+            self.out_3 = OutBlock(4 * E, out_channels)
+            self.out_4 = OutBlock(8 * E, out_channels)
+
+    def forward(self, x_in):
+        hs = self.mlla(x_in)
+        hs[1:] = self.mambaskip(hs[1:])
+        ds = self.deep_supervision
+        if ds:
+            y4 = self.out_4(hs[4])
+        x = self.dec_block_2(hs[3] + self.up_2(hs[4]))
+        if ds:
+            y3 = self.out_3(x)
+        x = self.dec_block_1(hs[2] + self.up_1(x))
+        if ds:
+            y2 = self.out_2(x)
+        x = self.dec_block_0(hs[1] + self.up_0(x))
+        if ds:
+            y1 = self.out_1(x)
+        x = self.out_0(self.decoder0(x, self.encoder0(hs[0])))
+        return [x, y1, y2, y3, y4] if ds else x
+
+
+def build_network_architecture(patch_size, num_input_channels, num_segmentation_heads, enable_deep_supervision=True,
+                               variant="B"):
+    """The hyper-parameters hard-coded at reference T:71-89; arguments are the only values that reach
+    the model from the plans (patch_size, #channels, #classes)."""
+    return MLLA_Uper(tuple(patch_size), 2, num_input_channels, num_segmentation_heads, 96, (2, 2, 2, 2),
+                     (2, 4, 8, 16), 2, 0.1, (16, 8, 4, 2), enable_deep_supervision, variant)

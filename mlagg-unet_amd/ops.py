@@ -1,0 +1,218 @@
+"""torch.autograd.Function wrappers over the C ABI (include/mlagg_hip.h).
+
+PyTorch is plumbing here: device memory, the current HIP stream and autograd bookkeeping.  Every
+op requires CUDA(HIP) fp32 tensors and raises RuntimeError otherwise -- there is no eager path.
+"""
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require(t, name, shape=None):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+        raise RuntimeError(f"{name}: expected a float32 tensor on the MI355X device, got "
+                           f"{getattr(t, 'dtype', type(t))} on {getattr(t, 'device', '?')}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise RuntimeError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+class SelectiveScanFn(torch.autograd.Function):
+    """K1.  Same contract as mamba-ssm's SelectiveScanFn as used at MambaSkip.py:445-451."""
+
+    @staticmethod
+    def forward(ctx, u, delta, A, B, C, D, delta_bias, delta_softplus):
+        b, d, L = u.shape
+        n, g = A.shape[1], B.shape[1]
+        u = _require(u.contiguous(), "u")
+        delta = _require(delta.contiguous(), "delta", (b, d, L))
+        A = _require(A.contiguous(), "A", (d, n))
+        B = _require(B.contiguous(), "B", (b, g, n, L))
+        C = _require(C.contiguous(), "C", (b, g, n, L))
+        D = None if D is None else _require(D.contiguous(), "D", (d,))
+        delta_bias = None if delta_bias is None else _require(delta_bias.contiguous(), "delta_bias", (d,))
+        lib = _lib.lib()
+        out = torch.empty_like(u)
+        state = torch.empty(lib.mlagg_selscan_state_floats(b, d, L, n), device=u.device, dtype=torch.float32)
+        _lib.check(lib.mlagg_selscan_fwd(_ptr(u), _ptr(delta), _ptr(A), _ptr(B), _ptr(C), _ptr(D),
+                                         _ptr(delta_bias), _ptr(out), _ptr(state), b, d, L, n, g,
+                                         int(bool(delta_softplus)), _stream()), "mlagg_selscan_fwd")
+        ctx.save_for_backward(u, delta, A, B, C, D, delta_bias, state)
+        ctx.delta_softplus = bool(delta_softplus)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        u, delta, A, B, C, D, delta_bias, state = ctx.saved_tensors
+        b, d, L = u.shape
+        n, g = A.shape[1], B.shape[1]
+        dout = _require(dout.contiguous(), "dout", (b, d, L))
+        lib = _lib.lib()
+        du, ddelta = torch.empty_like(u), torch.empty_like(u)
+        dA, dB, dC = torch.empty_like(A), torch.empty_like(B), torch.empty_like(C)
+        dD = None if D is None else torch.empty_like(D)
+        dbias = None if delta_bias is None else torch.empty_like(delta_bias)
+        ws = torch.empty(lib.mlagg_selscan_bwd_workspace_floats(b, d, L, n), device=u.device, dtype=torch.float32)
+        _lib.check(lib.mlagg_selscan_bwd(_ptr(u), _ptr(delta), _ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(delta_bias),
+                                         _ptr(dout), _ptr(state), _ptr(du), _ptr(ddelta), _ptr(dA), _ptr(dB),
+                                         _ptr(dC), _ptr(dD), _ptr(dbias), _ptr(ws), b, d, L, n, g,
+                                         int(ctx.delta_softplus), _stream()), "mlagg_selscan_bwd")
+        return du, ddelta, dA, dB, dC, dD, dbias, None
+
+
+def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                      return_last_state=False):
+    """Drop-in for ``mamba_ssm.ops.selective_scan_interface.selective_scan_fn`` on the arguments the
+    reference passes (MambaSkip.py:445-451: z=None, return_last_state=False).  Anything else raises."""
+    if z is not None or return_last_state:
+        raise RuntimeError("selective_scan_fn: z gating / return_last_state are not on the MLAgg-UNet path")
+    return SelectiveScanFn.apply(u, delta, A, B, C, D, delta_bias, delta_softplus)
+
+
+def _rows(t, name):
+    """(B, N, C) view whose last dim is contiguous and whose batch/token dims collapse to one row
+    stride (true for fresh Linear outputs and their channel slices); returns (tensor, row_stride)."""
+    _require(t, name)
+    if t.dim() != 3 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1) or t.stride(1) % 4 or \
+            t.data_ptr() % 16:
+        t = t.contiguous()
+    return t, t.stride(1)
+
+
+class DWConv3x3Fn(torch.autograd.Function):
+    """K2: depthwise 3x3 (+bias, optional SiLU) on token-major maps."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, H, W, silu):
+        x, xs = _rows(x, "x")
+        B, N, C = x.shape
+        if N != H * W:
+            raise RuntimeError(f"dwconv3x3: {N} tokens != {H}x{W}")
+        w = _require(weight.reshape(C, 9).contiguous(), "weight")
+        y = torch.empty(B, N, C, device=x.device, dtype=torch.float32)
+        pre = torch.empty_like(y) if silu else None      # pre-activation, needed by SiLU's backward
+        _lib.check(_lib.lib().mlagg_dwconv3x3_fwd(_ptr(x), xs, _ptr(w), _ptr(bias), _ptr(y), C, _ptr(pre), B, H, W, C,
+                                                  int(silu), _stream()), "mlagg_dwconv3x3_fwd")
+        ctx.save_for_backward(x, w, pre)
+        ctx.geom = (H, W, bool(silu), bias is not None, weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, pre = ctx.saved_tensors
+        H, W, silu, has_bias, wshape = ctx.geom
+        B, N, C = x.shape
+        dy, dys = _rows(dy, "dy")
+        dx = torch.empty(B, N, C, device=x.device, dtype=torch.float32)
+        dw = torch.zeros(C, 9, device=x.device, dtype=torch.float32)
+        db = torch.zeros(C, device=x.device, dtype=torch.float32) if has_bias else None
+        _lib.check(_lib.lib().mlagg_dwconv3x3_bwd(_ptr(x), x.stride(1), _ptr(w), _ptr(dy), dys, _ptr(pre), _ptr(dx), C,
+                                                  _ptr(dw), _ptr(db), B, H, W, C, int(silu), _stream()),
+                   "mlagg_dwconv3x3_bwd")
+        return dx, dw.reshape(wshape), db, None, None, None
+
+
+def dwconv3x3_nlc(x, weight, bias, H, W, silu=False):
+    return DWConv3x3Fn.apply(x, weight, bias, H, W, silu)
+
+
+class LocalDiffAttnFn(torch.autograd.Function):
+    """K3: fused 3x3-window differential attention + RMSNorm + LePE (AggregatedAttention local branch)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, lam, subln_w, lepe_w, lepe_b, H, W, nh, scale):
+        q, qs = _rows(q, "q")
+        kv, kvs = _rows(kv, "kv")
+        B, N, d = q.shape
+        if N != H * W or d != nh * 48 or kv.shape[2] != 2 * d:
+            raise RuntimeError(f"local_diff_attn: bad shapes q {tuple(q.shape)} kv {tuple(kv.shape)} H {H} W {W} nh {nh}")
+        lam = _require(lam.reshape(1).contiguous(), "lambda")
+        subln_w = _require(subln_w.contiguous(), "subln.weight", (48,))
+        lw = _require(lepe_w.reshape(d, 9).contiguous(), "lepe.weight")
+        lb = _require(lepe_b.contiguous(), "lepe.bias", (d,))
+        out = torch.empty(B, N, d, device=q.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mlagg_local_attn_fwd(_ptr(q), qs, _ptr(kv), kvs, _ptr(lam), _ptr(subln_w), _ptr(lw),
+                                                   _ptr(lb), _ptr(out), d, B, H, W, nh, float(scale), _stream()),
+                   "mlagg_local_attn_fwd")
+        ctx.save_for_backward(q, kv, lam, subln_w, lw)
+        ctx.geom = (H, W, nh, float(scale), lepe_w.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, lam, subln_w, lw = ctx.saved_tensors
+        H, W, nh, scale, lwshape = ctx.geom
+        B, N, d = q.shape
+        dout, dos = _rows(dout, "dout")
+        lib = _lib.lib()
+        dq = torch.empty(B, N, d, device=q.device, dtype=torch.float32)
+        dkv = torch.empty(B, N, 2 * d, device=q.device, dtype=torch.float32)
+        small = torch.zeros(1 + 48 + d * 9 + d, device=q.device, dtype=torch.float32)
+        dlam, dsub, dlw, dlb = small[:1], small[1:49], small[49:49 + d * 9], small[49 + d * 9:]
+        ws = torch.empty(lib.mlagg_local_attn_bwd_workspace_floats(B, H, W, nh), device=q.device, dtype=torch.float32)
+        _lib.check(lib.mlagg_local_attn_bwd(_ptr(q), q.stride(1), _ptr(kv), kv.stride(1), _ptr(lam), _ptr(subln_w),
+                                            _ptr(lw), _ptr(dout), dos, _ptr(dq), d, _ptr(dkv), 2 * d, _ptr(dlam),
+                                            _ptr(dsub), _ptr(dlw), _ptr(dlb), _ptr(ws), B, H, W, nh, scale, _stream()),
+                   "mlagg_local_attn_bwd")
+        return dq, dkv, dlam.reshape(()), dsub, dlw.reshape(lwshape), dlb, None, None, None, None
+
+
+class PooledDiffAttnFn(torch.autograd.Function):
+    """K4: fused pooled differential attention + RMSNorm (AggregatedAttention global branch)."""
+
+    @staticmethod
+    def forward(ctx, q, kp, vp, lam, subln_w, nh, scale):
+        q, qs = _rows(q, "q")
+        kp, kps = _rows(kp, "k_pool")
+        vp, vps = _rows(vp, "v_pool")
+        B, N, d = q.shape
+        P = kp.shape[1]
+        if d != nh * 48 or tuple(kp.shape) != (B, P, d) or tuple(vp.shape) != (B, P, d):
+            raise RuntimeError(f"pooled_diff_attn: bad shapes q {tuple(q.shape)} k {tuple(kp.shape)} v {tuple(vp.shape)}")
+        lam = _require(lam.reshape(1).contiguous(), "lambda")
+        subln_w = _require(subln_w.contiguous(), "subln.weight", (48,))
+        out = torch.empty(B, N, d, device=q.device, dtype=torch.float32)
+        need = any(ctx.needs_input_grad)      # grad mode is off inside Function.forward
+        lse = torch.empty(B, N, nh, 2, device=q.device, dtype=torch.float32) if need else None
+        o_pre = torch.empty(B, N, d, device=q.device, dtype=torch.float32) if need else None
+        _lib.check(_lib.lib().mlagg_pooled_attn_fwd(_ptr(q), qs, _ptr(kp), kps, _ptr(vp), vps, _ptr(lam), _ptr(subln_w),
+                                                    _ptr(out), d, _ptr(lse), _ptr(o_pre), B, N, P, nh, float(scale),
+                                                    _stream()), "mlagg_pooled_attn_fwd")
+        ctx.save_for_backward(q, kp, vp, lam, subln_w, lse, o_pre)
+        ctx.geom = (nh, float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kp, vp, lam, subln_w, lse, o_pre = ctx.saved_tensors
+        nh, scale = ctx.geom
+        B, N, d = q.shape
+        P = kp.shape[1]
+        dout, dos = _rows(dout, "dout")
+        lib = _lib.lib()
+        dq = torch.empty(B, N, d, device=q.device, dtype=torch.float32)
+        dkp = torch.zeros(B, P, d, device=q.device, dtype=torch.float32)
+        dvp = torch.zeros(B, P, d, device=q.device, dtype=torch.float32)
+        small = torch.zeros(1 + 48, device=q.device, dtype=torch.float32)
+        ws = torch.empty(lib.mlagg_pooled_attn_bwd_workspace_floats(B, N, nh), device=q.device, dtype=torch.float32)
+        _lib.check(lib.mlagg_pooled_attn_bwd(_ptr(q), q.stride(1), _ptr(kp), kp.stride(1), _ptr(vp), vp.stride(1),
+                                             _ptr(lam), _ptr(subln_w), _ptr(dout), dos, _ptr(lse), _ptr(o_pre),
+                                             _ptr(dq), d, _ptr(dkp), d, _ptr(dvp), d, _ptr(small[:1]), _ptr(small[1:]),
+                                             _ptr(ws), B, N, P, nh, scale, _stream()), "mlagg_pooled_attn_bwd")
+        return dq, dkp, dvp, small[0].reshape(()), small[1:], None, None
+
+
+def local_diff_attn(q, kv, lam, subln_w, lepe_w, lepe_b, H, W, nh, scale):
+    return LocalDiffAttnFn.apply(q, kv, lam, subln_w, lepe_w, lepe_b, H, W, nh, scale)
+
+
+def pooled_diff_attn(q, k_pool, v_pool, lam, subln_w, nh, scale):
+    return PooledDiffAttnFn.apply(q, k_pool, v_pool, lam, subln_w, nh, scale)

@@ -1,0 +1,163 @@
+"""Train step, loss and data-parallel wiring of ``nnUNetTrainer_MLAgg_2D_dt_MS`` for MI355X.
+
+Mirrors the reference's trainer surface on the hot path:
+  * ``train_step``            reference nnUNetTrainer.py:833-863 (fp32 branch: zero_grad, forward, loss,
+                              backward, clip_grad_norm_ 12, optimizer step)
+  * ``configure_optimizers``  reference nnUNetTrainer_MLAgg_2D_dt_MS.py:137-147 (AdamW 5e-4 / 3e-5 / eps 1e-4,
+                              timm CosineLRScheduler restated: t_initial 500, lr_min 1e-6, warmup 10 @ 1e-4)
+  * ``deep_supervision_loss`` reference loss/deep_supervision.py:17-34 over DC_and_CE_loss
+                              (loss/compound_losses.py:31-57, loss/dice.py:73-117, loss/robust_ce_loss.py:12-16)
+  * ``wrap_ddp``              reference nnUNetTrainer.py:205-207, without its ``dummy_tensor`` hazard
+  * ``split_batch_size``      reference nnUNetTrainer.py:283-328 with the zero/negative per-rank sizes fixed (7c)
+One process per GPU; ``torch.distributed`` backend "nccl" is RCCL on ROCm (xGMI inside a node).
+"""
+import math
+from typing import List
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------------------------
+# loss
+# ------------------------------------------------------------------------------------------------
+class _AllGatherSum(torch.autograd.Function):
+    """Sum over ranks of a small statistics tensor.  Equivalent to the reference's
+    AllGatherGrad(...).sum(0) (utilities/ddp_allgather.py:25-48 used at loss/dice.py:104-107) --
+    forward: sum of every rank's statistics; backward: the SUM over ranks of the upstream gradients
+    (reference :46 all_reduce then [rank] slice), which DDP's gradient averaging then turns into the
+    gradient of the global-batch dice -- but as ONE all-reduce each way for the three dice statistics
+    instead of three all_gathers forward + three all_reduces backward per deep-supervision level."""
+
+    @staticmethod
+    def forward(ctx, stats):
+        out = stats.clone()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        g = grad.clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        return g
+
+
+def soft_dice_loss(logits, target, batch_dice=True, smooth=1e-5, ddp=False):
+    probs = logits.softmax(1)[:, 1:]
+    axes = tuple(range(2, logits.ndim))
+    with torch.no_grad():
+        onehot = torch.zeros(logits.shape, dtype=torch.bool, device=logits.device)
+        onehot.scatter_(1, target.long(), 1)
+        onehot = onehot[:, 1:]
+        sum_gt = onehot.sum(axes).to(probs.dtype)
+    intersect = (probs * onehot).sum(axes)
+    sum_pred = probs.sum(axes)
+    if batch_dice:
+        stats = torch.stack([intersect.sum(0), sum_pred.sum(0), sum_gt.sum(0)])
+        if ddp:
+            stats = _AllGatherSum.apply(stats)
+        intersect, sum_pred, sum_gt = stats[0], stats[1], stats[2]
+    dc = (2 * intersect + smooth) / torch.clip(sum_gt + sum_pred + smooth, 1e-8)
+    return -dc.mean()
+
+
+def dc_and_ce_loss(logits, target, batch_dice=True, ddp=False):
+    return F.cross_entropy(logits, target[:, 0].long()) + soft_dice_loss(logits, target, batch_dice, ddp=ddp)
+
+
+def deep_supervision_weights(n=5):
+    w = [1.0 / 2 ** i for i in range(n)]
+    s = sum(w)
+    return [v / s for v in w]
+
+
+def deep_supervision_loss(outputs, targets, batch_dice=True, ddp=False):
+    ws = deep_supervision_weights(len(outputs))
+    total = ws[0] * dc_and_ce_loss(outputs[0], targets[0], batch_dice, ddp)
+    for w, o, t in zip(ws[1:], outputs[1:], targets[1:]):
+        total = total + w * dc_and_ce_loss(o, t, batch_dice, ddp)
+    return total
+
+
+# ------------------------------------------------------------------------------------------------
+# optimiser / schedule
+# ------------------------------------------------------------------------------------------------
+def configure_optimizers(model, initial_lr=5e-4, weight_decay=3e-5, fused=None):
+    params = [p for p in model.parameters() if p.requires_grad]
+    if fused is None:
+        fused = all(p.is_cuda for p in params)
+    opt = torch.optim.AdamW(params, initial_lr, weight_decay=weight_decay, eps=1e-4, fused=fused)
+    return opt, CosineLRSchedule(opt, t_initial=500, lr_min=1e-6, warmup_t=10, warmup_lr_init=1e-4)
+
+
+class CosineLRSchedule:
+    """timm CosineLRScheduler semantics for one cycle, stepped with the epoch index at epoch start
+    (reference nnUNetTrainer.py:825)."""
+
+    def __init__(self, optimizer, t_initial, lr_min, warmup_t, warmup_lr_init):
+        self.opt, self.t_initial, self.lr_min = optimizer, t_initial, lr_min
+        self.warmup_t, self.warmup_lr_init = warmup_t, warmup_lr_init
+        self.base = [g["lr"] for g in optimizer.param_groups]
+
+    def lr_at(self, epoch, base):
+        if epoch < self.warmup_t:
+            return self.warmup_lr_init + epoch * (base - self.warmup_lr_init) / self.warmup_t
+        if epoch >= self.t_initial:
+            return self.lr_min
+        return self.lr_min + 0.5 * (base - self.lr_min) * (1 + math.cos(math.pi * epoch / self.t_initial))
+
+    def step(self, epoch):
+        for g, base in zip(self.opt.param_groups, self.base):
+            g["lr"] = self.lr_at(epoch, base)
+
+
+# ------------------------------------------------------------------------------------------------
+# data parallelism
+# ------------------------------------------------------------------------------------------------
+def split_batch_size(global_batch, world_size):
+    """Per-rank batch sizes that always sum to ``global_batch`` and are never zero or negative
+    (the reference's ceil-based split yields (2,2,2,2,2,0,-2,-4) for 10 over 8, SURVEY finding 7c)."""
+    if global_batch < world_size:
+        raise RuntimeError("Cannot run DDP if the batch size is smaller than the number of GPUs")
+    base, rem = divmod(global_batch, world_size)
+    return [base + (1 if r < rem else 0) for r in range(world_size)]
+
+
+def wrap_ddp(model, device_index=None, bucket_cap_mb=25):
+    """DistributedDataParallel over RCCL with gradient buckets overlapped with backward.  The
+    never-used ``dummy_tensor`` (reference T:1362) is excluded from reduction so that
+    ``find_unused_parameters`` can stay False (SURVEY finding 7a)."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    model._ddp_params_and_buffers_to_ignore = ["dummy_tensor"]
+    ids = None if device_index is None else [device_index]
+    return DDP(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True,
+               broadcast_buffers=False)
+
+
+def set_deep_supervision_enabled(network, enabled):
+    """Reference T:94-99 writes the attribute on the DDP wrapper (SURVEY finding 7b); unwrap first."""
+    getattr(network, "module", network).deep_supervision = enabled
+
+
+# ------------------------------------------------------------------------------------------------
+# step
+# ------------------------------------------------------------------------------------------------
+def train_step(network, optimizer, data, target: List[torch.Tensor], batch_dice=True, ddp=False, clip=12.0):
+    """One optimisation step on device-resident tensors; returns the detached loss tensor (the caller
+    decides when to synchronise -- the reference's ``.cpu()`` per step, B:863, is a host sync)."""
+    optimizer.zero_grad(set_to_none=True)
+    output = network(data)
+    loss = deep_supervision_loss(output, target, batch_dice, ddp)
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_([p for p in network.parameters() if p.grad is not None], clip)
+    optimizer.step()
+    return loss.detach()
+
+
+def synthetic_batch(batch, in_ch, H, W, n_cls, seed=1234, device="cpu"):
+    """Benchmark inputs of the reference's nnUNetTrainerBenchmark_5epochs_noDataLoading.py:16-22."""
+    g = torch.Generator().manual_seed(seed)
+    data = torch.rand(batch, in_ch, H, W, generator=g)
+    target = [torch.round(torch.rand(batch, 1, H >> s, W >> s, generator=g) * (n_cls - 1)) for s in range(5)]
+    return data.to(device), [t.to(device) for t in target]

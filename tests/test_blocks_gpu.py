@@ -1,0 +1,152 @@
+"""GPU parity of the HIP token mixers and of the assembled network against the CPU oracle and the
+golden vectors captured from the reference (tolerance: north_star's 1e-3 on logits, tighter per op)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import mlagg_oracle as O
+
+gpu = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _close(got, ref, atol, rtol, name=""):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else got
+    ref = ref.detach().cpu().numpy() if isinstance(ref, torch.Tensor) else ref
+    np.testing.assert_allclose(got, ref, atol=atol * max(1.0, float(np.abs(ref).max())), rtol=rtol, err_msg=name)
+
+
+def _param_grads_close(prod, orac, atol=2e-4, rtol=2e-3):
+    og = {n: p.grad for n, p in orac.named_parameters() if p.grad is not None}
+    pg = {n: p.grad for n, p in prod.named_parameters() if p.grad is not None}
+    assert set(og) == set(pg), set(og) ^ set(pg)
+    for n in og:
+        _close(pg[n], og[n], atol, rtol, n)
+
+
+@gpu
+@pytest.mark.parametrize("C,H,W,silu", [(96, 16, 12, True), (48, 7, 9, False), (128, 32, 32, True), (4, 1, 1, False)])
+def test_dwconv3x3_matches_conv2d(C, H, W, silu):
+    from mlagg_unet_amd import ops
+    g = torch.Generator().manual_seed(C + H)
+    B = 2
+    x = torch.randn(B, H * W, C, generator=g)
+    w = torch.randn(C, 1, 3, 3, generator=g) * 0.3
+    b = torch.randn(C, generator=g) * 0.1
+    gy = torch.randn(B, H * W, C, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    img = xr.view(B, H, W, C).permute(0, 3, 1, 2)
+    ref = F.conv2d(img, wr, br, padding=1, groups=C)
+    ref = (F.silu(ref) if silu else ref).permute(0, 2, 3, 1).reshape(B, H * W, C)
+    ref.backward(gy)
+    xg, wg, bg = [t.clone().to(DEV).requires_grad_(True) for t in (x, w, b)]
+    out = ops.dwconv3x3_nlc(xg, wg, bg, H, W, silu=silu)
+    out.backward(gy.to(DEV))
+    _close(out, ref, 1e-5, 1e-5, "y")
+    _close(xg.grad, xr.grad, 1e-5, 1e-4, "dx")
+    _close(wg.grad, wr.grad, 1e-5, 1e-4, "dw")
+    _close(bg.grad, br.grad, 1e-5, 1e-4, "db")
+
+
+def _attn_pair(local, dim, res, nh, sr, variant, seed):
+    from mlagg_unet_amd import model as PM
+    torch.manual_seed(seed)
+    orac = O.AggregatedAttention(dim, res, nh, local, sr, variant)
+    O.deterministic_fill_(orac.state_dict(), seed=seed)
+    prod = PM.AggregatedAttention(dim, res, nh, local, sr, variant)
+    prod.load_state_dict(orac.state_dict())
+    return orac, prod.to(DEV)
+
+
+@gpu
+@pytest.mark.parametrize("local", [True, False])
+@pytest.mark.parametrize("dim,res,nh,sr,variant", [
+    (48, (16, 16), 1, 4, "B"),     # stage-0 geometry (one head pair)
+    (192, (6, 10), 4, 2, "B"),     # 4 heads, non-square, tile edges inside the image
+    (96, (9, 8), 2, 4, "A"),       # variant A scaling; 9 % 4 != 0 -> adaptive-pool fallback (pooled branch)
+    (48, (1, 3), 1, 1, "B"),       # degenerate window: every token on the border
+])
+def test_aggregated_attention_matches_oracle(local, dim, res, nh, sr, variant):
+    if not local and (res[0] // sr == 0 or res[1] // sr == 0):
+        pytest.skip("no pooled keys")
+    orac, prod = _attn_pair(local, dim, res, nh, sr, variant, seed=11)
+    g = torch.Generator().manual_seed(5)
+    B, N = 2, res[0] * res[1]
+    x = torch.randn(B, N, dim, generator=g)
+    gy = torch.randn(B, N, dim, generator=g)
+    xo = x.clone().requires_grad_(True)
+    yo = orac(xo, *res)
+    yo.backward(gy)
+    xp = x.clone().to(DEV).requires_grad_(True)
+    yp = prod(xp)
+    yp.backward(gy.to(DEV))
+    _close(yp, yo, 2e-5, 1e-4, "out")
+    _close(xp.grad, xo.grad, 5e-5, 1e-3, "dx")
+    _param_grads_close(prod, orac)
+
+
+@gpu
+@pytest.mark.parametrize("variant", ["B", "A"])
+@pytest.mark.parametrize("tag", ["s0", "s2"])
+def test_mllablock_matches_reference_golden(golden_dir, tag, variant):
+    from mlagg_unet_amd import model as PM
+    g = np.load(os.path.join(golden_dir, f"mllablock_{tag}_variant{variant}.npz"))
+    blk = PM.MLLABlock(int(g["dim"]), tuple(int(v) for v in g["res"]), int(g["heads"]), 2, 0.0, int(g["sr"]), variant)
+    sd = blk.state_dict()
+    O.deterministic_fill_(sd, seed=7)
+    blk = blk.to(DEV).eval()
+    x = torch.from_numpy(g["x"]).to(DEV).requires_grad_(True)
+    y = blk(x)
+    _close(y, g["y"], 5e-5, 1e-4, "y")
+    y.backward(torch.from_numpy(g["gy"]).to(DEV))
+    _close(x.grad, g["gx"], 1e-4, 1e-3, "gx")
+    norms = {n: float(p.grad.double().norm()) for n, p in blk.named_parameters() if p.grad is not None}
+    for n, ref in zip(g["grad_names"], g["grad_norms"]):
+        assert abs(norms[str(n)] - ref) <= 2e-3 * max(ref, 1e-3), (n, norms[str(n)], ref)
+
+
+@gpu
+def test_msmm_matches_reference_golden(golden_dir):
+    from mlagg_unet_amd import model as PM
+    g = np.load(os.path.join(golden_dir, "msmm_nonsquare.npz"))
+    layer = PM.VSS_Conv_Layer([96, 192, 384, 768], 48, depth=1, drop_path=0.1)
+    O.deterministic_fill_(layer.state_dict(), seed=3)
+    layer = layer.to(DEV).eval()
+    xs = [torch.from_numpy(g[f"x{i}"]).to(DEV).requires_grad_(True) for i in range(4)]
+    ys = layer(xs)
+    for i, y in enumerate(ys):
+        _close(y, g[f"y{i}"], 5e-5, 1e-4, f"y{i}")
+    torch.autograd.backward(ys, [torch.from_numpy(g[f"gy{i}"]).to(DEV) for i in range(4)])
+    for i, x in enumerate(xs):
+        _close(x.grad, g[f"gx{i}"], 1e-4, 1e-3, f"gx{i}")
+    sa = layer.blocks[0].self_attention
+    for p, key in ((sa.A_logs, "g_A_logs"), (sa.Ds, "g_Ds"), (sa.dt_projs_bias, "g_dt_bias"),
+                   (sa.x_proj_weight, "g_x_proj"), (sa.dt_projs_weight, "g_dt_w")):
+        _close(p.grad, g[key], 2e-4, 2e-3, key)
+
+
+@gpu
+@pytest.mark.parametrize("variant", ["B", "A"])
+def test_full_model_logits_match_reference_golden(golden_dir, variant):
+    """north_star: segmentation logits within 1e-3 (fp32) of the reference on identical inputs."""
+    from mlagg_unet_amd import model as PM
+    g = np.load(os.path.join(golden_dir, f"full_model_64_variant{variant}.npz"))
+    img = tuple(int(v) for v in g["img"])
+    m = PM.build_network_architecture(img, 1, 14, True, variant)
+    O.deterministic_fill_(m.state_dict())
+    m = m.to(DEV).eval()
+    data, target = O.synthetic_batch(1, 1, *img, 14, seed=int(g["data_seed"]))
+    out = m(data.to(DEV))
+    for i, o in enumerate(out):
+        assert float((o.cpu() - torch.from_numpy(g[f"out{i}"])).abs().max()) < 1e-3, i
+    from mlagg_unet_amd import trainer as TR
+    loss = TR.deep_supervision_loss(out, [t.to(DEV) for t in target], batch_dice=True)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4
+    loss.backward()
+    norms = {n: float(p.grad.double().norm()) for n, p in m.named_parameters() if p.grad is not None}
+    assert "dummy_tensor" not in norms
+    for n, ref in zip(g["grad_names"], g["grad_norms"]):
+        assert abs(norms[str(n)] - ref) <= 5e-3 * max(ref, 1e-3), (n, norms[str(n)], ref)
