@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""Headline benchmark: train-step images/sec of MLAgg-UNet 2D (nnUNetTrainer_MLAgg_2D_dt_MS) on
+synthetic AbdomenMRI-shaped batches -- BASELINE.json config 2: 256x256x1, batch 10 per GPU, fp32,
+14 classes, attention variant B (the fp32 path, reference T:762-777).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = zero_grad + forward + Dice/CE deep-supervision loss + backward + clip_grad_norm_(12) + AdamW
+(reference nnUNetTrainer.py:833-863), inputs resident in HBM before the timed region
+(nnUNetTrainerBenchmark_5epochs_noDataLoading.py:16-22).  One JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+IMG = (256, 256)
+BATCH_PER_GPU = 10
+N_CLASSES = 14
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def host_threads():
+    """CPU share of this process: the affinity mask, capped at 16 (the GPU box's per-GPU CPU share; its
+    os.cpu_count() reports the whole host and oversubscribing it makes torch crawl)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
+def _oracle_step_seconds(img, batch):
+    from oracle import mlagg_oracle as O
+    torch.manual_seed(0)
+    net = O.build_reference_config_model(img, 1, N_CLASSES, True, "B").train()
+    opt = O.make_optimizer(net)
+    data, target = O.synthetic_batch(batch, 1, *img, N_CLASSES, seed=1234)
+    t0 = time.perf_counter()
+    O.train_step(net, opt, data, target)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(budget_s=45.0):
+    """The CPU oracle's train step (plain PyTorch eager, unbind-loop scan) on this
+    box's host cores, on a bounded sample: one step at batch 1 of the 128x128 case (BASELINE configs[0])
+    first; if that predicts the 256x256 step fits the budget, one step at batch 1 of the real workload."""
+    cores = host_threads()
+    torch.set_num_threads(cores)
+    small = (IMG[0] // 2, IMG[1] // 2)
+    dt_small = _oracle_step_seconds(small, 1)
+    if 4.5 * dt_small <= budget_s:
+        dt = _oracle_step_seconds(IMG, 1)
+        value, sample = 1.0 / dt, (f"1 train step (fwd+bwd+clip+AdamW) at batch 1 of the {IMG[0]}x{IMG[1]} workload: "
+                                   f"{dt:.1f} s; torch eager fp32, {cores} threads, no warm-up")
+    else:
+        value, sample = 1.0 / (4.0 * dt_small), (
+            f"1 train step at batch 1 of the {small[0]}x{small[1]} case: {dt_small:.1f} s, scaled by the 4x pixel "
+            f"(= token) ratio to {IMG[0]}x{IMG[1]} images; torch eager fp32, {cores} threads, no warm-up")
+    return {"value": round(value, 5), "unit": "images/sec", "cores": cores, "kind": "port", "sample": sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    ddp = world > 1
+    if ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
+
+    import mlagg_unet_amd  # noqa: F401
+    from mlagg_unet_amd import _lib, model, profiling, trainer
+
+    _lib.lib()                                              # fail loudly if the HIP library is missing
+    # The reference sets cudnn.benchmark=True (run_training.py:123-125).  On ROCm that is MIOpen's exhaustive
+    # find mode, which compiles every candidate solver at first use (minutes on a fresh box with an empty
+    # user perf-db); the default immediate mode picks from the shipped kernel database instead.
+    torch.backends.cudnn.benchmark = os.environ.get("MLAGG_MIOPEN_FIND", "0") == "1"
+    torch.manual_seed(0)
+    net = model.build_network_architecture(IMG, 1, N_CLASSES, True, "B").to(dev).train()
+    opt, sched = trainer.configure_optimizers(net)
+    sched.step(0)
+    step_net = trainer.wrap_ddp(net, local_rank) if ddp else net
+    data, target = trainer.synthetic_batch(args.batch, 1, *IMG, N_CLASSES, seed=1234 + rank, device=dev)
+
+    def one_step():
+        return trainer.train_step(step_net, opt, data, target, batch_dice=True, ddp=ddp)
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    for i in range(args.warmup):
+        one_step()
+        torch.cuda.synchronize()
+        note(f"warm-up step {i + 1}/{args.warmup} done")
+
+    # pick the dominant hand-written kernel from one instrumented (untimed) step, then time ONLY that
+    # kernel with HIP events on its launch stream during the timed region
+    roof = None
+    if not args.no_roofline:
+        profiling.select_all()
+        one_step()
+        table = profiling.collect()
+        dominant = max(table, key=lambda k: table[k]["ms"]) if table else None
+        profiling.select(dominant)
+
+    if ddp:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    if ddp:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if ddp:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if not args.no_roofline and dominant is not None:
+        res = profiling.collect()[dominant]
+        avg_ms = res["ms"] / max(res["count"], 1)
+        alg = profiling.algorithmic_bytes(dominant, args.batch, IMG)
+        achieved = alg / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 4), "launches_timed": res["count"],
+                "algorithmic_bytes_per_launch": alg,
+                "all_kernels_ms_per_step": {k: round(v["ms"], 3) for k, v in sorted(table.items())}}
+        profiling.select(None)
+
+    if rank == 0:
+        n_img = args.batch * world * args.steps
+        line = {
+            "metric": "images/sec (train step) MLAgg-UNet-2D 256x256 bs10",
+            "value": round(n_img / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "nnUNetTrainer_MLAgg_2D_dt_MS train step, AbdomenMRI-shaped 256x256x1, "
+                                   "14 classes, attention variant B (BASELINE.json configs[1])",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}", "final_loss": round(float(loss), 5)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if ddp:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -28,6 +28,15 @@ extern "C" {
 const char *mlagg_version(void);
 const char *mlagg_error_string(int code);
 
+/* Per-kernel HIP-event timing for bench.py's roofline line (diagnostics; off by default, zero cost).
+ * select: -1 off, -2 every kernel, otherwise one kernel id in [0, mlagg_profile_kernel_count()).
+ * collect: synchronises with the recorded events (so NOT graph-capturable), writes the summed
+ * milliseconds and launch counts per kernel id into ms[count] / counts[count] and resets. */
+int mlagg_profile_kernel_count(void);
+const char *mlagg_profile_kernel_name(int id);
+int mlagg_profile_select(int id);
+int mlagg_profile_collect(double *ms, int *counts);
+
 /* ------------------------------------------------------------------------------------------
  * K1: selective scan.  Replaces mamba-ssm's `selective_scan_cuda.fwd/bwd` behind
  * `selective_scan_fn(u, delta, A, B, C, D, z=None, delta_bias, delta_softplus=True)` as called at
@@ -115,9 +124,20 @@ int mlagg_pooled_attn_bwd(const float *q, int q_stride, const float *kp, int kp_
  * ------------------------------------------------------------------------------------------ */
 int mlagg_dwconv3x3_fwd(const float *x, int x_stride, const float *w, const float *bias, float *y,
                         int y_stride, float *pre, int batch, int H, int W, int C, int silu, void *stream);
+size_t mlagg_dwconv3x3_bwd_workspace_floats(int batch, int H, int W, int C);
 int mlagg_dwconv3x3_bwd(const float *x, int x_stride, const float *w, const float *dy, int dy_stride,
-                        const float *pre, float *dx, int dx_stride, float *dw, float *dbias,
+                        const float *pre, float *dx, int dx_stride, float *dw, float *dbias, float *workspace,
                         int batch, int H, int W, int C, int silu, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K5w: weight / bias gradient of a token-major Linear,  dW (O, I) = dy^T x,  db (O) = column sums of dy,
+ * with dy (M, O) and x (M, I) (row strides in floats), M = batch * tokens.  Replaces the library GEMM in the
+ * backward of the nn.Linear layers at nnUNetTrainer_MLAgg_2D_dt_MS.py:687-690, 887-907 and
+ * MambaSkip.py:518, 538, 572-575 (split-K over tokens on fp32 MFMA).  dW / db are overwritten.
+ * ------------------------------------------------------------------------------------------ */
+size_t mlagg_linear_wgrad_workspace_floats(int M, int O, int I);
+int mlagg_linear_wgrad(const float *dy, int dy_stride, const float *x, int x_stride, float *dW, float *db,
+                       float *workspace, int M, int O, int I, void *stream);
 
 #ifdef __cplusplus
 }

@@ -21,6 +21,10 @@ _FL = ctypes.c_float
 SIGNATURES = {
     "mlagg_version": (ctypes.c_char_p, []),
     "mlagg_error_string": (ctypes.c_char_p, [_I]),
+    "mlagg_profile_kernel_count": (_I, []),
+    "mlagg_profile_kernel_name": (ctypes.c_char_p, [_I]),
+    "mlagg_profile_select": (_I, [_I]),
+    "mlagg_profile_collect": (_I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     "mlagg_selscan_state_floats": (_SZ, [_I, _I, _I, _I]),
     "mlagg_selscan_fwd": (_I, [_F] * 9 + [_I] * 6 + [_S]),
     "mlagg_selscan_bwd_workspace_floats": (_SZ, [_I, _I, _I, _I]),
@@ -34,7 +38,10 @@ SIGNATURES = {
     "mlagg_pooled_attn_bwd": (_I, [_F, _I, _F, _I, _F, _I, _F, _F, _F, _I, _F, _F, _F, _I, _F, _I, _F, _I, _F, _F,
                                    _F, _I, _I, _I, _I, _FL, _S]),
     "mlagg_dwconv3x3_fwd": (_I, [_F, _I, _F, _F, _F, _I, _F, _I, _I, _I, _I, _I, _S]),
-    "mlagg_dwconv3x3_bwd": (_I, [_F, _I, _F, _F, _I, _F, _F, _I, _F, _F, _I, _I, _I, _I, _I, _S]),
+    "mlagg_dwconv3x3_bwd_workspace_floats": (_SZ, [_I, _I, _I, _I]),
+    "mlagg_dwconv3x3_bwd": (_I, [_F, _I, _F, _F, _I, _F, _F, _I, _F, _F, _F, _I, _I, _I, _I, _I, _S]),
+    "mlagg_linear_wgrad_workspace_floats": (_SZ, [_I, _I, _I]),
+    "mlagg_linear_wgrad": (_I, [_F, _I, _F, _I, _F, _F, _F, _I, _I, _I, _S]),
 }
 
 _lib = None

@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 
 #include "mlagg_hip.h"
+#include "prof.h"
+#include "internal.h"
 
 namespace {
 
@@ -90,35 +92,87 @@ dwconv_bwd_data_kernel(const float *__restrict__ dy, int dy_stride, const float 
     *reinterpret_cast<float4 *>(dx + ((size_t)b * N + t) * dx_stride + c) = acc;
 }
 
-// dw[c][j] = sum_{b,t} g[t] x[t + off_j], dbias[c] = sum g[t]; lane = channel, a workgroup sweeps a
-// token chunk and finishes with 10 atomics per channel.
-constexpr int WG_TOK = 256;
+// dw[c][j] = sum_{b,t} g[t] x[t + off_j], dbias[c] = sum g[t].  Workgroup = (batch b, image row y,
+// 64 channels); lane = channel (coalesced), the 4 waves split the row into 4 column segments.  A lane
+// walks its segment with a sliding 3x3 register window, so each step loads 3 new x values and 1 g
+// instead of 10.  LDS-reduced over the 4 segments, one partial row per workgroup, summed by
+// dwconv_wgrad_reduce_kernel (deterministic, no atomics).
 template <bool SILU>
-__global__ void dwconv_bwd_weight_kernel(const float *__restrict__ x, const float *__restrict__ dy, int dy_stride,
-                                         const float *__restrict__ pre, float *__restrict__ dw,
-                                         float *__restrict__ dbias, Geom g)
+__global__ void __launch_bounds__(256)
+dwconv_bwd_weight_kernel(const float *__restrict__ x, int x_stride, const float *__restrict__ dy, int dy_stride,
+                         const float *__restrict__ pre, float *__restrict__ part, int batch, int H, int W, int C)
 {
-    const int c = blockIdx.y * blockDim.x + threadIdx.x;
-    if (c >= g.C) return;
-    const int N = g.H * g.W, b = blockIdx.z;
-    const int t_begin = blockIdx.x * WG_TOK, t_end = min(t_begin + WG_TOK, N);
+    __shared__ float red[4][10][64];
+    const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cx;
+    const int y = blockIdx.x, b = blockIdx.z;
+    const size_t N = (size_t)H * W;
+    const int seg = (W + 3) / 4;
+    const int x_begin = ph * seg, x_end = min(x_begin + seg, W);
     float gw[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float gb = 0.f;
-    for (int t = t_begin; t < t_end; ++t) {
-        const int yy0 = t / g.W, xx0 = t - yy0 * g.W;
-        float gv = dy[((size_t)b * N + t) * dy_stride + c];
-        if (SILU) gv *= dsilu_f(pre[((size_t)b * N + t) * g.C + c]);
-        gb += gv;
+    if (c < C && x_begin < x_end) {
+        const float *xb = x + (size_t)b * N * x_stride + c;
+        const bool up = y > 0, dn = y + 1 < H;
+        // window columns: l (x-1), m (x), r (x+1) for rows y-1, y, y+1
+        float l[3], m[3], r[3];
+        auto col = [&](int xx, float (&v)[3]) {
+            const bool in = xx >= 0 && xx < W;
+            v[0] = (in && up) ? xb[((size_t)(y - 1) * W + xx) * x_stride] : 0.f;
+            v[1] = in ? xb[((size_t)y * W + xx) * x_stride] : 0.f;
+            v[2] = (in && dn) ? xb[((size_t)(y + 1) * W + xx) * x_stride] : 0.f;
+        };
+        col(x_begin - 1, l);
+        col(x_begin, m);
+        for (int xx = x_begin; xx < x_end; ++xx) {
+            col(xx + 1, r);
+            const size_t t = (size_t)b * N + (size_t)y * W + xx;
+            float gv = dy[t * dy_stride + c];
+            if (SILU) gv *= dsilu_f(pre[t * C + c]);
+            gb += gv;
 #pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            const int yy = yy0 + j / 3 - 1, xx = xx0 + j % 3 - 1;
-            if (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W)
-                gw[j] += gv * x[((size_t)b * N + (size_t)yy * g.W + xx) * g.x_stride + c];
+            for (int ky = 0; ky < 3; ++ky) {
+                gw[3 * ky + 0] += gv * l[ky];
+                gw[3 * ky + 1] += gv * m[ky];
+                gw[3 * ky + 2] += gv * r[ky];
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) { l[ky] = m[ky]; m[ky] = r[ky]; }
         }
     }
 #pragma unroll
-    for (int j = 0; j < 9; ++j) atomicAdd(dw + c * 9 + j, gw[j]);
-    if (dbias) atomicAdd(dbias + c, gb);
+    for (int j = 0; j < 9; ++j) red[ph][j][cx] = gw[j];
+    red[ph][9][cx] = gb;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 640; i += 256) {
+        const int j = i >> 6, cc = i & 63;
+        if (blockIdx.y * 64 + cc < C) {
+            const float s = red[0][j][cc] + red[1][j][cc] + red[2][j][cc] + red[3][j][cc];
+            const size_t row = (size_t)b * gridDim.x + blockIdx.x;
+            part[(row * C + blockIdx.y * 64 + cc) * 10 + j] = s;
+        }
+    }
+}
+
+// part[rows][C][10] -> dw[C][9] += , dbias[C] +=
+__global__ void dwconv_wgrad_reduce_kernel(const float *__restrict__ part, int rows, int C, float *__restrict__ dw,
+                                           float *__restrict__ dbias)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * 10) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = 0;
+    for (; r + 3 < rows; r += 4) {
+        s0 += part[(size_t)r * C * 10 + i];
+        s1 += part[(size_t)(r + 1) * C * 10 + i];
+        s2 += part[(size_t)(r + 2) * C * 10 + i];
+        s3 += part[(size_t)(r + 3) * C * 10 + i];
+    }
+    for (; r < rows; ++r) s0 += part[(size_t)r * C * 10 + i];
+    const float s = (s0 + s1) + (s2 + s3);
+    const int c = i / 10, j = i - c * 10;
+    if (j < 9) dw[c * 9 + j] += s;
+    else if (dbias) dbias[c] += s;
 }
 
 int make_geom(Geom &g, int batch, int H, int W, int C, int xs, int ys)
@@ -131,6 +185,37 @@ int make_geom(Geom &g, int batch, int H, int W, int C, int xs, int ys)
 
 }  // namespace
 
+namespace mlagg_internal {
+size_t dwconv_wgrad_workspace_floats(int batch, int H, int W, int C)
+{
+    (void)W;
+    return (size_t)batch * H * C * 10;      // one partial row per (batch, image row)
+}
+
+void dwconv_wgrad_launch(const float *x, int x_stride, const float *dy, int dy_stride, const float *pre, float *dw,
+                         float *dbias, float *part, int batch, int H, int W, int C, int silu, hipStream_t st)
+{
+    const int chunks = H;
+    const dim3 grid(chunks, (C + 63) / 64, batch);
+    {
+        MLAGG_TIMED(K_DWCONV_BWD_WEIGHT, st);
+        if (silu)
+            hipLaunchKernelGGL(dwconv_bwd_weight_kernel<true>, grid, dim3(256), 0, st, x, x_stride, dy, dy_stride, pre,
+                               part, batch, H, W, C);
+        else
+            hipLaunchKernelGGL(dwconv_bwd_weight_kernel<false>, grid, dim3(256), 0, st, x, x_stride, dy, dy_stride, pre,
+                               part, batch, H, W, C);
+        hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3((C * 10 + 255) / 256), dim3(256), 0, st, part,
+                           batch * chunks, C, dw, dbias);
+    }
+}
+}  // namespace mlagg_internal
+
+extern "C" size_t mlagg_dwconv3x3_bwd_workspace_floats(int batch, int H, int W, int C)
+{
+    return mlagg_internal::dwconv_wgrad_workspace_floats(batch, H, W, C);
+}
+
 extern "C" int mlagg_dwconv3x3_fwd(const float *x, int x_stride, const float *w, const float *bias, float *y,
                                    int y_stride, float *pre, int batch, int H, int W, int C, int silu,
                                    void *stream)
@@ -142,34 +227,31 @@ extern "C" int mlagg_dwconv3x3_fwd(const float *x, int x_stride, const float *w,
     const dim3 grid((unsigned)((total + 255) / 256), batch), block(256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (silu)
-        hipLaunchKernelGGL(dwconv_fwd_kernel<true>, grid, block, 0, st, x, w, bias, y, pre, g);
+        { MLAGG_TIMED(K_DWCONV_FWD, st); hipLaunchKernelGGL(dwconv_fwd_kernel<true>, grid, block, 0, st, x, w, bias, y, pre, g); }
     else
-        hipLaunchKernelGGL(dwconv_fwd_kernel<false>, grid, block, 0, st, x, w, bias, y, pre, g);
+        { MLAGG_TIMED(K_DWCONV_FWD, st); hipLaunchKernelGGL(dwconv_fwd_kernel<false>, grid, block, 0, st, x, w, bias, y, pre, g); }
     return (int)hipGetLastError();
 }
 
 extern "C" int mlagg_dwconv3x3_bwd(const float *x, int x_stride, const float *w, const float *dy, int dy_stride,
-                                   const float *pre, float *dx, int dx_stride, float *dw, float *dbias, int batch,
-                                   int H, int W, int C, int silu, void *stream)
+                                   const float *pre, float *dx, int dx_stride, float *dw, float *dbias,
+                                   float *workspace, int batch, int H, int W, int C, int silu, void *stream)
 {
-    if (!x || !w || !dy || !dx || !dw || (silu && !pre)) return MLAGG_E_NULLPTR;
+    if (!x || !w || !dy || !dx || !dw || !workspace || (silu && !pre)) return MLAGG_E_NULLPTR;
     Geom g;
     if (int rc = make_geom(g, batch, H, W, C, x_stride, dx_stride)) return rc;
     if (dy_stride < C || (dy_stride & 3)) return MLAGG_E_UNSUPPORTED;
     const size_t total = (size_t)H * W * (C / 4);
     const dim3 grid((unsigned)((total + 255) / 256), batch), block(256);
-    const int cthreads = C < 256 ? ((C + 63) / 64) * 64 : 256;
-    const dim3 wgrid((H * W + WG_TOK - 1) / WG_TOK, (C + cthreads - 1) / cthreads, batch);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (silu) {
-        hipLaunchKernelGGL(dwconv_bwd_data_kernel<true>, grid, block, 0, st, dy, dy_stride, pre, w, dx, dx_stride, g);
-        hipLaunchKernelGGL(dwconv_bwd_weight_kernel<true>, wgrid, dim3(cthreads), 0, st, x, dy, dy_stride, pre, dw,
-                           dbias, g);
-    } else {
-        hipLaunchKernelGGL(dwconv_bwd_data_kernel<false>, grid, block, 0, st, dy, dy_stride, pre, w, dx, dx_stride,
-                           g);
-        hipLaunchKernelGGL(dwconv_bwd_weight_kernel<false>, wgrid, dim3(cthreads), 0, st, x, dy, dy_stride, pre, dw,
-                           dbias, g);
+    {
+        MLAGG_TIMED(K_DWCONV_BWD_DATA, st);
+        if (silu)
+            hipLaunchKernelGGL(dwconv_bwd_data_kernel<true>, grid, block, 0, st, dy, dy_stride, pre, w, dx, dx_stride, g);
+        else
+            hipLaunchKernelGGL(dwconv_bwd_data_kernel<false>, grid, block, 0, st, dy, dy_stride, pre, w, dx, dx_stride,
+                               g);
     }
+    mlagg_internal::dwconv_wgrad_launch(x, x_stride, dy, dy_stride, pre, dw, dbias, workspace, batch, H, W, C, silu, st);
     return (int)hipGetLastError();
 }

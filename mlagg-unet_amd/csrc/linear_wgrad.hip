@@ -1,0 +1,200 @@
+// K5w -- weight / bias gradient of the token-major Linear layers:  dW[o][i] = sum_m dy[m][o] x[m][i],
+// db[o] = sum_m dy[m][o], for M = batch * tokens in the 10^4..10^5 range and O, I in {48 .. 384}.
+//
+// These are the tall-skinny "reduce over tokens" GEMMs behind every nn.Linear of MLLABlock / Mlp /
+// AggregatedAttention / SS2D_skip (reference nnUNetTrainer_MLAgg_2D_dt_MS.py:687-690, 887-907,
+// MambaSkip.py:518,538,572-575).  The library GEMM picks 32x32 macro-tiles with a serial K loop for
+// them (267 us for 96x96 at M = 163840 in the round-1 profile); the shape wants split-K over tokens.
+//
+// MFMA mapping (v_mfma_f32_32x32x2_f32, exact fp32): the contraction index k is the TOKEN.  For one
+// token pair, lane l supplies A[o = l & 31][k = l >> 5] = dy[m0 + (l >> 5)][o0 + (l & 31)] and
+// B[k][i = l & 31] = x[m0 + (l >> 5)][i0 + (l & 31)]: both are 128-byte runs of one row, read straight
+// from HBM into one VGPR each -- no LDS, no transpose.  A wave owns a slab of tokens and up to 3x3
+// output tiles (144 accumulator registers), streams the slab once, and writes its partial block;
+// a second kernel sums the partial blocks over slabs (16 row-groups, one float atomic each).
+//
+// Roofline: HBM-bound, algorithmic bytes 4 * M * (O + I) per launch (dy and x read once).
+#include <hip/hip_runtime.h>
+
+#include "mlagg_hip.h"
+#include "prof.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TMAX = 3;            // output tiles per wave along O and along I
+constexpr int RGROUPS = 16;        // row-groups of the partial reduction
+
+struct WGeom {
+    int M, O, I, dy_stride, x_stride;
+    int slab, nslabs, ogroups, igroups;
+};
+
+__device__ __forceinline__ float ld_or_zero(const float *__restrict__ p, bool ok) { return ok ? *p : 0.f; }
+
+template <int TO, int TI>
+__global__ void __launch_bounds__(64)
+linear_wgrad_kernel(const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ part, WGeom g)
+{
+    const int lane = threadIdx.x, col = lane & 31, kh = lane >> 5;
+    const int slab = blockIdx.x, og = blockIdx.y, ig = blockIdx.z;
+    const int o0 = og * TMAX * 32, i0 = ig * TMAX * 32;
+    f32x16 acc[TO][TI];
+#pragma unroll
+    for (int a = 0; a < TO; ++a)
+#pragma unroll
+        for (int b = 0; b < TI; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum[TO];
+    bool oko[TO], oki[TI];
+#pragma unroll
+    for (int a = 0; a < TO; ++a) { bsum[a] = 0.f; oko[a] = o0 + 32 * a + col < g.O; }
+#pragma unroll
+    for (int b = 0; b < TI; ++b) oki[b] = i0 + 32 * b + col < g.I;
+
+    const int m_begin = slab * g.slab, m_end = min(m_begin + g.slab, g.M);
+    const float *dyp = dy + (size_t)(m_begin + kh) * g.dy_stride + o0 + col;
+    const float *xp = x + (size_t)(m_begin + kh) * g.x_stride + i0 + col;
+    constexpr int UNR = 4;
+    int m = m_begin;
+    for (; m + 2 * UNR <= m_end; m += 2 * UNR) {       // 4 token pairs per iteration, all rows in range
+        float av[UNR][TO], bv[UNR][TI];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+            for (int a = 0; a < TO; ++a) av[u][a] = ld_or_zero(dyp + (size_t)(2 * u) * g.dy_stride + 32 * a, oko[a]);
+#pragma unroll
+            for (int b = 0; b < TI; ++b) bv[u][b] = ld_or_zero(xp + (size_t)(2 * u) * g.x_stride + 32 * b, oki[b]);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+            for (int a = 0; a < TO; ++a) {
+                bsum[a] += av[u][a];
+#pragma unroll
+                for (int b = 0; b < TI; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+            }
+        }
+        dyp += (size_t)(2 * UNR) * g.dy_stride;
+        xp += (size_t)(2 * UNR) * g.x_stride;
+    }
+    for (; m < m_end; m += 2) {                         // tail pairs (second row may be out of range)
+        const bool rowok = m + kh < m_end;
+#pragma unroll
+        for (int a = 0; a < TO; ++a) {
+            const float av = ld_or_zero(dyp + 32 * a, oko[a] && rowok);
+            bsum[a] += av;
+#pragma unroll
+            for (int b = 0; b < TI; ++b) {
+                const float bv = ld_or_zero(xp + 32 * b, oki[b] && rowok);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
+            }
+        }
+        dyp += (size_t)2 * g.dy_stride;
+        xp += (size_t)2 * g.x_stride;
+    }
+    // partial block of this slab: part[slab][O*I + O]; D layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*kh
+    float *prow = part + (size_t)slab * ((size_t)g.O * g.I + g.O);
+#pragma unroll
+    for (int a = 0; a < TO; ++a) {
+#pragma unroll
+        for (int b = 0; b < TI; ++b) {
+            if (!oki[b]) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (o < g.O) prow[(size_t)o * g.I + i0 + 32 * b + col] = acc[a][b][r];
+            }
+        }
+        if (ig == 0) {
+            const float s = bsum[a] + __shfl_down(bsum[a], 32, 64);
+            if (kh == 0 && oko[a]) prow[(size_t)g.O * g.I + o0 + 32 * a + col] = s;
+        }
+    }
+}
+
+// dW[O*I] (+ db[O]) = sum over slabs of part rows; grid (ceil(n / 256), RGROUPS), outputs pre-zeroed
+__global__ void linear_wgrad_reduce_kernel(const float *__restrict__ part, int nslabs, int OI, int O,
+                                           float *__restrict__ dW, float *__restrict__ db)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = OI + O;
+    if (idx >= n) return;
+    float s0 = 0.f, s1 = 0.f;
+    int r = blockIdx.y;
+    for (; r + RGROUPS < nslabs; r += 2 * RGROUPS) {
+        s0 += part[(size_t)r * n + idx];
+        s1 += part[(size_t)(r + RGROUPS) * n + idx];
+    }
+    if (r < nslabs) s0 += part[(size_t)r * n + idx];
+    const float s = s0 + s1;
+    if (idx < OI) atomicAdd(dW + idx, s);
+    else if (db) atomicAdd(db + (idx - OI), s);
+}
+
+int make_geom(WGeom &g, int M, int O, int I, int dys, int xs)
+{
+    if (M <= 0 || O <= 0 || I <= 0 || dys < O || xs < I) return MLAGG_E_UNSUPPORTED;
+    g.M = M; g.O = O; g.I = I; g.dy_stride = dys; g.x_stride = xs;
+    g.ogroups = (O + TMAX * 32 - 1) / (TMAX * 32);
+    g.igroups = (I + TMAX * 32 - 1) / (TMAX * 32);
+    // ~2 waves per SIMD (1024 SIMDs), slabs of an even number of tokens, at least 64
+    int slab = (int)(((long long)M * g.ogroups * g.igroups + 2047) / 2048);
+    slab = ((slab + 7) / 8) * 8;
+    if (slab < 64) slab = 64;
+    g.slab = slab;
+    g.nslabs = (M + slab - 1) / slab;
+    if (g.ogroups > 65535 || g.igroups > 65535) return MLAGG_E_UNSUPPORTED;
+    return 0;
+}
+
+template <int TO, int TI>
+void launch(const float *dy, const float *x, float *part, const WGeom &g, hipStream_t st)
+{
+    hipLaunchKernelGGL((linear_wgrad_kernel<TO, TI>), dim3(g.nslabs, g.ogroups, g.igroups), dim3(64), 0, st, dy, x,
+                       part, g);
+}
+
+}  // namespace
+
+extern "C" size_t mlagg_linear_wgrad_workspace_floats(int M, int O, int I)
+{
+    WGeom g;
+    if (make_geom(g, M, O, I, O, I)) return 0;
+    return (size_t)g.nslabs * ((size_t)O * I + O);
+}
+
+extern "C" int mlagg_linear_wgrad(const float *dy, int dy_stride, const float *x, int x_stride, float *dW, float *db,
+                                  float *workspace, int M, int O, int I, void *stream)
+{
+    if (!dy || !x || !dW || !workspace) return MLAGG_E_NULLPTR;
+    WGeom g;
+    if (int rc = make_geom(g, M, O, I, dy_stride, x_stride)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    (void)hipMemsetAsync(dW, 0, sizeof(float) * (size_t)O * I, st);
+    if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)O, st);
+    // tiles per wave: full 3x3 groups when a dimension exceeds 96, else exactly what the dimension needs
+    const int to = g.ogroups > 1 ? TMAX : (O + 31) / 32;
+    const int ti = g.igroups > 1 ? TMAX : (I + 31) / 32;
+    {
+        MLAGG_TIMED(K_LINEAR_WGRAD, st);
+        switch (to * 4 + ti) {
+        case 1 * 4 + 1: launch<1, 1>(dy, x, workspace, g, st); break;
+        case 1 * 4 + 2: launch<1, 2>(dy, x, workspace, g, st); break;
+        case 1 * 4 + 3: launch<1, 3>(dy, x, workspace, g, st); break;
+        case 2 * 4 + 1: launch<2, 1>(dy, x, workspace, g, st); break;
+        case 2 * 4 + 2: launch<2, 2>(dy, x, workspace, g, st); break;
+        case 2 * 4 + 3: launch<2, 3>(dy, x, workspace, g, st); break;
+        case 3 * 4 + 1: launch<3, 1>(dy, x, workspace, g, st); break;
+        case 3 * 4 + 2: launch<3, 2>(dy, x, workspace, g, st); break;
+        default: launch<3, 3>(dy, x, workspace, g, st); break;
+        }
+    }
+    const int n = O * I + O;
+    hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((n + 255) / 256, RGROUPS), dim3(256), 0, st, workspace,
+                       g.nslabs, O * I, O, dW, db);
+    return (int)hipGetLastError();
+}

@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 
 #include "mlagg_hip.h"
+#include "prof.h"
+#include "internal.h"
 
 namespace {
 
@@ -338,37 +340,6 @@ local_attn_bwd_b_kernel(const float *__restrict__ q, const float *__restrict__ l
     store12(dkv + tok * dkv_stride + g.d + cbase, dv);
 }
 
-// backward C: LePE (depthwise 3x3 on v) weight / bias gradients.  Lane = channel (coalesced in the
-// token-major layout), each workgroup sweeps LEPE_TOK tokens and issues 10 atomics per channel.
-constexpr int LEPE_TOK = 256;
-__global__ void local_attn_lepe_wgrad_kernel(const float *__restrict__ kv, const float *__restrict__ dout,
-                                             int dout_stride, float *__restrict__ dlepe_w,
-                                             float *__restrict__ dlepe_b, Geom g)
-{
-    const int c = blockIdx.y * blockDim.x + threadIdx.x;
-    if (c >= g.d) return;
-    const int N = g.H * g.W, b = blockIdx.z;
-    const int t_begin = blockIdx.x * LEPE_TOK, t_end = min(t_begin + LEPE_TOK, N);
-    float gw[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float gb = 0.f;
-    for (int t = t_begin; t < t_end; ++t) {
-        const int y = t / g.W, x = t - y * g.W;
-        const float vme = kv[((size_t)b * N + t) * g.kv_stride + g.d + c];
-#pragma unroll
-        for (int jj = 0; jj < 9; ++jj) {
-            const int yy = y + jj / 3 - 1, xx = x + jj % 3 - 1;
-            if (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) {
-                const float dy = dout[((size_t)b * N + (size_t)yy * g.W + xx) * dout_stride + c];
-                gw[8 - jj] += dy * vme;
-                if (jj == 4) gb += dy;
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 9; ++j) atomicAdd(dlepe_w + c * 9 + j, gw[j]);
-    atomicAdd(dlepe_b + c, gb);
-}
-
 int make_geom(Geom &g, int batch, int H, int W, int nh, int qs, int kvs, int outs, float scale)
 {
     if (batch <= 0 || H <= 0 || W <= 0 || nh <= 0 || batch > 65535 || nh > 65535) return MLAGG_E_UNSUPPORTED;
@@ -394,14 +365,15 @@ extern "C" int mlagg_local_attn_fwd(const float *q, int q_stride, const float *k
     Geom g;
     if (int rc = make_geom(g, batch, H, W, nh, q_stride, kv_stride, out_stride, scale)) return rc;
     if (out_stride < g.d || (out_stride & 3)) return MLAGG_E_UNSUPPORTED;
-    hipLaunchKernelGGL(local_attn_fwd_kernel, tile_grid(g), dim3(256), 0, static_cast<hipStream_t>(stream), q, kv,
-                       lam, subln_w, lepe_w, lepe_b, out, g);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    { MLAGG_TIMED(K_LOCAL_FWD, st); hipLaunchKernelGGL(local_attn_fwd_kernel, tile_grid(g), dim3(256), 0, st, q, kv, lam, subln_w, lepe_w, lepe_b,
+                       out, g); }
     return (int)hipGetLastError();
 }
 
 extern "C" size_t mlagg_local_attn_bwd_workspace_floats(int batch, int H, int W, int nh)
 {
-    return (size_t)batch * H * W * nh * WS_PER_UNIT;
+    return (size_t)batch * H * W * nh * WS_PER_UNIT + mlagg_internal::dwconv_wgrad_workspace_floats(batch, H, W, nh * HD2);
 }
 
 extern "C" int mlagg_local_attn_bwd(const float *q, int q_stride, const float *kv, int kv_stride,
@@ -420,13 +392,12 @@ extern "C" int mlagg_local_attn_bwd(const float *q, int q_stride, const float *k
         (dkv_stride & 3))
         return MLAGG_E_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(local_attn_bwd_a_kernel, tile_grid(g), dim3(256), 0, st, q, kv, lam, subln_w, dout,
-                       dout_stride, dq, dq_stride, workspace, dlam, dsubln_w, g);
-    hipLaunchKernelGGL(local_attn_bwd_b_kernel, tile_grid(g), dim3(256), 0, st, q, lepe_w, dout, dout_stride,
-                       workspace, dkv, dkv_stride, g);
-    const int cthreads = g.d < 256 ? ((g.d + 63) / 64) * 64 : 256;
-    hipLaunchKernelGGL(local_attn_lepe_wgrad_kernel,
-                       dim3((H * W + LEPE_TOK - 1) / LEPE_TOK, (g.d + cthreads - 1) / cthreads, batch),
-                       dim3(cthreads), 0, st, kv, dout, dout_stride, dlepe_w, dlepe_b, g);
+    { MLAGG_TIMED(K_LOCAL_BWD_A, st); hipLaunchKernelGGL(local_attn_bwd_a_kernel, tile_grid(g), dim3(256), 0, st, q, kv, lam, subln_w, dout,
+                       dout_stride, dq, dq_stride, workspace, dlam, dsubln_w, g); }
+    { MLAGG_TIMED(K_LOCAL_BWD_B, st); hipLaunchKernelGGL(local_attn_bwd_b_kernel, tile_grid(g), dim3(256), 0, st, q, lepe_w, dout, dout_stride,
+                       workspace, dkv, dkv_stride, g); }
+    // LePE is a depthwise 3x3 on v: its weight/bias gradients are K2's weight-gradient kernel on (v, dout)
+    mlagg_internal::dwconv_wgrad_launch(kv + g.d, kv_stride, dout, dout_stride, nullptr, dlepe_w, dlepe_b,
+                                        workspace + (size_t)batch * H * W * nh * WS_PER_UNIT, batch, H, W, g.d, 0, st);
     return (int)hipGetLastError();
 }

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mlagg_hip.h"
+#include "prof.h"
 
 namespace {
 
@@ -28,7 +29,8 @@ constexpr int HD = 24;        // head_dim
 constexpr int HD2 = 48;
 constexpr int TOK_PER_BLOCK = 128;        // forward / backward-1: 256 threads = 128 lane pairs
 constexpr int TCH = 64;                   // backward-2: tokens per LDS tile
-constexpr int CHUNKS_PER_BLOCK = 4;       // backward-2: tiles per workgroup
+constexpr int CHUNKS_PER_BLOCK = 1;       // backward-2: tiles per workgroup (more, shorter waves: the kernel
+                                          // is issue/latency-bound at <1 wave per SIMD otherwise)
 constexpr int WS_PER_UNIT = 52;           // d(o)[48], D1, D2, pad
 constexpr float RMS_EPS = 1e-5f;
 constexpr float OUT_GAIN = 0.2f;
@@ -358,8 +360,9 @@ extern "C" int mlagg_pooled_attn_fwd(const float *q, int q_stride, const float *
     if (int rc = make_geom(g, batch, N, P, nh, q_stride, kp_stride, vp_stride, out_stride, scale)) return rc;
     const size_t lds = kv_lds_bytes(g, false);
     if (int rc = allow_lds(pooled_attn_fwd_kernel, lds)) return rc;
-    hipLaunchKernelGGL(pooled_attn_fwd_kernel, dim3((N + TOK_PER_BLOCK - 1) / TOK_PER_BLOCK, nh, batch), dim3(256),
-                       lds, static_cast<hipStream_t>(stream), q, kp, vp, lam, subln_w, out, lse, o_pre, g);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    { MLAGG_TIMED(K_POOLED_FWD, st); hipLaunchKernelGGL(pooled_attn_fwd_kernel, dim3((N + TOK_PER_BLOCK - 1) / TOK_PER_BLOCK, nh, batch), dim3(256),
+                       lds, st, q, kp, vp, lam, subln_w, out, lse, o_pre, g); }
     return (int)hipGetLastError();
 }
 
@@ -385,12 +388,12 @@ extern "C" int mlagg_pooled_attn_bwd(const float *q, int q_stride, const float *
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t lds = kv_lds_bytes(g, true);
     if (int rc = allow_lds(pooled_attn_bwd1_kernel, lds)) return rc;
-    hipLaunchKernelGGL(pooled_attn_bwd1_kernel, dim3((N + TOK_PER_BLOCK - 1) / TOK_PER_BLOCK, nh, batch), dim3(256),
+    { MLAGG_TIMED(K_POOLED_BWD1, st); hipLaunchKernelGGL(pooled_attn_bwd1_kernel, dim3((N + TOK_PER_BLOCK - 1) / TOK_PER_BLOCK, nh, batch), dim3(256),
                        lds, st, q, kp, vp, lam, subln_w, dout, dout_stride, lse, o_pre, dq, dq_stride, workspace,
-                       dlam, dsubln_w, g);
+                       dlam, dsubln_w, g); }
     const int pblocks = (P + 63) / 64;
     const int tblocks = (N + TCH * CHUNKS_PER_BLOCK - 1) / (TCH * CHUNKS_PER_BLOCK);
-    hipLaunchKernelGGL(pooled_attn_bwd2_kernel, dim3(pblocks * tblocks, nh, batch), dim3(64), 0, st, q, kp, vp, lam,
-                       lse, workspace, dkp, dkp_stride, dvp, dvp_stride, g);
+    { MLAGG_TIMED(K_POOLED_BWD2, st); hipLaunchKernelGGL(pooled_attn_bwd2_kernel, dim3(pblocks * tblocks, nh, batch), dim3(64), 0, st, q, kp, vp, lam,
+                       lse, workspace, dkp, dkp_stride, dvp, dvp_stride, g); }
     return (int)hipGetLastError();
 }

@@ -1,0 +1,32 @@
+// Optional per-kernel HIP-event timing used by bench.py's roofline line (off by default: zero cost).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mlagg_prof {
+
+enum KernelId {
+    K_SELSCAN_FWD_LOCAL = 0, K_SELSCAN_PREFIX, K_SELSCAN_FWD_FINAL, K_SELSCAN_BWD_LOCAL, K_SELSCAN_BWD,
+    K_SELSCAN_REDUCE, K_LOCAL_FWD, K_LOCAL_BWD_A, K_LOCAL_BWD_B, K_POOLED_FWD,
+    K_POOLED_BWD1, K_POOLED_BWD2, K_DWCONV_FWD, K_DWCONV_BWD_DATA, K_DWCONV_BWD_WEIGHT, K_LINEAR_WGRAD, K_COUNT
+};
+
+extern int g_selected;                 // -1: off, -2: every kernel, else one KernelId
+void record(int id, hipStream_t st, bool begin);
+
+struct Scope {
+    int id;
+    hipStream_t st;
+    bool on;
+    Scope(int id_, hipStream_t st_) : id(id_), st(st_), on(g_selected == -2 || g_selected == id_)
+    {
+        if (on) record(id, st, true);
+    }
+    ~Scope()
+    {
+        if (on) record(id, st, false);
+    }
+};
+
+}  // namespace mlagg_prof
+
+#define MLAGG_TIMED(id, st) mlagg_prof::Scope mlagg_prof_scope_##id(mlagg_prof::id, st)

@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include "mlagg_hip.h"
+#include "prof.h"
 
 namespace {
 
@@ -175,32 +176,32 @@ __global__ void selscan_fwd_kernel(const float *__restrict__ u, const float *__r
     float dsum = 0.f;
     const int tc0 = id.chunk * TC;
 
-    float4 pu, pd, pbc;
-    pu = pd = pbc = make_float4(0.f, 0.f, 0.f, 0.f);
-    {
-        const int t = tc0 + 4 * id.s;
-        if (id.act) { pu = load4(urow, t, L, vec); pd = load4(drow, t, L, vec); }
-        if (bcrow) pbc = load4(bcrow, tc0 + 4 * (tid & 3), L, vec);
+    // Every load of the chunk is issued up front (4 sub-tiles x {u, delta, B|C} = 12 float4 per lane in
+    // flight): the kernel is latency-bound on 64-byte row segments, so memory-level parallelism, not
+    // LDS capacity, is what the chunk needs; LDS still only ever holds one 16-step sub-tile.
+    float4 pu[NSUB], pd[NSUB], pbc[NSUB];
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+        const int t0 = tc0 + sub * ST;
+        pu[sub] = pd[sub] = pbc[sub] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (id.act) { pu[sub] = load4(urow, t0 + 4 * id.s, L, vec); pd[sub] = load4(drow, t0 + 4 * id.s, L, vec); }
+        if (bcrow) pbc[sub] = load4(bcrow, t0 + 4 * (tid & 3), L, vec);
     }
 
+#pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
         const int t0 = tc0 + sub * ST;
         __syncthreads();
         if (id.act) {
-            *reinterpret_cast<float4 *>(su + id.cl * UP + 4 * id.s) = pu;
+            *reinterpret_cast<float4 *>(su + id.cl * UP + 4 * id.s) = pu[sub];
             *reinterpret_cast<float4 *>(sd + id.cl * UP + 4 * id.s) =
-                activate_delta(pd, bias, softplus, t0 + 4 * id.s, L);
+                activate_delta(pd[sub], bias, softplus, t0 + 4 * id.s, L);
         }
         if (bcrow) {
             float *dst = (tid < 64 ? sB : sC) + (4 * (tid & 3)) * BP + ((tid & 63) >> 2);
-            dst[0] = pbc.x; dst[BP] = pbc.y; dst[2 * BP] = pbc.z; dst[3 * BP] = pbc.w;
+            dst[0] = pbc[sub].x; dst[BP] = pbc[sub].y; dst[2 * BP] = pbc[sub].z; dst[3 * BP] = pbc[sub].w;
         }
         __syncthreads();
-        if (sub + 1 < NSUB) {
-            const int t = t0 + ST + 4 * id.s;
-            if (id.act) { pu = load4(urow, t, L, vec); pd = load4(drow, t, L, vec); }
-            if (bcrow) pbc = load4(bcrow, t0 + ST + 4 * (tid & 3), L, vec);
-        }
         if (id.act) {
             float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -289,31 +290,28 @@ __global__ void selscan_bwd_local_kernel(const float *__restrict__ delta, const 
         q[i] = 0.f;
     }
     const int tc0 = id.chunk * TC;
-    float4 pg, pd, pc;
-    pg = pd = pc = make_float4(0.f, 0.f, 0.f, 0.f);
-    {
-        const int t0 = tc0 + (NSUB - 1) * ST;
-        if (id.act) { pg = load4(grow, t0 + 4 * id.s, L, vec); pd = load4(drow, t0 + 4 * id.s, L, vec); }
-        if (crow) pc = load4(crow, t0 + 4 * (tid & 3), L, vec);
+    float4 pg[NSUB], pd[NSUB], pc[NSUB];          // all loads of the chunk in flight at once (see forward)
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+        const int t0 = tc0 + sub * ST;
+        pg[sub] = pd[sub] = pc[sub] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (id.act) { pg[sub] = load4(grow, t0 + 4 * id.s, L, vec); pd[sub] = load4(drow, t0 + 4 * id.s, L, vec); }
+        if (crow) pc[sub] = load4(crow, t0 + 4 * (tid & 3), L, vec);
     }
+#pragma unroll
     for (int sub = NSUB - 1; sub >= 0; --sub) {
         const int t0 = tc0 + sub * ST;
         __syncthreads();
         if (id.act) {
-            *reinterpret_cast<float4 *>(sg + id.cl * UP + 4 * id.s) = pg;
+            *reinterpret_cast<float4 *>(sg + id.cl * UP + 4 * id.s) = pg[sub];
             *reinterpret_cast<float4 *>(sd + id.cl * UP + 4 * id.s) =
-                activate_delta(pd, bias, softplus, t0 + 4 * id.s, L);
+                activate_delta(pd[sub], bias, softplus, t0 + 4 * id.s, L);
         }
         if (crow) {
             float *dst = sC + (4 * (tid & 3)) * BP + (tid >> 2);
-            dst[0] = pc.x; dst[BP] = pc.y; dst[2 * BP] = pc.z; dst[3 * BP] = pc.w;
+            dst[0] = pc[sub].x; dst[BP] = pc[sub].y; dst[2 * BP] = pc[sub].z; dst[3 * BP] = pc[sub].w;
         }
         __syncthreads();
-        if (sub > 0) {
-            const int tn = t0 - ST;
-            if (id.act) { pg = load4(grow, tn + 4 * id.s, L, vec); pd = load4(drow, tn + 4 * id.s, L, vec); }
-            if (crow) pc = load4(crow, tn + 4 * (tid & 3), L, vec);
-        }
         if (id.act) {
 #pragma unroll
             for (int qq = 3; qq >= 0; --qq) {
@@ -685,12 +683,12 @@ extern "C" int mlagg_selscan_fwd(const float *u, const float *delta, const float
     float *cdsum = chunk_state + (size_t)batch * gm.nchunks * dim * NS;
     const dim3 grid(gm.nchunks, G * gm.nblk, batch), block(block_threads(gm));
     const size_t lds = (size_t)(2 * gm.CB * UP + 2 * ST * BP) * sizeof(float);
-    hipLaunchKernelGGL(selscan_fwd_kernel<false>, grid, block, lds, st, u, delta, A, B, C, D, delta_bias, out,
-                       cstate, cdsum, gm, delta_softplus);
-    hipLaunchKernelGGL(selscan_chunk_prefix, dim3((dim * NS + 255) / 256, batch), dim3(256), 0, st, A, cstate,
-                       cdsum, gm, 0);
-    hipLaunchKernelGGL(selscan_fwd_kernel<true>, grid, block, lds, st, u, delta, A, B, C, D, delta_bias, out,
-                       cstate, cdsum, gm, delta_softplus);
+    { MLAGG_TIMED(K_SELSCAN_FWD_LOCAL, st); hipLaunchKernelGGL(selscan_fwd_kernel<false>, grid, block, lds, st, u, delta, A, B, C, D, delta_bias, out,
+                       cstate, cdsum, gm, delta_softplus); }
+    { MLAGG_TIMED(K_SELSCAN_PREFIX, st); hipLaunchKernelGGL(selscan_chunk_prefix, dim3((dim * NS + 255) / 256, batch), dim3(256), 0, st, A, cstate,
+                       cdsum, gm, 0); }
+    { MLAGG_TIMED(K_SELSCAN_FWD_FINAL, st); hipLaunchKernelGGL(selscan_fwd_kernel<true>, grid, block, lds, st, u, delta, A, B, C, D, delta_bias, out,
+                       cstate, cdsum, gm, delta_softplus); }
     return (int)hipGetLastError();
 }
 
@@ -718,13 +716,13 @@ extern "C" int mlagg_selscan_bwd(const float *u, const float *delta, const float
         (void)hipMemsetAsync(dC, 0, bytes, st);
     }
     const size_t lds1 = (size_t)(2 * gm.CB * UP + ST * BP) * sizeof(float);
-    hipLaunchKernelGGL(selscan_bwd_local_kernel, grid, block, lds1, st, delta, A, C, delta_bias, dout, cq, gm,
-                       delta_softplus);
-    hipLaunchKernelGGL(selscan_chunk_prefix, dim3((dim * NS + 255) / 256, batch), dim3(256), 0, st, A, cq, cdsum,
-                       gm, 1);
+    { MLAGG_TIMED(K_SELSCAN_BWD_LOCAL, st); hipLaunchKernelGGL(selscan_bwd_local_kernel, grid, block, lds1, st, delta, A, C, delta_bias, dout, cq, gm,
+                       delta_softplus); }
+    { MLAGG_TIMED(K_SELSCAN_PREFIX, st); hipLaunchKernelGGL(selscan_chunk_prefix, dim3((dim * NS + 255) / 256, batch), dim3(256), 0, st, A, cq, cdsum,
+                       gm, 1); }
     const size_t lds3 = (size_t)(3 * gm.CB * UP + 2 * ST * BP + 2 * ST * NS) * sizeof(float);
-    hipLaunchKernelGGL(selscan_bwd_kernel, grid, block, lds3, st, u, delta, A, B, C, D, delta_bias, dout, cstate,
-                       cq, du, ddelta, dB, dC, part, gm, delta_softplus, atomic_bc);
-    hipLaunchKernelGGL(selscan_reduce_partials, dim3(dim), dim3(256), 0, st, part, dA, dD, ddelta_bias, gm);
+    { MLAGG_TIMED(K_SELSCAN_BWD, st); hipLaunchKernelGGL(selscan_bwd_kernel, grid, block, lds3, st, u, delta, A, B, C, D, delta_bias, dout, cstate,
+                       cq, du, ddelta, dB, dC, part, gm, delta_softplus, atomic_bc); }
+    { MLAGG_TIMED(K_SELSCAN_REDUCE, st); hipLaunchKernelGGL(selscan_reduce_partials, dim3(dim), dim3(256), 0, st, part, dA, dD, ddelta_bias, gm); }
     return (int)hipGetLastError();
 }

@@ -42,11 +42,18 @@ class DropPath(nn.Module):
         return x * (mask / keep)
 
 
+class Linear(nn.Linear):
+    """nn.Linear (same parameter names) whose weight/bias gradients run on K5w for large token counts."""
+
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+
 class Mlp(nn.Module):
     def __init__(self, dim, hidden):
         super().__init__()
-        self.fc1 = nn.Linear(dim, hidden)
-        self.fc2 = nn.Linear(hidden, dim)
+        self.fc1 = Linear(dim, hidden)
+        self.fc2 = Linear(hidden, dim)
 
     def forward(self, x):
         return self.fc2(F.gelu(self.fc1(x)))
@@ -80,8 +87,8 @@ class AggregatedAttention(nn.Module):
             self.pool_H, self.pool_W = self.H // sr_ratio, self.W // sr_ratio
             self.sr = nn.Conv2d(dim, dim, 1)
             self.norm = nn.LayerNorm(dim)
-        self.q = nn.Linear(dim, dim)
-        self.kv = nn.Linear(dim, 2 * dim)
+        self.q = Linear(dim, dim)
+        self.kv = Linear(dim, 2 * dim)
         self.lepe = nn.Conv2d(dim, dim, 3, padding=1, groups=dim)
 
     def lambda_full(self):
@@ -99,8 +106,8 @@ class AggregatedAttention(nn.Module):
             return ops.local_diff_attn(q, kv, lam, self.subln.weight, self.lepe.weight, self.lepe.bias,
                                        self.H, self.W, self.num_heads, self.scale)
         # only the value half of kv(x) is used at full resolution (LePE); k is discarded at T:719
-        v_full = F.linear(x, self.kv.weight[d:], self.kv.bias[d:])
-        s = F.gelu(F.linear(x, self.sr.weight.view(d, d), self.sr.bias))
+        v_full = ops.linear(x, self.kv.weight[d:], self.kv.bias[d:])
+        s = F.gelu(ops.linear(x, self.sr.weight.view(d, d), self.sr.bias))
         if self.H % self.sr_ratio == 0 and self.W % self.sr_ratio == 0:
             r = self.sr_ratio
             pooled = s.view(B, self.pool_H, r, self.pool_W, r, d).mean(dim=(2, 4)).reshape(B, -1, d)
@@ -120,13 +127,13 @@ class MLLABlock(nn.Module):
         super().__init__()
         self.dim, self.input_resolution = dim, tuple(input_resolution)
         self.norm1 = nn.LayerNorm(dim)
-        self.in_proj = nn.Linear(dim, dim)
-        self.act_proj = nn.Linear(dim, dim)
+        self.in_proj = Linear(dim, dim)
+        self.act_proj = Linear(dim, dim)
         self.dwc = nn.Conv2d(dim, dim, 3, padding=1, groups=dim)
         self.attn = nn.ModuleList([
             AggregatedAttention(dim // 2, input_resolution, num_heads // 2, True, sr_ratio, variant),
             AggregatedAttention(dim // 2, input_resolution, num_heads // 2, False, sr_ratio, variant)])
-        self.out_proj = nn.Linear(dim, dim)
+        self.out_proj = Linear(dim, dim)
         self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
@@ -136,8 +143,13 @@ class MLLABlock(nn.Module):
         C = self.dim
         xn = self.norm1(x)
         act_res = F.silu(self.act_proj(xn))
-        xc = ops.dwconv3x3_nlc(self.in_proj(xn), self.dwc.weight, self.dwc.bias, H, W, silu=True)
-        mixed = torch.cat([self.attn[0](xc[..., :C // 2]), self.attn[1](xc[..., C // 2:])], dim=-1)
+        # depthwise conv per channel half: the halves come out contiguous for the branch projections
+        # (a channel slice of a (B, N, C) row would be copied by every Linear that consumes it)
+        xi = self.in_proj(xn)
+        h = C // 2
+        xa = ops.dwconv3x3_nlc(xi[..., :h], self.dwc.weight[:h], self.dwc.bias[:h], H, W, silu=True)
+        za = ops.dwconv3x3_nlc(xi[..., h:], self.dwc.weight[h:], self.dwc.bias[h:], H, W, silu=True)
+        mixed = torch.cat([self.attn[0](xa), self.attn[1](za)], dim=-1)
         x = x + self.drop_path(self.out_proj(mixed * act_res))
         return x + self.drop_path(self.mlp(self.norm2(x)))
 
@@ -336,7 +348,7 @@ class SS2D_skip(nn.Module):
         self.d_model, self.d_state = d_model, d_state
         self.d_inner = int(expand * d_model)
         self.dt_rank = math.ceil(d_model / 16)
-        self.in_proj = nn.Linear(d_model, self.d_inner, bias=False)
+        self.in_proj = Linear(d_model, self.d_inner, bias=False)
         self.conv2d = nn.ModuleList([
             nn.Conv2d(self.d_inner, self.d_inner, 3, padding=1, groups=self.d_inner) for _ in range(stage_num)])
         xp = [nn.Linear(self.d_inner, self.dt_rank + 2 * d_state, bias=False) for _ in range(4)]
@@ -348,7 +360,7 @@ class SS2D_skip(nn.Module):
         self.A_logs = nn.Parameter(torch.log(A))
         self.Ds = nn.Parameter(torch.ones(4 * self.d_inner))
         self.out_norm = nn.LayerNorm(self.d_inner)
-        self.out_proj = nn.Linear(self.d_inner, d_model, bias=False)
+        self.out_proj = Linear(self.d_inner, d_model, bias=False)
 
     def core(self, xs_tok: List[torch.Tensor], HW):
         """xs_tok[i]: (B, H_i*W_i, d_inner) token-major conv outputs -> (B, L_cat, d_inner) sum of the four
@@ -406,9 +418,9 @@ class ConvolutionalGLU(nn.Module):  # reference M:559-577
         super().__init__()
         hidden = int(2 * hidden / 3)
         self.hidden = hidden
-        self.fc1 = nn.Linear(dim, hidden * 2)
+        self.fc1 = Linear(dim, hidden * 2)
         self.dwconv = _DWConv(hidden)
-        self.fc2 = nn.Linear(hidden, dim)
+        self.fc2 = Linear(hidden, dim)
 
     def forward(self, x, H, W):
         xv = self.fc1(x)

@@ -114,8 +114,10 @@ class DWConv3x3Fn(torch.autograd.Function):
         dx = torch.empty(B, N, C, device=x.device, dtype=torch.float32)
         dw = torch.zeros(C, 9, device=x.device, dtype=torch.float32)
         db = torch.zeros(C, device=x.device, dtype=torch.float32) if has_bias else None
-        _lib.check(_lib.lib().mlagg_dwconv3x3_bwd(_ptr(x), x.stride(1), _ptr(w), _ptr(dy), dys, _ptr(pre), _ptr(dx), C,
-                                                  _ptr(dw), _ptr(db), B, H, W, C, int(silu), _stream()),
+        lib = _lib.lib()
+        ws = torch.empty(lib.mlagg_dwconv3x3_bwd_workspace_floats(B, H, W, C), device=x.device, dtype=torch.float32)
+        _lib.check(lib.mlagg_dwconv3x3_bwd(_ptr(x), x.stride(1), _ptr(w), _ptr(dy), dys, _ptr(pre), _ptr(dx), C,
+                                           _ptr(dw), _ptr(db), _ptr(ws), B, H, W, C, int(silu), _stream()),
                    "mlagg_dwconv3x3_bwd")
         return dx, dw.reshape(wshape), db, None, None, None
 
@@ -216,3 +218,54 @@ def local_diff_attn(q, kv, lam, subln_w, lepe_w, lepe_b, H, W, nh, scale):
 
 def pooled_diff_attn(q, k_pool, v_pool, lam, subln_w, nh, scale):
     return PooledDiffAttnFn.apply(q, k_pool, v_pool, lam, subln_w, nh, scale)
+
+
+WGRAD_MIN_ROWS = 8192      # below this many tokens the library GEMM is no longer the split-K corner case
+
+
+def _rows2d(t, name):
+    """(..., C) tensor -> (M, C) view with unit inner stride and one row stride; copies only if it must."""
+    _require(t, name)
+    t2 = t.reshape(-1, t.shape[-1])
+    if t2.stride(1) != 1:
+        t2 = t2.contiguous()
+    return t2, t2.stride(0)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b.  Forward and dx on the library GEMM (plain dense contraction); dW / db on K5w, the
+    split-K-over-tokens MFMA kernel, when the token count makes it the tall-skinny case."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = dy.matmul(weight)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            O, I = weight.shape
+            dy2, dys = _rows2d(dy, "dy")
+            x2, xs = _rows2d(x, "x")
+            M = dy2.shape[0]
+            if M >= WGRAD_MIN_ROWS:
+                lib = _lib.lib()
+                dW = torch.empty_like(weight)
+                db = torch.empty(O, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
+                ws = torch.empty(lib.mlagg_linear_wgrad_workspace_floats(M, O, I), device=dy.device,
+                                 dtype=torch.float32)
+                _lib.check(lib.mlagg_linear_wgrad(_ptr(dy2), dys, _ptr(x2), xs, _ptr(dW), _ptr(db), _ptr(ws), M, O, I,
+                                                  _stream()), "mlagg_linear_wgrad")
+            else:
+                dW = dy2.t().matmul(x2)
+                db = dy2.sum(0) if ctx.has_bias else None
+        return dx, dW, db
+
+
+def linear(x, weight, bias=None):
+    return LinearFn.apply(x, weight, bias)

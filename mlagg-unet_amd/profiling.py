@@ -1,0 +1,59 @@
+"""Host side of the library's per-kernel HIP-event timers + the algorithmic byte counts the roofline
+line of bench.py prices each kernel with (derivations in DESIGN.md)."""
+import ctypes
+
+from . import _lib
+
+
+def _names():
+    lib = _lib.lib()
+    return [lib.mlagg_profile_kernel_name(i).decode() for i in range(lib.mlagg_profile_kernel_count())]
+
+
+def select_all():
+    _lib.check(_lib.lib().mlagg_profile_select(-2), "mlagg_profile_select")
+
+
+def select(name):
+    idx = -1 if name is None else _names().index(name)
+    _lib.check(_lib.lib().mlagg_profile_select(idx), "mlagg_profile_select")
+
+
+def collect():
+    """{kernel name: {"ms": summed milliseconds, "count": launches}} since the last collect()."""
+    lib = _lib.lib()
+    n = lib.mlagg_profile_kernel_count()
+    ms = (ctypes.c_double * n)()
+    cnt = (ctypes.c_int * n)()
+    _lib.check(lib.mlagg_profile_collect(ms, cnt), "mlagg_profile_collect")
+    return {nm: {"ms": ms[i], "count": cnt[i]} for i, nm in enumerate(_names()) if cnt[i] > 0}
+
+
+def algorithmic_bytes(kernel, batch, img):
+    """Bytes ONE launch of `kernel` must move for `batch` images of size img (fp32, D = 384 scan channels,
+    N = 16 states, G = 4 directions; C * tokens = 96 * 128 * 128 at every encoder stage)."""
+    H, W = img
+    n0 = (H // 2) * (W // 2)                      # stage-0 tokens
+    l_cat = sum(n0 >> (2 * i) for i in range(4))  # 21760 at 256x256
+    D, N, G = 384, 16, 4
+    scan = {
+        "selscan_fwd_kernel<false>": 4 * l_cat * (2 * D + G * N),            # read u, delta, B
+        "selscan_fwd_kernel<true>": 4 * l_cat * (3 * D + 2 * G * N),         # K1 fwd op boundary (5120 L)
+        "selscan_bwd_local_kernel": 4 * l_cat * (2 * D + G * N),             # read delta, dy, C
+        "selscan_bwd_kernel": 4 * l_cat * (5 * D + 4 * G * N),               # K1 bwd op boundary (8704 L)
+    }
+    if kernel in scan:
+        return scan[kernel] * batch
+    dn = 48 * n0                                   # (C/2) * N, identical at all four stages
+    per_module = {
+        "local_attn_fwd_kernel": 16 * dn,          # q, k, v in; out
+        "local_attn_bwd_a_kernel": 20 * dn,        # q, k, v, dout in; dq out
+        "local_attn_bwd_b_kernel": 16 * dn,        # q, dout in; dk, dv out
+        "pooled_attn_fwd_kernel": 8 * dn,          # q in, out (pooled K/V negligible)
+        "pooled_attn_bwd1_kernel": 16 * dn,        # q, dout, o_pre in; dq out
+        "pooled_attn_bwd2_kernel": 8 * dn,         # q, d(o) in
+        "dwconv_fwd_kernel": 16 * dn,              # x in, y out at C = 96 * 2^i (the MLLA dwc; other callers differ)
+        "dwconv_bwd_data_kernel": 16 * dn,
+        "dwconv_bwd_weight_kernel": 16 * dn,
+    }
+    return per_module.get(kernel, 0) * batch

@@ -129,7 +129,8 @@ def wrap_ddp(model, device_index=None, bucket_cap_mb=25):
     never-used ``dummy_tensor`` (reference T:1362) is excluded from reduction so that
     ``find_unused_parameters`` can stay False (SURVEY finding 7a)."""
     from torch.nn.parallel import DistributedDataParallel as DDP
-    model._ddp_params_and_buffers_to_ignore = ["dummy_tensor"]
+    # torch builds the name as f"{module_name}.{param_name}", which is ".dummy_tensor" for the root module
+    DDP._set_params_and_buffers_to_ignore_for_model(model, ["dummy_tensor", ".dummy_tensor"])
     ids = None if device_index is None else [device_index]
     return DDP(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True,
                broadcast_buffers=False)

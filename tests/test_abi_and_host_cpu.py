@@ -1,0 +1,106 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mlagg_hip.h declares (no compute
+calls: there is no GPU here), argument validation, and the host logic around the hot path."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mlagg_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mlagg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as G
+    G.build()
+    from mlagg_unet_amd import _lib
+    handle = ctypes.CDLL(_lib.SO_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in mlagg_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(_lib.SIGNATURES) == set(declared)
+    lib = _lib.lib()
+    assert lib.mlagg_version().startswith(b"mlagg_hip")
+    assert b"unsupported" in lib.mlagg_error_string(-1)
+    # size queries are pure host arithmetic
+    assert lib.mlagg_selscan_state_floats(10, 384, 21760, 16) == 10 * 340 * 384 * 17
+    assert lib.mlagg_local_attn_bwd_workspace_floats(2, 8, 8, 1) >= 2 * 64 * 76
+    names = [lib.mlagg_profile_kernel_name(i).decode() for i in range(lib.mlagg_profile_kernel_count())]
+    assert "selscan_bwd_kernel" in names and len(set(names)) == len(names)
+
+
+def test_ops_refuse_cpu_tensors_and_unsupported_arguments():
+    """No CPU / eager fallback: the product ops raise instead of computing elsewhere."""
+    from mlagg_unet_amd import ops
+    u = torch.zeros(1, 8, 16)
+    with pytest.raises(RuntimeError):
+        ops.selective_scan_fn(u, u, torch.zeros(8, 16), torch.zeros(1, 1, 16, 16), torch.zeros(1, 1, 16, 16))
+    with pytest.raises(RuntimeError):
+        ops.selective_scan_fn(u, u, torch.zeros(8, 16), torch.zeros(1, 1, 16, 16), torch.zeros(1, 1, 16, 16),
+                              z=torch.zeros(1, 8, 16))
+    with pytest.raises(RuntimeError):
+        ops.dwconv3x3_nlc(torch.zeros(1, 4, 8), torch.zeros(8, 1, 3, 3), None, 2, 2)
+    with pytest.raises(RuntimeError):
+        ops.local_diff_attn(torch.zeros(1, 4, 48), torch.zeros(1, 4, 96), torch.zeros(()), torch.ones(48),
+                            torch.zeros(48, 1, 3, 3), torch.zeros(48), 2, 2, 1, 24 ** -0.5)
+
+
+def test_product_model_has_reference_state_dict_keys():
+    from mlagg_unet_amd import model
+    from oracle import mlagg_oracle as O
+    m = model.build_network_architecture((64, 64), 1, 14)
+    o = O.build_reference_config_model((64, 64))
+    assert list(sorted(m.state_dict())) == list(sorted(o.state_dict()))
+    assert sum(p.numel() for p in m.parameters()) == 27_095_447
+    for k, v in o.state_dict().items():
+        assert m.state_dict()[k].shape == v.shape, k
+    m2 = model.build_network_architecture((64, 64), 1, 14, enable_deep_supervision=False)
+    assert not any(k.startswith("out_1") for k in m2.state_dict())
+
+
+def test_split_batch_size_never_zero_or_negative():
+    from mlagg_unet_amd import trainer
+    assert trainer.split_batch_size(10, 8) == [2, 2, 1, 1, 1, 1, 1, 1]      # reference gives (2,2,2,2,2,0,-2,-4)
+    assert trainer.split_batch_size(80, 8) == [10] * 8
+    assert sum(trainer.split_batch_size(13, 4)) == 13
+    with pytest.raises(RuntimeError):
+        trainer.split_batch_size(3, 4)
+
+
+def test_cosine_schedule_matches_timm_formula():
+    from mlagg_unet_amd import trainer
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], 5e-4)
+    s = trainer.CosineLRSchedule(opt, t_initial=500, lr_min=1e-6, warmup_t=10, warmup_lr_init=1e-4)
+    s.step(0)
+    assert abs(opt.param_groups[0]["lr"] - 1e-4) < 1e-12
+    s.step(5)
+    assert abs(opt.param_groups[0]["lr"] - (1e-4 + 5 * (5e-4 - 1e-4) / 10)) < 1e-12
+    s.step(250)
+    assert abs(opt.param_groups[0]["lr"] - (1e-6 + 0.5 * (5e-4 - 1e-6))) < 1e-9
+    s.step(500)
+    assert abs(opt.param_groups[0]["lr"] - 1e-6) < 1e-12
+
+
+def test_product_loss_equals_oracle_loss_on_cpu():
+    from mlagg_unet_amd import trainer
+    from oracle import mlagg_oracle as O
+    g = torch.Generator().manual_seed(3)
+    outs = [torch.randn(2, 6, 32 >> s, 32 >> s, generator=g, requires_grad=True) for s in range(5)]
+    tg = [torch.round(torch.rand(2, 1, 32 >> s, 32 >> s, generator=g) * 5) for s in range(5)]
+    for bd in (True, False):
+        a = trainer.deep_supervision_loss(outs, tg, batch_dice=bd)
+        b = O.deep_supervision_loss(outs, tg, batch_dice=bd)
+        assert abs(float(a.detach()) - float(b.detach())) < 1e-6
+        ga = torch.autograd.grad(a, outs)
+        gb = torch.autograd.grad(b, outs)
+        for x, y in zip(ga, gb):
+            assert torch.allclose(x, y, atol=1e-7)

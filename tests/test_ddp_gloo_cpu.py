@@ -1,0 +1,97 @@
+"""CPU, world_size 2 over gloo: the data-parallel pieces of the train step that do not need a GPU --
+the coalesced batch-dice statistics exchange (one all-reduce each way instead of the reference's
+3 all_gathers + 3 all_reduces per level) and DDP wiring with the unused `dummy_tensor` excluded."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn, world=2):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), fn, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+def _dice_case(rank, world):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import mlagg_unet_amd  # noqa: F401
+    from mlagg_unet_amd import trainer
+    g = torch.Generator().manual_seed(17)
+    # the "global" batch of 4, two samples per rank
+    logits = torch.randn(4, 5, 16, 16, generator=g)
+    target = torch.round(torch.rand(4, 1, 16, 16, generator=g) * 4)
+    mine = logits[2 * rank:2 * rank + 2].clone().requires_grad_(True)
+    loss = trainer.soft_dice_loss(mine, target[2 * rank:2 * rank + 2], batch_dice=True, ddp=True)
+    loss.backward()
+    # reference semantics: DDP averages gradients over ranks
+    gsum = mine.grad.clone()
+    dist.all_reduce(gsum)          # only to keep ranks in lock-step; value unused
+    full = logits.clone().requires_grad_(True)
+    ref = trainer.soft_dice_loss(full, target, batch_dice=True, ddp=False)
+    ref.backward()
+    return (float(loss.detach()), float(ref.detach()),
+            float((mine.grad / world - full.grad[2 * rank:2 * rank + 2]).abs().max()))
+
+
+def test_ddp_batch_dice_equals_global_batch_dice():
+    for loss, ref, gerr in _run(_dice_case):
+        assert abs(loss - ref) < 1e-6          # every rank sees the global-batch dice value
+        assert gerr < 1e-7                     # and, after DDP's 1/world averaging, the global gradient
+
+
+class _Tiny(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.lin = torch.nn.Linear(4, 3)
+        self.dummy_tensor = torch.nn.Parameter(torch.tensor([1.0]))    # never used in forward (reference T:1362)
+
+    def forward(self, x):
+        return self.lin(x)
+
+
+def _ddp_case(rank, world):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import mlagg_unet_amd  # noqa: F401
+    from mlagg_unet_amd import trainer
+    torch.manual_seed(0)
+    net = _Tiny()
+    ddp = trainer.wrap_ddp(net)
+    opt = torch.optim.SGD(net.parameters(), 0.1)
+    g = torch.Generator().manual_seed(100 + rank)
+    for _ in range(3):     # the reference configuration errors on the 2nd iteration (SURVEY finding 7a)
+        opt.zero_grad()
+        x = torch.randn(5, 4, generator=g)
+        ddp(x).square().mean().backward()
+        opt.step()
+    trainer.set_deep_supervision_enabled(ddp, False)
+    return [net.lin.weight.detach().clone(), net.dummy_tensor.grad is None, getattr(net, "deep_supervision", None)]
+
+
+def test_ddp_runs_with_unused_dummy_tensor_and_stays_in_sync():
+    res = _run(_ddp_case)
+    assert torch.equal(res[0][0], res[1][0])           # replicas identical after 3 steps
+    assert res[0][1] and res[1][1]                     # dummy_tensor never received a gradient
+    assert res[0][2] is False                          # attribute set on the module, not on the wrapper
