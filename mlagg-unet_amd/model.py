@@ -34,12 +34,22 @@ class DropPath(nn.Module):
         super().__init__()
         self.drop_prob = float(p)
 
-    def forward(self, x):
+    def scale_mask(self, x):
+        """Per-sample keep mask already divided by the keep probability, or None when inactive."""
         if self.drop_prob == 0.0 or not self.training:
-            return x
+            return None
         keep = 1.0 - self.drop_prob
         mask = torch.empty((x.shape[0],) + (1,) * (x.dim() - 1), device=x.device, dtype=x.dtype).bernoulli_(keep)
-        return x * (mask / keep)
+        return mask.div_(keep)
+
+    def forward(self, x):
+        m = self.scale_mask(x)
+        return x if m is None else x * m
+
+    def residual(self, skip, branch):
+        """skip + drop_path(branch) as one fused multiply-add."""
+        m = self.scale_mask(branch)
+        return skip + branch if m is None else torch.addcmul(skip, branch, m)
 
 
 class Linear(nn.Linear):
@@ -100,14 +110,19 @@ class AggregatedAttention(nn.Module):
         """x: (B, N, dim) (may be a channel slice of a wider row) -> (B, N, dim)."""
         B, N, d = x.shape
         lam = self.lambda_full()
-        q = self.q(x)
         if self.local:
-            kv = self.kv(x)
-            return ops.local_diff_attn(q, kv, lam, self.subln.weight, self.lepe.weight, self.lepe.bias,
-                                       self.H, self.W, self.num_heads, self.scale)
-        # only the value half of kv(x) is used at full resolution (LePE); k is discarded at T:719
-        v_full = ops.linear(x, self.kv.weight[d:], self.kv.bias[d:])
-        s = F.gelu(ops.linear(x, self.sr.weight.view(d, d), self.sr.bias))
+            # q and kv in ONE GEMM over stacked weights (one read of x, one gradient into x); the kernel
+            # takes the q / kv column blocks of the (B, N, 3d) result as strided views
+            qkv = ops.linear(x, torch.cat([self.q.weight, self.kv.weight]), torch.cat([self.q.bias, self.kv.bias]))
+            return ops.local_diff_attn(qkv[..., :d], qkv[..., d:], lam, self.subln.weight, self.lepe.weight,
+                                       self.lepe.bias, self.H, self.W, self.num_heads, self.scale)
+        # q, the value half of kv (LePE input; k is discarded at full resolution, T:719) and the 1x1 `sr`
+        # conv in ONE GEMM
+        w3 = torch.cat([self.q.weight, self.kv.weight[d:], self.sr.weight.view(d, d)])
+        b3 = torch.cat([self.q.bias, self.kv.bias[d:], self.sr.bias])
+        qvs = ops.linear(x, w3, b3)
+        q, v_full = qvs[..., :d], qvs[..., d:2 * d]
+        s = F.gelu(qvs[..., 2 * d:])
         if self.H % self.sr_ratio == 0 and self.W % self.sr_ratio == 0:
             r = self.sr_ratio
             pooled = s.view(B, self.pool_H, r, self.pool_W, r, d).mean(dim=(2, 4)).reshape(B, -1, d)
@@ -142,16 +157,21 @@ class MLLABlock(nn.Module):
         H, W = self.input_resolution
         C = self.dim
         xn = self.norm1(x)
-        act_res = F.silu(self.act_proj(xn))
+        # act_proj and in_proj in ONE GEMM over stacked weights: (B, N, 2C) = [act | in]
+        ai = ops.linear(xn, torch.cat([self.act_proj.weight, self.in_proj.weight]),
+                        torch.cat([self.act_proj.bias, self.in_proj.bias]))
+        act_res = F.silu(ai[..., :C])
         # depthwise conv per channel half: the halves come out contiguous for the branch projections
         # (a channel slice of a (B, N, C) row would be copied by every Linear that consumes it)
-        xi = self.in_proj(xn)
         h = C // 2
-        xa = ops.dwconv3x3_nlc(xi[..., :h], self.dwc.weight[:h], self.dwc.bias[:h], H, W, silu=True)
-        za = ops.dwconv3x3_nlc(xi[..., h:], self.dwc.weight[h:], self.dwc.bias[h:], H, W, silu=True)
+        xa = ops.dwconv3x3_nlc(ai[..., C:C + h], self.dwc.weight[:h], self.dwc.bias[:h], H, W, silu=True)
+        za = ops.dwconv3x3_nlc(ai[..., C + h:], self.dwc.weight[h:], self.dwc.bias[h:], H, W, silu=True)
         mixed = torch.cat([self.attn[0](xa), self.attn[1](za)], dim=-1)
-        x = x + self.drop_path(self.out_proj(mixed * act_res))
-        return x + self.drop_path(self.mlp(self.norm2(x)))
+        dp = self.drop_path if isinstance(self.drop_path, DropPath) else None
+        y = self.out_proj(mixed * act_res)
+        x = dp.residual(x, y) if dp is not None else x + y
+        y = self.mlp(self.norm2(x))
+        return dp.residual(x, y) if dp is not None else x + y
 
     def forward(self, x):
         B, C, h, w = x.shape
@@ -170,7 +190,7 @@ class BasicLayer(nn.Module):
 
     def forward(self, x):
         B, C, h, w = x.shape
-        t = x.flatten(2).transpose(1, 2)          # one NCHW -> NLC per stage
+        t = x.flatten(2).transpose(1, 2).contiguous()          # one NCHW -> NLC copy per stage
         for blk in self.blocks:
             t = blk.forward_tokens(t)
         return t.transpose(1, 2).reshape(B, C, h, w).contiguous()
@@ -448,15 +468,15 @@ class VSS_Conv_Block(nn.Module):  # reference M:669-753
         HW = [(t.shape[2], t.shape[3]) for t in inputs]
         Ls = [h * w for h, w in HW]
         hd = self.hidden_dim
-        m = torch.cat([t[:, :hd].flatten(2) for t in inputs], dim=-1).transpose(1, 2)    # (B, L_cat, 48)
-        m = m + self.drop_path(self.self_attention(self.ln_1(m), HW, Ls))
+        m = torch.cat([t[:, :hd].flatten(2) for t in inputs], dim=-1).transpose(1, 2).contiguous()    # (B, L_cat, 48)
+        m = self.drop_path.residual(m, self.self_attention(self.ln_1(m), HW, Ls))
         m = self.norm2(m)
         outs = []
         off = 0
         for i, ((H, W), L) in enumerate(zip(HW, Ls)):
             mi = m[:, off:off + L]
             off += L
-            mi = mi + self.drop_path(self.mlps[i](mi, H, W))
+            mi = self.drop_path.residual(mi, self.mlps[i](mi, H, W))
             mi = mi.transpose(1, 2).reshape(B, hd, H, W)
             outs.append(torch.cat([mi, self.conv_branches[i](inputs[i][:, hd:])], dim=1))
         return outs
