@@ -105,8 +105,8 @@ int mlagg_pooled_attn_fwd(const float *q, int q_stride, const float *kp, int kp_
                           float *o_pre, /* (batch, N, d) output before the RMSNorm, or NULL (inference) */
                           int batch, int N, int P, int nh, float scale, void *stream);
 /* Backward needs the forward's lse / o_pre and mlagg_pooled_attn_bwd_workspace_floats() of scratch.
- * dkp / dvp / dlam / dsubln_w are ACCUMULATED into (caller zero-fills). */
-size_t mlagg_pooled_attn_bwd_workspace_floats(int batch, int N, int nh);
+ * dq / dkp / dvp are overwritten; dlam / dsubln_w are ACCUMULATED into (caller zero-fills). */
+size_t mlagg_pooled_attn_bwd_workspace_floats(int batch, int N, int P, int nh);
 int mlagg_pooled_attn_bwd(const float *q, int q_stride, const float *kp, int kp_stride,
                           const float *vp, int vp_stride, const float *lam, const float *subln_w,
                           const float *dout, int dout_stride, const float *lse, const float *o_pre,

@@ -28,9 +28,6 @@ namespace {
 constexpr int HD = 24;        // head_dim
 constexpr int HD2 = 48;
 constexpr int TOK_PER_BLOCK = 128;        // forward / backward-1: 256 threads = 128 lane pairs
-constexpr int TCH = 64;                   // backward-2: tokens per LDS tile
-constexpr int CHUNKS_PER_BLOCK = 1;       // backward-2: tiles per workgroup (more, shorter waves: the kernel
-                                          // is issue/latency-bound at <1 wave per SIMD otherwise)
 constexpr int WS_PER_UNIT = 52;           // d(o)[48], D1, D2, pad
 constexpr float RMS_EPS = 1e-5f;
 constexpr float OUT_GAIN = 0.2f;
@@ -244,20 +241,32 @@ pooled_attn_bwd1_kernel(const float *__restrict__ q, const float *__restrict__ k
     }
 }
 
-// backward-2: lane = key.  dK, dV of the (batch, head) accumulate in VGPRs over the workgroup's token
-// tiles, then one atomic per element.
-__global__ void __launch_bounds__(64)
+// backward-2: lane = key.  A workgroup of 4 waves covers TPB tokens of one (batch, head, 64-key block);
+// each wave streams its share of the tokens through a private LDS tile while dK / dV rows accumulate in
+// VGPRs, the 4 waves are summed through LDS and the workgroup writes ONE partial block -- no atomics
+// (256 adders per address made the atomic form contention-bound: 0.5 ms per launch in the first profile).
+// pooled_attn_bwd2_reduce_kernel sums the partial blocks.
+constexpr int B2_WAVES = 4;
+constexpr int B2_TILE = 32;                      // tokens per LDS tile of one wave
+constexpr int B2_TILE_FLOATS = B2_TILE * (HD2 + HD2 + 4);
+constexpr int B2_TPB = 512;                      // tokens per workgroup
+constexpr int B2_RED_PITCH = 65;                 // [wave][channel][key] reduction image, conflict-free both ways
+
+__global__ void __launch_bounds__(256)
 pooled_attn_bwd2_kernel(const float *__restrict__ q, const float *__restrict__ kp, const float *__restrict__ vp,
                         const float *__restrict__ lamp, const float *__restrict__ lse, const float *__restrict__ ws,
-                        float *__restrict__ dkp, int dkp_stride, float *__restrict__ dvp, int dvp_stride, Geom g)
+                        float *__restrict__ part, Geom g)
 {
-    __shared__ float4 tile4[TCH * (HD2 + HD2 + 4) / 4];
-    float *sQ = reinterpret_cast<float *>(tile4);       // [TCH][48] scaled q
-    float *sO = sQ + TCH * HD2;                          // [TCH][48] d(o)
-    float *sS = sO + TCH * HD2;                          // [TCH][4]  lse1, lse2, D1, D2
+    __shared__ float4 lds4[B2_WAVES * B2_TILE_FLOATS / 4];
+    float *lds = reinterpret_cast<float *>(lds4);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *sQ = lds + wave * B2_TILE_FLOATS;           // [tile][48] scaled q
+    float *sO = sQ + B2_TILE * HD2;                     // [tile][48] d(o)
+    float *sS = sO + B2_TILE * HD2;                     // [tile][4]  lse1, lse2, D1, D2
     const int h = blockIdx.y, b = blockIdx.z;
-    const int p = blockIdx.x % ((g.P + 63) / 64) * 64 + threadIdx.x;
-    const int chunk0 = blockIdx.x / ((g.P + 63) / 64) * CHUNKS_PER_BLOCK;
+    const int pblocks = (g.P + 63) / 64;
+    const int pb = blockIdx.x % pblocks, tb = blockIdx.x / pblocks;
+    const int p = pb * 64 + lane;
     const bool act = p < g.P;
     const float lam = lamp[0];
     float kv[HD2], vv[HD2], dk[HD2], dv[HD2];
@@ -267,12 +276,11 @@ pooled_attn_bwd2_kernel(const float *__restrict__ q, const float *__restrict__ k
         loadv<HD2>(kp + ((size_t)b * g.P + p) * g.kp_stride + h * HD2, kv);
         loadv<HD2>(vp + ((size_t)b * g.P + p) * g.vp_stride + h * HD2, vv);
     }
-    for (int c = 0; c < CHUNKS_PER_BLOCK; ++c) {
-        const int t0 = (chunk0 + c) * TCH;
-        if (t0 >= g.N) break;
-        const int nt = min(TCH, g.N - t0);
-        __syncthreads();
-        for (int i = threadIdx.x; i < nt * (HD2 / 4); i += blockDim.x) {
+    const int t_begin = tb * B2_TPB + wave * (B2_TPB / B2_WAVES);
+    const int t_end = min(t_begin + B2_TPB / B2_WAVES, g.N);
+    for (int t0 = t_begin; t0 < t_end; t0 += B2_TILE) {       // wave-private tiles: no block barrier needed
+        const int nt = min(B2_TILE, t_end - t0);
+        for (int i = lane; i < nt * (HD2 / 4); i += 64) {
             const int tt = i / (HD2 / 4), c4 = i - tt * (HD2 / 4);
             const size_t tok = (size_t)b * g.N + t0 + tt;
             float4 a = *reinterpret_cast<const float4 *>(q + tok * g.q_stride + h * HD2 + 4 * c4);
@@ -281,13 +289,14 @@ pooled_attn_bwd2_kernel(const float *__restrict__ q, const float *__restrict__ k
             *reinterpret_cast<float4 *>(sO + tt * HD2 + 4 * c4) =
                 *reinterpret_cast<const float4 *>(ws + (tok * g.nh + h) * WS_PER_UNIT + 4 * c4);
         }
-        for (int tt = threadIdx.x; tt < nt; tt += blockDim.x) {
-            const size_t tok = (size_t)b * g.N + t0 + tt;
+        if (lane < nt) {
+            const size_t tok = (size_t)b * g.N + t0 + lane;
             const float *wrow = ws + (tok * g.nh + h) * WS_PER_UNIT;
-            *reinterpret_cast<float4 *>(sS + 4 * tt) =
+            *reinterpret_cast<float4 *>(sS + 4 * lane) =
                 make_float4(lse[(tok * g.nh + h) * 2], lse[(tok * g.nh + h) * 2 + 1], wrow[HD2], wrow[HD2 + 1]);
         }
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0);       // wave-local LDS hand-off: writes landed before the reads below
+        __builtin_amdgcn_wave_barrier();
         for (int tt = 0; tt < nt; ++tt) {
             const float4 st = *reinterpret_cast<const float4 *>(sS + 4 * tt);
             const float *qt = sQ + tt * HD2, *ot = sO + tt * HD2;
@@ -309,16 +318,46 @@ pooled_attn_bwd2_kernel(const float *__restrict__ q, const float *__restrict__ k
 #pragma unroll
             for (int e = 0; e < HD2; ++e) dv[e] += w * ot[e];
         }
+        __builtin_amdgcn_wave_barrier();
     }
-    if (act) {
-        float *dkrow = dkp + ((size_t)b * g.P + p) * dkp_stride + h * HD2;
-        float *dvrow = dvp + ((size_t)b * g.P + p) * dvp_stride + h * HD2;
+    // cross-wave sum through LDS, dK then dV; the image is [wave][channel][key] with pitch 65
+    float *red = lds;
+    float *pbase = part + ((((size_t)b * g.nh + h) * gridDim.x + blockIdx.x) * 2) * (64 * HD2);
+#pragma unroll 1
+    for (int kind = 0; kind < 2; ++kind) {
+        __syncthreads();
 #pragma unroll
-        for (int e = 0; e < HD2; ++e) {
-            atomicAdd(dkrow + e, dk[e]);
-            atomicAdd(dvrow + e, dv[e]);
+        for (int e = 0; e < HD2; ++e) red[(wave * HD2 + e) * B2_RED_PITCH + lane] = kind ? dv[e] : dk[e];
+        __syncthreads();
+        for (int o = threadIdx.x; o < 64 * HD2; o += 256) {
+            const int pp = o / HD2, e = o - pp * HD2;
+            float sum = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < B2_WAVES; ++w2) sum += red[(w2 * HD2 + e) * B2_RED_PITCH + pp];
+            pbase[(size_t)kind * (64 * HD2) + o] = sum;
         }
     }
+}
+
+// part[(b, h)][block][kind][64 keys][48] -> dkp / dvp (batch, P, d); one thread per output element
+__global__ void pooled_attn_bwd2_reduce_kernel(const float *__restrict__ part, int nblocks, int pblocks,
+                                               float *__restrict__ dkp, int dkp_stride, float *__restrict__ dvp,
+                                               int dvp_stride, Geom g)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // over P * 48
+    const int h = blockIdx.y, b = blockIdx.z;
+    if (idx >= g.P * HD2) return;
+    const int p = idx / HD2, e = idx - p * HD2;
+    const int pb = p >> 6, pl = p & 63;
+    const float *base = part + (((size_t)b * g.nh + h) * nblocks) * 2 * (64 * HD2);
+    float sk = 0.f, sv = 0.f;
+    for (int blk = pb; blk < nblocks; blk += pblocks) {
+        const float *pr = base + (size_t)blk * 2 * (64 * HD2) + pl * HD2 + e;
+        sk += pr[0];
+        sv += pr[64 * HD2];
+    }
+    dkp[((size_t)b * g.P + p) * dkp_stride + h * HD2 + e] = sk;
+    dvp[((size_t)b * g.P + p) * dvp_stride + h * HD2 + e] = sv;
 }
 
 int make_geom(Geom &g, int batch, int N, int P, int nh, int qs, int kps, int vps, int outs, float scale)
@@ -366,9 +405,10 @@ extern "C" int mlagg_pooled_attn_fwd(const float *q, int q_stride, const float *
     return (int)hipGetLastError();
 }
 
-extern "C" size_t mlagg_pooled_attn_bwd_workspace_floats(int batch, int N, int nh)
+extern "C" size_t mlagg_pooled_attn_bwd_workspace_floats(int batch, int N, int P, int nh)
 {
-    return (size_t)batch * N * nh * WS_PER_UNIT;
+    const size_t nblocks = (size_t)((P + 63) / 64) * ((N + B2_TPB - 1) / B2_TPB);
+    return (size_t)batch * N * nh * WS_PER_UNIT + (size_t)batch * nh * nblocks * 2 * (64 * HD2);
 }
 
 extern "C" int mlagg_pooled_attn_bwd(const float *q, int q_stride, const float *kp, int kp_stride, const float *vp,
@@ -392,8 +432,14 @@ extern "C" int mlagg_pooled_attn_bwd(const float *q, int q_stride, const float *
                        lds, st, q, kp, vp, lam, subln_w, dout, dout_stride, lse, o_pre, dq, dq_stride, workspace,
                        dlam, dsubln_w, g); }
     const int pblocks = (P + 63) / 64;
-    const int tblocks = (N + TCH * CHUNKS_PER_BLOCK - 1) / (TCH * CHUNKS_PER_BLOCK);
-    { MLAGG_TIMED(K_POOLED_BWD2, st); hipLaunchKernelGGL(pooled_attn_bwd2_kernel, dim3(pblocks * tblocks, nh, batch), dim3(64), 0, st, q, kp, vp, lam,
-                       lse, workspace, dkp, dkp_stride, dvp, dvp_stride, g); }
+    const int tblocks = (N + B2_TPB - 1) / B2_TPB;
+    float *part = workspace + (size_t)batch * N * nh * WS_PER_UNIT;
+    {
+        MLAGG_TIMED(K_POOLED_BWD2, st);
+        hipLaunchKernelGGL(pooled_attn_bwd2_kernel, dim3(pblocks * tblocks, nh, batch), dim3(256), 0, st, q, kp, vp,
+                           lam, lse, workspace, part, g);
+        hipLaunchKernelGGL(pooled_attn_bwd2_reduce_kernel, dim3((P * HD2 + 255) / 256, nh, batch), dim3(256), 0, st,
+                           part, pblocks * tblocks, pblocks, dkp, dkp_stride, dvp, dvp_stride, g);
+    }
     return (int)hipGetLastError();
 }

@@ -201,10 +201,10 @@ class PooledDiffAttnFn(torch.autograd.Function):
         dout, dos = _rows(dout, "dout")
         lib = _lib.lib()
         dq = torch.empty(B, N, d, device=q.device, dtype=torch.float32)
-        dkp = torch.zeros(B, P, d, device=q.device, dtype=torch.float32)
-        dvp = torch.zeros(B, P, d, device=q.device, dtype=torch.float32)
+        dkp = torch.empty(B, P, d, device=q.device, dtype=torch.float32)
+        dvp = torch.empty(B, P, d, device=q.device, dtype=torch.float32)
         small = torch.zeros(1 + 48, device=q.device, dtype=torch.float32)
-        ws = torch.empty(lib.mlagg_pooled_attn_bwd_workspace_floats(B, N, nh), device=q.device, dtype=torch.float32)
+        ws = torch.empty(lib.mlagg_pooled_attn_bwd_workspace_floats(B, N, P, nh), device=q.device, dtype=torch.float32)
         _lib.check(lib.mlagg_pooled_attn_bwd(_ptr(q), q.stride(1), _ptr(kp), kp.stride(1), _ptr(vp), vp.stride(1),
                                              _ptr(lam), _ptr(subln_w), _ptr(dout), dos, _ptr(lse), _ptr(o_pre),
                                              _ptr(dq), d, _ptr(dkp), d, _ptr(dvp), d, _ptr(small[:1]), _ptr(small[1:]),
