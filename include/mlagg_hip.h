@@ -139,6 +139,21 @@ size_t mlagg_linear_wgrad_workspace_floats(int M, int O, int I);
 int mlagg_linear_wgrad(const float *dy, int dy_stride, const float *x, int x_stride, float *dW, float *db,
                        float *workspace, int M, int O, int I, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K6: LayerNorm over the last dimension of token-major rows, x (rows, C) with row stride x_stride,
+ * y (rows, C) contiguous.  Replaces nn.LayerNorm at nnUNetTrainer_MLAgg_2D_dt_MS.py:723, 887, 907, 984-1001 and
+ * MambaSkip.py:536, 741-742.  Built for C in {48, 96, 192, 384, 768} (mlagg_layernorm_supported).
+ *   stats: (rows, 2) mean / rstd saved for backward (NULL for inference).
+ *   backward overwrites dx (rows, C), dgamma (C), dbeta (C or NULL).
+ * ------------------------------------------------------------------------------------------ */
+int mlagg_layernorm_supported(int C);
+int mlagg_layernorm_fwd(const float *x, int x_stride, const float *gamma, const float *beta, float *y,
+                        float *stats, int rows, int C, float eps, void *stream);
+size_t mlagg_layernorm_bwd_workspace_floats(int rows, int C);
+int mlagg_layernorm_bwd(const float *x, int x_stride, const float *dy, int dy_stride, const float *gamma,
+                        const float *stats, float *dx, float *dgamma, float *dbeta, float *workspace,
+                        int rows, int C, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,8 @@ const char *const kNames[K_COUNT] = {
     "selscan_fwd_kernel<false>", "selscan_chunk_prefix", "selscan_fwd_kernel<true>", "selscan_bwd_local_kernel",
     "selscan_bwd_kernel", "selscan_reduce_partials", "local_attn_fwd_kernel", "local_attn_bwd_a_kernel",
     "local_attn_bwd_b_kernel", "pooled_attn_fwd_kernel", "pooled_attn_bwd1_kernel",
-    "pooled_attn_bwd2_kernel", "dwconv_fwd_kernel", "dwconv_bwd_data_kernel", "dwconv_bwd_weight_kernel", "linear_wgrad_kernel"};
+    "pooled_attn_bwd2_kernel", "dwconv_fwd_kernel", "dwconv_bwd_data_kernel", "dwconv_bwd_weight_kernel", "linear_wgrad_kernel", "layernorm_fwd_kernel",
+    "layernorm_bwd_kernel"};
 }  // namespace
 
 // begin/end pairs of one kernel are issued back to back from one host thread (the launcher), so the

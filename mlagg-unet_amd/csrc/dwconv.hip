@@ -154,25 +154,33 @@ dwconv_bwd_weight_kernel(const float *__restrict__ x, int x_stride, const float 
     }
 }
 
-// part[rows][C][10] -> dw[C][9] += , dbias[C] +=
-__global__ void dwconv_wgrad_reduce_kernel(const float *__restrict__ part, int rows, int C, float *__restrict__ dw,
-                                           float *__restrict__ dbias)
+// part[rows][C][10] -> dw[C][9] += , dbias[C] += ; workgroup = 64 columns x 16 row-groups
+__global__ void __launch_bounds__(1024)
+dwconv_wgrad_reduce_kernel(const float *__restrict__ part, int rows, int C, float *__restrict__ dw,
+                           float *__restrict__ dbias)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= C * 10) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int r = 0;
-    for (; r + 3 < rows; r += 4) {
-        s0 += part[(size_t)r * C * 10 + i];
-        s1 += part[(size_t)(r + 1) * C * 10 + i];
-        s2 += part[(size_t)(r + 2) * C * 10 + i];
-        s3 += part[(size_t)(r + 3) * C * 10 + i];
+    __shared__ float red[16][65];
+    const int cx = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + cx, cols = C * 10;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < cols) {
+        int r = rg;
+        for (; r + 16 < rows; r += 32) {
+            s0 += part[(size_t)r * cols + i];
+            s1 += part[(size_t)(r + 16) * cols + i];
+        }
+        if (r < rows) s0 += part[(size_t)r * cols + i];
     }
-    for (; r < rows; ++r) s0 += part[(size_t)r * C * 10 + i];
-    const float s = (s0 + s1) + (s2 + s3);
-    const int c = i / 10, j = i - c * 10;
-    if (j < 9) dw[c * 9 + j] += s;
-    else if (dbias) dbias[c] += s;
+    red[rg][cx] = s0 + s1;
+    __syncthreads();
+    if (rg == 0 && i < cols) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][cx];
+        const int c = i / 10, j = i - c * 10;
+        if (j < 9) dw[c * 9 + j] += s;
+        else if (dbias) dbias[c] += s;
+    }
 }
 
 int make_geom(Geom &g, int batch, int H, int W, int C, int xs, int ys)
@@ -205,7 +213,7 @@ void dwconv_wgrad_launch(const float *x, int x_stride, const float *dy, int dy_s
         else
             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<false>, grid, dim3(256), 0, st, x, x_stride, dy, dy_stride, pre,
                                part, batch, H, W, C);
-        hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3((C * 10 + 255) / 256), dim3(256), 0, st, part,
+        hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3((C * 10 + 63) / 64), dim3(1024), 0, st, part,
                            batch * chunks, C, dw, dbias);
     }
 }

@@ -4,6 +4,36 @@
 #include <stddef.h>
 
 namespace mlagg_internal {
+
+// out[c] (+)= sum_r part[r * pitch + c], c < cols: column sums of per-workgroup partial rows.
+// Workgroup = 64 columns x 16 row-groups (1024 threads): coalesced 256-byte row reads, 16-way row
+// parallelism, LDS combine.  Deterministic (fixed summation order), no atomics.
+template <bool ACCUMULATE>
+__global__ void __launch_bounds__(1024)
+column_sum_kernel(const float *__restrict__ part, int rows, int pitch, int cols, float *__restrict__ out)
+{
+    __shared__ float red[16][65];
+    const int cx = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < cols) {
+        int r = rg;
+        for (; r + 16 < rows; r += 32) {
+            s0 += part[(size_t)r * pitch + c];
+            s1 += part[(size_t)(r + 16) * pitch + c];
+        }
+        if (r < rows) s0 += part[(size_t)r * pitch + c];
+    }
+    red[rg][cx] = s0 + s1;
+    __syncthreads();
+    if (rg == 0 && c < cols) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += red[i][cx];
+        if (ACCUMULATE) out[c] += s; else out[c] = s;
+    }
+}
+
 size_t dwconv_wgrad_workspace_floats(int batch, int H, int W, int C);
 // dw (C, 9) and dbias (C, may be NULL) are ACCUMULATED into; part = workspace of the size above
 void dwconv_wgrad_launch(const float *x, int x_stride, const float *dy, int dy_stride, const float *pre, float *dw,

@@ -1,0 +1,202 @@
+// K6 -- LayerNorm over the channel dimension of token-major rows, forward and backward.
+//
+// Replaces ATen's layer_norm on the path's short rows (C = 48 .. 768): nn.LayerNorm in MLLABlock
+// (nnUNetTrainer_MLAgg_2D_dt_MS.py:887, 907), the pooled branch (T:723), PatchEmbed's project (T:984-1001) and the
+// MSMM block (MambaSkip.py:536, 741-742).  ATen launches one workgroup per row; at C = 96 and 163 840 rows
+// that is 160 us forward and 310 us backward per call in the round-1 profile against ~25 / ~40 us of HBM
+// time.  Here a row is owned by C/12 lanes (3 float4 per lane, so every supported C fills whole
+// power-of-two lane groups: 4, 8, 16, 32 or 64 lanes), statistics are cross-lane butterflies, each wave
+// streams several rows per iteration with 16-byte accesses, and the weight/bias gradients are
+// accumulated per lane over the grid-stride loop, reduced through LDS to one partial row per workgroup
+// and summed by a second tiny kernel (deterministic, no atomics).
+//
+// HBM-bound: algorithmic bytes 8*C per row forward (x in, y out), 12*C backward (x, dy in; dx out).
+#include <hip/hip_runtime.h>
+
+#include "mlagg_hip.h"
+#include "prof.h"
+#include "internal.h"
+
+namespace {
+
+constexpr int F4 = 3;               // float4 per lane and row
+constexpr int BLOCK = 256;
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v)
+{
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int LPR>
+__global__ void __launch_bounds__(BLOCK)
+layernorm_fwd_kernel(const float *__restrict__ x, int x_stride, const float *__restrict__ gamma,
+                     const float *__restrict__ beta, float *__restrict__ y, float *__restrict__ stats, int rows,
+                     float eps)
+{
+    constexpr int C = LPR * F4 * 4;
+    constexpr int RPB = BLOCK / LPR;                   // rows per workgroup iteration
+    const int sub = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+    float4 g[F4], b[F4];
+#pragma unroll
+    for (int i = 0; i < F4; ++i) {
+        g[i] = *reinterpret_cast<const float4 *>(gamma + 4 * (sub + LPR * i));
+        b[i] = beta ? *reinterpret_cast<const float4 *>(beta + 4 * (sub + LPR * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (long row = (long)blockIdx.x * RPB + rl; row < rows; row += (long)gridDim.x * RPB) {
+        float4 v[F4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < F4; ++i) {
+            v[i] = *reinterpret_cast<const float4 *>(x + row * x_stride + 4 * (sub + LPR * i));
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        const float mean = group_sum<LPR>(s) * (1.f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < F4; ++i) {
+            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+            q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+        const float rstd = rsqrtf(group_sum<LPR>(q) * (1.f / C) + eps);
+#pragma unroll
+        for (int i = 0; i < F4; ++i) {
+            float4 o;
+            o.x = v[i].x * rstd * g[i].x + b[i].x; o.y = v[i].y * rstd * g[i].y + b[i].y;
+            o.z = v[i].z * rstd * g[i].z + b[i].z; o.w = v[i].w * rstd * g[i].w + b[i].w;
+            *reinterpret_cast<float4 *>(y + row * C + 4 * (sub + LPR * i)) = o;
+        }
+        if (stats && sub == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+    }
+}
+
+template <int LPR>
+__global__ void __launch_bounds__(BLOCK)
+layernorm_bwd_kernel(const float *__restrict__ x, int x_stride, const float *__restrict__ dy, int dy_stride,
+                     const float *__restrict__ gamma, const float *__restrict__ stats, float *__restrict__ dx,
+                     float *__restrict__ part, int rows)
+{
+    constexpr int C = LPR * F4 * 4;
+    constexpr int RPB = BLOCK / LPR;
+    __shared__ float red[2][RPB][C + 4];
+    const int sub = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+    float4 g[F4], dg[F4], db[F4];
+#pragma unroll
+    for (int i = 0; i < F4; ++i) {
+        g[i] = *reinterpret_cast<const float4 *>(gamma + 4 * (sub + LPR * i));
+        dg[i] = db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (long row = (long)blockIdx.x * RPB + rl; row < rows; row += (long)gridDim.x * RPB) {
+        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        float4 xh[F4], gy[F4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < F4; ++i) {
+            const float4 xv = *reinterpret_cast<const float4 *>(x + row * x_stride + 4 * (sub + LPR * i));
+            const float4 d = *reinterpret_cast<const float4 *>(dy + row * dy_stride + 4 * (sub + LPR * i));
+            xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+            gy[i] = make_float4(d.x * g[i].x, d.y * g[i].y, d.z * g[i].z, d.w * g[i].w);
+            s1 += (gy[i].x + gy[i].y) + (gy[i].z + gy[i].w);
+            s2 += (gy[i].x * xh[i].x + gy[i].y * xh[i].y) + (gy[i].z * xh[i].z + gy[i].w * xh[i].w);
+            dg[i].x += d.x * xh[i].x; dg[i].y += d.y * xh[i].y; dg[i].z += d.z * xh[i].z; dg[i].w += d.w * xh[i].w;
+            db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
+        }
+        const float m1 = group_sum<LPR>(s1) * (1.f / C), m2 = group_sum<LPR>(s2) * (1.f / C);
+#pragma unroll
+        for (int i = 0; i < F4; ++i) {
+            float4 o;
+            o.x = rstd * (gy[i].x - m1 - xh[i].x * m2); o.y = rstd * (gy[i].y - m1 - xh[i].y * m2);
+            o.z = rstd * (gy[i].z - m1 - xh[i].z * m2); o.w = rstd * (gy[i].w - m1 - xh[i].w * m2);
+            *reinterpret_cast<float4 *>(dx + row * C + 4 * (sub + LPR * i)) = o;
+        }
+    }
+    // per-workgroup partial of d(gamma), d(beta): sum the RPB row-lanes through LDS
+#pragma unroll
+    for (int i = 0; i < F4; ++i) {
+        *reinterpret_cast<float4 *>(&red[0][rl][4 * (sub + LPR * i)]) = dg[i];
+        *reinterpret_cast<float4 *>(&red[1][rl][4 * (sub + LPR * i)]) = db[i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += BLOCK) {
+        const int which = i / C, c = i - which * C;
+        float s = 0.f;
+#pragma unroll 4
+        for (int r = 0; r < RPB; ++r) s += red[which][r][c];
+        part[((size_t)blockIdx.x * 2 + which) * C + c] = s;
+    }
+}
+
+inline int lanes_per_row(int C)
+{
+    if (C % 12) return 0;
+    const int l = C / 12;
+    return (l == 4 || l == 8 || l == 16 || l == 32 || l == 64) ? l : 0;
+}
+
+inline int grid_blocks(int rows, int lpr)
+{
+    const int rpb = BLOCK / lpr;
+    long need = ((long)rows + rpb - 1) / rpb;
+    return (int)(need < 1024 ? need : 1024);       // grid-stride beyond 4 workgroups per CU
+}
+
+}  // namespace
+
+extern "C" int mlagg_layernorm_supported(int C) { return lanes_per_row(C) != 0; }
+
+extern "C" size_t mlagg_layernorm_bwd_workspace_floats(int rows, int C)
+{
+    const int lpr = lanes_per_row(C);
+    return lpr ? (size_t)grid_blocks(rows, lpr) * 2 * C : 0;
+}
+
+extern "C" int mlagg_layernorm_fwd(const float *x, int x_stride, const float *gamma, const float *beta, float *y,
+                                   float *stats, int rows, int C, float eps, void *stream)
+{
+    if (!x || !gamma || !y) return MLAGG_E_NULLPTR;
+    const int lpr = lanes_per_row(C);
+    if (!lpr || rows <= 0 || x_stride < C || (x_stride & 3)) return MLAGG_E_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(grid_blocks(rows, lpr)), block(BLOCK);
+    MLAGG_TIMED(K_LAYERNORM_FWD, st);
+    switch (lpr) {
+    case 4: hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, block, 0, st, x, x_stride, gamma, beta, y, stats, rows, eps); break;
+    case 8: hipLaunchKernelGGL(layernorm_fwd_kernel<8>, grid, block, 0, st, x, x_stride, gamma, beta, y, stats, rows, eps); break;
+    case 16: hipLaunchKernelGGL(layernorm_fwd_kernel<16>, grid, block, 0, st, x, x_stride, gamma, beta, y, stats, rows, eps); break;
+    case 32: hipLaunchKernelGGL(layernorm_fwd_kernel<32>, grid, block, 0, st, x, x_stride, gamma, beta, y, stats, rows, eps); break;
+    default: hipLaunchKernelGGL(layernorm_fwd_kernel<64>, grid, block, 0, st, x, x_stride, gamma, beta, y, stats, rows, eps); break;
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int mlagg_layernorm_bwd(const float *x, int x_stride, const float *dy, int dy_stride, const float *gamma,
+                                   const float *stats, float *dx, float *dgamma, float *dbeta, float *workspace,
+                                   int rows, int C, void *stream)
+{
+    if (!x || !dy || !gamma || !stats || !dx || !dgamma || !workspace) return MLAGG_E_NULLPTR;
+    const int lpr = lanes_per_row(C);
+    if (!lpr || rows <= 0 || x_stride < C || (x_stride & 3) || dy_stride < C || (dy_stride & 3))
+        return MLAGG_E_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nb = grid_blocks(rows, lpr);
+    const dim3 grid(nb), block(BLOCK);
+    {
+        MLAGG_TIMED(K_LAYERNORM_BWD, st);
+        switch (lpr) {
+        case 4: hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, st, x, x_stride, dy, dy_stride, gamma, stats, dx, workspace, rows); break;
+        case 8: hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, block, 0, st, x, x_stride, dy, dy_stride, gamma, stats, dx, workspace, rows); break;
+        case 16: hipLaunchKernelGGL(layernorm_bwd_kernel<16>, grid, block, 0, st, x, x_stride, dy, dy_stride, gamma, stats, dx, workspace, rows); break;
+        case 32: hipLaunchKernelGGL(layernorm_bwd_kernel<32>, grid, block, 0, st, x, x_stride, dy, dy_stride, gamma, stats, dx, workspace, rows); break;
+        default: hipLaunchKernelGGL(layernorm_bwd_kernel<64>, grid, block, 0, st, x, x_stride, dy, dy_stride, gamma, stats, dx, workspace, rows); break;
+        }
+    }
+    // partial rows are [d(gamma) | d(beta)]: column sums of an (nb x 2C) matrix
+    hipLaunchKernelGGL(mlagg_internal::column_sum_kernel<false>, dim3((C + 63) / 64), dim3(1024), 0, st, workspace, nb,
+                       2 * C, C, dgamma);
+    if (dbeta)
+        hipLaunchKernelGGL(mlagg_internal::column_sum_kernel<false>, dim3((C + 63) / 64), dim3(1024), 0, st,
+                           workspace + C, nb, 2 * C, C, dbeta);
+    return (int)hipGetLastError();
+}

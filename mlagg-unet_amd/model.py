@@ -25,6 +25,11 @@ import torch.nn.functional as F
 from . import ops
 
 LAMBDA_INIT = 0.8
+# MLAGG_CHANNELS_LAST=1: keep the convolutional parts in NHWC memory (torch.channels_last) so that the
+# NCHW <-> token-major transposes around the encoder stages and MIOpen's own NCHW->NHWC staging disappear.
+import os  # noqa: E402
+
+CHANNELS_LAST = os.environ.get("MLAGG_CHANNELS_LAST", "0") == "1"
 
 
 class DropPath(nn.Module):
@@ -57,6 +62,13 @@ class Linear(nn.Linear):
 
     def forward(self, x):
         return ops.linear(x, self.weight, self.bias)
+
+
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm (same parameter names) over the channel dimension, on K6."""
+
+    def forward(self, x):
+        return ops.layer_norm(x, self.weight, self.bias, self.eps)
 
 
 class Mlp(nn.Module):
@@ -96,7 +108,7 @@ class AggregatedAttention(nn.Module):
             self.sr_ratio = sr_ratio
             self.pool_H, self.pool_W = self.H // sr_ratio, self.W // sr_ratio
             self.sr = nn.Conv2d(dim, dim, 1)
-            self.norm = nn.LayerNorm(dim)
+            self.norm = LayerNorm(dim)
         self.q = Linear(dim, dim)
         self.kv = Linear(dim, 2 * dim)
         self.lepe = nn.Conv2d(dim, dim, 3, padding=1, groups=dim)
@@ -141,7 +153,7 @@ class MLLABlock(nn.Module):
     def __init__(self, dim, input_resolution, num_heads, mlp_ratio, drop_path, sr_ratio, variant="B"):
         super().__init__()
         self.dim, self.input_resolution = dim, tuple(input_resolution)
-        self.norm1 = nn.LayerNorm(dim)
+        self.norm1 = LayerNorm(dim)
         self.in_proj = Linear(dim, dim)
         self.act_proj = Linear(dim, dim)
         self.dwc = nn.Conv2d(dim, dim, 3, padding=1, groups=dim)
@@ -150,7 +162,7 @@ class MLLABlock(nn.Module):
             AggregatedAttention(dim // 2, input_resolution, num_heads // 2, False, sr_ratio, variant)])
         self.out_proj = Linear(dim, dim)
         self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
-        self.norm2 = nn.LayerNorm(dim)
+        self.norm2 = LayerNorm(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
     def forward_tokens(self, x):
@@ -190,10 +202,13 @@ class BasicLayer(nn.Module):
 
     def forward(self, x):
         B, C, h, w = x.shape
-        t = x.flatten(2).transpose(1, 2).contiguous()          # one NCHW -> NLC copy per stage
+        # (B, C, H, W) -> token-major (B, N, C).  For a channels_last tensor this is a free view (NHWC memory
+        # IS the token-major layout); for a plain NCHW tensor it is the one transpose copy of the stage.
+        t = x.permute(0, 2, 3, 1).reshape(B, h * w, C)
         for blk in self.blocks:
             t = blk.forward_tokens(t)
-        return t.transpose(1, 2).reshape(B, C, h, w).contiguous()
+        y = t.view(B, h, w, C).permute(0, 3, 1, 2)              # NCHW-shaped view of NHWC memory
+        return y if CHANNELS_LAST else y.contiguous()
 
 
 class Project(nn.Module):  # reference T:972-1001
@@ -201,10 +216,10 @@ class Project(nn.Module):  # reference T:972-1001
         super().__init__()
         self.conv1 = nn.Conv2d(cin, cout, 3, stride=stride, padding=1)
         self.conv2 = nn.Conv2d(cout, cout, 3, stride=1, padding=1)
-        self.norm1 = nn.LayerNorm(cout)
+        self.norm1 = LayerNorm(cout)
         self.last = last
         if not last:
-            self.norm2 = nn.LayerNorm(cout)
+            self.norm2 = LayerNorm(cout)
 
     @staticmethod
     def _ln(norm, x):
@@ -379,7 +394,7 @@ class SS2D_skip(nn.Module):
         A = torch.arange(1, d_state + 1, dtype=torch.float32).repeat(4 * self.d_inner, 1)
         self.A_logs = nn.Parameter(torch.log(A))
         self.Ds = nn.Parameter(torch.ones(4 * self.d_inner))
-        self.out_norm = nn.LayerNorm(self.d_inner)
+        self.out_norm = LayerNorm(self.d_inner)
         self.out_proj = Linear(self.d_inner, d_model, bias=False)
 
     def core(self, xs_tok: List[torch.Tensor], HW):
@@ -454,10 +469,10 @@ class VSS_Conv_Block(nn.Module):  # reference M:669-753
         super().__init__()
         self.hidden_dim = hidden_dim
         self.conv_dims = [c - hidden_dim for c in feature_dims]
-        self.ln_1 = nn.LayerNorm(hidden_dim)
+        self.ln_1 = LayerNorm(hidden_dim)
         self.self_attention = SS2D_skip(len(feature_dims), hidden_dim)
         self.drop_path = DropPath(drop_path)
-        self.norm2 = nn.LayerNorm(hidden_dim)
+        self.norm2 = LayerNorm(hidden_dim)
         self.mlps = nn.ModuleList([ConvolutionalGLU(hidden_dim, hidden_dim * 4) for _ in feature_dims])
         self.conv_branches = nn.ModuleList([
             nn.Sequential(nn.Conv2d(c, c, 3, padding=1), nn.InstanceNorm2d(c, affine=True), nn.SiLU())
@@ -468,7 +483,8 @@ class VSS_Conv_Block(nn.Module):  # reference M:669-753
         HW = [(t.shape[2], t.shape[3]) for t in inputs]
         Ls = [h * w for h, w in HW]
         hd = self.hidden_dim
-        m = torch.cat([t[:, :hd].flatten(2) for t in inputs], dim=-1).transpose(1, 2).contiguous()    # (B, L_cat, 48)
+        # (B, L_cat, 48) token-major concatenation of the first 48 channels of every scale
+        m = torch.cat([t.permute(0, 2, 3, 1)[..., :hd].reshape(B, -1, hd) for t in inputs], dim=1)
         m = self.drop_path.residual(m, self.self_attention(self.ln_1(m), HW, Ls))
         m = self.norm2(m)
         outs = []
@@ -477,7 +493,7 @@ class VSS_Conv_Block(nn.Module):  # reference M:669-753
             mi = m[:, off:off + L]
             off += L
             mi = self.drop_path.residual(mi, self.mlps[i](mi, H, W))
-            mi = mi.transpose(1, 2).reshape(B, hd, H, W)
+            mi = mi.reshape(B, H, W, hd).permute(0, 3, 1, 2)
             outs.append(torch.cat([mi, self.conv_branches[i](inputs[i][:, hd:])], dim=1))
         return outs
 
@@ -521,6 +537,8 @@ class MLLA_Uper(nn.Module):  # reference T:1183-1407
             self.out_4 = OutBlock(8 * E, out_channels)
 
     def forward(self, x_in):
+        if CHANNELS_LAST:
+            x_in = x_in.contiguous(memory_format=torch.channels_last)
         hs = self.mlla(x_in)
         hs[1:] = self.mambaskip(hs[1:])
         ds = self.deep_supervision

@@ -269,3 +269,48 @@ class LinearFn(torch.autograd.Function):
 
 def linear(x, weight, bias=None):
     return LinearFn.apply(x, weight, bias)
+
+
+class LayerNormFn(torch.autograd.Function):
+    """K6: LayerNorm over the last dimension (C in {48, 96, 192, 384, 768})."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        C = x.shape[-1]
+        x2, xs = _rows2d(x, "x")
+        if xs % 4 or x2.data_ptr() % 16:
+            x2 = x2.contiguous()
+            xs = C
+        rows = x2.shape[0]
+        y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+        stats = torch.empty(rows, 2, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mlagg_layernorm_fwd(_ptr(x2), xs, _ptr(weight), _ptr(bias), _ptr(y), _ptr(stats), rows, C,
+                                                  float(eps), _stream()), "mlagg_layernorm_fwd")
+        ctx.save_for_backward(x2, weight, stats)
+        ctx.has_bias = bias is not None
+        ctx.xshape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, stats = ctx.saved_tensors
+        rows, C = x2.shape
+        dy2, dys = _rows2d(dy, "dy")
+        if dys % 4 or dy2.data_ptr() % 16:
+            dy2 = dy2.contiguous()
+            dys = C
+        lib = _lib.lib()
+        dx = torch.empty(ctx.xshape, device=dy.device, dtype=torch.float32)
+        dg = torch.empty(C, device=dy.device, dtype=torch.float32)
+        db = torch.empty(C, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
+        ws = torch.empty(lib.mlagg_layernorm_bwd_workspace_floats(rows, C), device=dy.device, dtype=torch.float32)
+        _lib.check(lib.mlagg_layernorm_bwd(_ptr(x2), x2.stride(0), _ptr(dy2), dys, _ptr(weight), _ptr(stats), _ptr(dx),
+                                           _ptr(dg), _ptr(db), _ptr(ws), rows, C, _stream()), "mlagg_layernorm_bwd")
+        return dx, dg, db, None
+
+
+def layer_norm(x, weight, bias, eps=1e-5):
+    """LayerNorm over the last dimension: K6 for the channel counts of the MLAgg-UNet path, ATen otherwise."""
+    if _lib.lib().mlagg_layernorm_supported(int(x.shape[-1])):
+        return LayerNormFn.apply(x, weight, bias, eps)
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), weight, bias, eps)

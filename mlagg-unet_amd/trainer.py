@@ -83,11 +83,14 @@ def deep_supervision_loss(outputs, targets, batch_dice=True, ddp=False):
 # ------------------------------------------------------------------------------------------------
 # optimiser / schedule
 # ------------------------------------------------------------------------------------------------
-def configure_optimizers(model, initial_lr=5e-4, weight_decay=3e-5, fused=None):
+def configure_optimizers(model, initial_lr=5e-4, weight_decay=3e-5, fused=None, capturable=False):
+    """AdamW + cosine schedule of reference T:137-147.  ``capturable=True`` keeps the step counter and the
+    learning rate on the device so that the whole step can live inside one hipGraph (GraphedTrainStep)."""
     params = [p for p in model.parameters() if p.requires_grad]
     if fused is None:
         fused = all(p.is_cuda for p in params)
-    opt = torch.optim.AdamW(params, initial_lr, weight_decay=weight_decay, eps=1e-4, fused=fused)
+    lr = torch.tensor(initial_lr, device=params[0].device, dtype=torch.float32) if capturable else initial_lr
+    opt = torch.optim.AdamW(params, lr, weight_decay=weight_decay, eps=1e-4, fused=fused, capturable=capturable)
     return opt, CosineLRSchedule(opt, t_initial=500, lr_min=1e-6, warmup_t=10, warmup_lr_init=1e-4)
 
 
@@ -98,7 +101,7 @@ class CosineLRSchedule:
     def __init__(self, optimizer, t_initial, lr_min, warmup_t, warmup_lr_init):
         self.opt, self.t_initial, self.lr_min = optimizer, t_initial, lr_min
         self.warmup_t, self.warmup_lr_init = warmup_t, warmup_lr_init
-        self.base = [g["lr"] for g in optimizer.param_groups]
+        self.base = [float(g["lr"]) for g in optimizer.param_groups]
 
     def lr_at(self, epoch, base):
         if epoch < self.warmup_t:
@@ -109,7 +112,10 @@ class CosineLRSchedule:
 
     def step(self, epoch):
         for g, base in zip(self.opt.param_groups, self.base):
-            g["lr"] = self.lr_at(epoch, base)
+            if torch.is_tensor(g["lr"]):
+                g["lr"].fill_(self.lr_at(epoch, base))      # device-resident lr: visible to a captured graph
+            else:
+                g["lr"] = self.lr_at(epoch, base)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -154,6 +160,38 @@ def train_step(network, optimizer, data, target: List[torch.Tensor], batch_dice=
     torch.nn.utils.clip_grad_norm_([p for p in network.parameters() if p.grad is not None], clip)
     optimizer.step()
     return loss.detach()
+
+
+class GraphedTrainStep:
+    """The whole train step (zero_grad, forward, loss, backward, clip, AdamW) captured once into a hipGraph
+    and replayed: ~3400 kernel launches per step otherwise cost more host time than the MI355X needs to
+    execute them.  Inputs are copied into static buffers; every HIP op of this package launches on the
+    capturing stream and never allocates or synchronises, so it records cleanly.  Single-process use
+    (the DDP path stays eager: its bucketed RCCL all-reduces are launched from autograd hooks)."""
+
+    def __init__(self, network, optimizer, data, target, batch_dice=True, clip=12.0, warmup=3):
+        self.data = data.clone()
+        self.target = [t.clone() for t in target]
+        body = lambda: train_step(network, optimizer, self.data, self.target, batch_dice, False, clip)  # noqa: E731
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        optimizer.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = body()
+
+    def __call__(self, data=None, target=None):
+        if data is not None:
+            self.data.copy_(data, non_blocking=True)
+        if target is not None:
+            for dst, src in zip(self.target, target):
+                dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.loss
 
 
 def synthetic_batch(batch, in_ch, H, W, n_cls, seed=1234, device="cpu"):

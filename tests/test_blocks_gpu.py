@@ -195,3 +195,28 @@ def test_linear_wgrad_matches_torch(M, O, I, bias):
     if bias:
         _close(bg.grad, gy.double().sum(0).float(), 2e-6, 1e-4, "db")
     _close(xg.grad, (gy.double() @ w.double()).float(), 1e-5, 1e-4, "dx")
+
+
+@gpu
+@pytest.mark.parametrize("rows,C,strided", [(1000, 48, False), (4097, 96, True), (513, 192, False), (130, 384, True),
+                                             (77, 768, False), (5, 96, False)])
+def test_layernorm_matches_torch(rows, C, strided):
+    from mlagg_unet_amd import ops
+    g = torch.Generator().manual_seed(rows + C)
+    wide = torch.randn(rows, 2 * C, generator=g) * 2 + 0.5
+    x = wide[:, C:] if strided else wide[:, :C].contiguous()
+    w = torch.randn(C, generator=g) * 0.2 + 1
+    b = torch.randn(C, generator=g) * 0.1
+    gy = torch.randn(rows, C, generator=g)
+    xr = x.clone().double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    F.layer_norm(xr, (C,), wr, br, 1e-5).backward(gy.double())
+    wide_g = wide.to(DEV)
+    xg = (wide_g[:, C:] if strided else wide_g[:, :C].contiguous()).detach().requires_grad_(True)
+    wg, bg = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    y = ops.layer_norm(xg, wg, bg, 1e-5)
+    y.backward(gy.to(DEV))
+    _close(y, F.layer_norm(x.double(), (C,), w.double(), b.double(), 1e-5).float(), 2e-6, 1e-5, "y")
+    _close(xg.grad, xr.grad.float(), 5e-6, 1e-4, "dx")
+    _close(wg.grad, wr.grad.float(), 5e-6, 1e-4, "dgamma")
+    _close(bg.grad, br.grad.float(), 5e-6, 1e-4, "dbeta")
