@@ -154,6 +154,30 @@ int mlagg_layernorm_bwd(const float *x, int x_stride, const float *dy, int dy_st
                         const float *stats, float *dx, float *dgamma, float *dbeta, float *workspace,
                         int rows, int C, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K2n: depthwise 3x3 convolution on NCHW maps (zero padding 1, stride 1 or 2) + bias.  x (B, C, H, W),
+ * y (B, C, Ho, Wo), w (C, 9).  Replaces nn.Conv2d(groups=C) of MedNeXtBlock.conv1 / MedNeXtDownBlock.conv1
+ * (nnUNetTrainer_MLAgg_2D_dt_MS.py:256-263, 310, 349-356).  Backward overwrites dx, dw (C, 9), dbias (C or NULL).
+ * ------------------------------------------------------------------------------------------ */
+int mlagg_dwconv3x3_nchw_fwd(const float *x, const float *w, const float *bias, float *y, int B, int C, int H, int W,
+                             int stride, void *stream);
+size_t mlagg_dwconv3x3_nchw_bwd_workspace_floats(int B, int C, int H, int W, int stride);
+int mlagg_dwconv3x3_nchw_bwd(const float *x, const float *w, const float *dy, float *dx, float *dw, float *dbias,
+                             float *workspace, int B, int C, int H, int W, int stride, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K1': cross-scan / cross-merge of SS2D_skip.forward_corev0 (MambaSkip.py:414-422 and 455-471 + 534).
+ *   tok: token-major (B, L_cat, tok_stride floats per token); direction k reads/writes CB channels at
+ *        column k * blk_stride (nblk = 4) or at column 0 for every direction (nblk = 1);
+ *   seq: (B, 4 * CB, L_cat), row k * CB + c = direction k in scan order (k=0 row-major, 1 column-major,
+ *        2/3 their reversals; scales concatenated in order).  H, W: host arrays of the nscale (<= 4) map sizes.
+ * cross_scan: tok -> seq.  cross_merge: the adjoint, seq -> tok (sums the four directions when nblk = 1).
+ * ------------------------------------------------------------------------------------------ */
+int mlagg_cross_scan(const float *tok, int tok_stride, int blk_stride, float *seq, int B, int nscale,
+                     const int *H, const int *W, int CB, int nblk, void *stream);
+int mlagg_cross_merge(const float *seq, float *tok, int tok_stride, int blk_stride, int B, int nscale,
+                      const int *H, const int *W, int CB, int nblk, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

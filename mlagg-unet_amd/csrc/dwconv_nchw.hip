@@ -1,0 +1,188 @@
+// K2n -- depthwise 3x3 convolution on NCHW maps, stride 1 or 2, zero padding 1, + bias.
+//
+// Replaces nn.Conv2d(groups=C) in MedNeXtBlock.conv1 (reference nnUNetTrainer_MLAgg_2D_dt_MS.py:256-263, 310) and
+// MedNeXtDownBlock.conv1 (T:349-356), which stay NCHW because full MIOpen convolutions surround them.
+// MIOpen has no tuned fp32 depthwise solver for these shapes on gfx950 and falls back to its naive
+// reference kernels (naive_conv_ab_nonpacked_{fwd,bwd}_nchw: 1.8 ms per step in the round-1 profile).
+// Lane = output pixel along W (coalesced rows), one (batch, channel) plane slice per workgroup, the 9
+// weights are workgroup-uniform (scalar loads).  Weight gradients: LDS block reduction, one partial
+// row per workgroup, then the shared column-sum kernel.
+//
+// HBM-bound: 4 * (H*W + Ho*Wo) bytes per plane forward.
+#include <hip/hip_runtime.h>
+
+#include "mlagg_hip.h"
+#include "prof.h"
+#include "internal.h"
+
+namespace {
+
+struct G {
+    int B, C, H, W, Ho, Wo, stride;
+};
+
+__global__ void __launch_bounds__(256)
+dwconv_nchw_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                       float *__restrict__ y, G g)
+{
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.Ho * g.Wo) return;
+    const int oy = idx / g.Wo, ox = idx - oy * g.Wo;
+    const float *xp = x + ((size_t)b * g.C + c) * g.H * g.W;
+    const float *wp = w + c * 9;
+    float acc = bias ? bias[c] : 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * g.stride + ky - 1;
+        if (iy < 0 || iy >= g.H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * g.stride + kx - 1;
+            if (ix >= 0 && ix < g.W) acc += wp[ky * 3 + kx] * xp[(size_t)iy * g.W + ix];
+        }
+    }
+    y[((size_t)b * g.C + c) * g.Ho * g.Wo + idx] = acc;
+}
+
+// dx[iy][ix] = sum_{ky,kx} w[ky][kx] * dy[oy][ox] with oy*s + ky - 1 = iy, ox*s + kx - 1 = ix
+__global__ void __launch_bounds__(256)
+dwconv_nchw_bwd_data_kernel(const float *__restrict__ dy, const float *__restrict__ w, float *__restrict__ dx, G g)
+{
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.H * g.W) return;
+    const int iy = idx / g.W, ix = idx - iy * g.W;
+    const float *dp = dy + ((size_t)b * g.C + c) * g.Ho * g.Wo;
+    const float *wp = w + c * 9;
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int ty = iy + 1 - ky;
+        if (ty < 0 || ty % g.stride) continue;
+        const int oy = ty / g.stride;
+        if (oy >= g.Ho) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int tx = ix + 1 - kx;
+            if (tx < 0 || tx % g.stride) continue;
+            const int ox = tx / g.stride;
+            if (ox < g.Wo) acc += wp[ky * 3 + kx] * dp[(size_t)oy * g.Wo + ox];
+        }
+    }
+    dx[((size_t)b * g.C + c) * g.H * g.W + idx] = acc;
+}
+
+// one workgroup per (slice of a plane, channel, batch): part[(b * nslices + slice)][c][10]
+__global__ void __launch_bounds__(256)
+dwconv_nchw_bwd_weight_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ part, G g)
+{
+    __shared__ float red[10][4];
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float *xp = x + ((size_t)b * g.C + c) * g.H * g.W;
+    const float *dp = dy + ((size_t)b * g.C + c) * g.Ho * g.Wo;
+    float gw[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float gb = 0.f;
+    const int n = g.Ho * g.Wo;
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(lo + per, n);
+    for (int idx = lo + threadIdx.x; idx < hi; idx += blockDim.x) {
+        const int oy = idx / g.Wo, ox = idx - oy * g.Wo;
+        const float gv = dp[idx];
+        gb += gv;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * g.stride + ky - 1;
+            if (iy < 0 || iy >= g.H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * g.stride + kx - 1;
+                if (ix >= 0 && ix < g.W) gw[ky * 3 + kx] += gv * xp[(size_t)iy * g.W + ix];
+            }
+        }
+    }
+    // wave reduction (64 lanes), then across the 4 waves through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        float v = j < 9 ? gw[j] : gb;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[j][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        const float s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        part[(((size_t)b * gridDim.x + blockIdx.x) * g.C + c) * 10 + threadIdx.x] = s;
+    }
+}
+
+// part[rows][C][10] -> dw[C][9], dbias[C] (overwrite)
+__global__ void dwconv_nchw_wgrad_reduce_kernel(const float *__restrict__ part, int rows, int C,
+                                                float *__restrict__ dw, float *__restrict__ dbias)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * 10) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += part[(size_t)r * C * 10 + i];
+    const int c = i / 10, j = i - c * 10;
+    if (j < 9) dw[c * 9 + j] = s;
+    else if (dbias) dbias[c] = s;
+}
+
+int make_g(G &g, int B, int C, int H, int W, int stride)
+{
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2) || B > 65535 || C > 65535)
+        return MLAGG_E_UNSUPPORTED;
+    g.B = B; g.C = C; g.H = H; g.W = W; g.stride = stride;
+    g.Ho = (H + 2 - 3) / stride + 1;
+    g.Wo = (W + 2 - 3) / stride + 1;
+    return 0;
+}
+
+inline int wgrad_slices(const G &g)
+{
+    const int n = g.Ho * g.Wo;
+    int s = (n + 4095) / 4096;          // ~16 pixels per thread and workgroup
+    return s < 1 ? 1 : s;
+}
+
+}  // namespace
+
+extern "C" int mlagg_dwconv3x3_nchw_fwd(const float *x, const float *w, const float *bias, float *y, int B, int C,
+                                        int H, int W, int stride, void *stream)
+{
+    if (!x || !w || !y) return MLAGG_E_NULLPTR;
+    G g;
+    if (int rc = make_g(g, B, C, H, W, stride)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MLAGG_TIMED(K_DWCONV_NCHW_FWD, st);
+    hipLaunchKernelGGL(dwconv_nchw_fwd_kernel, dim3((g.Ho * g.Wo + 255) / 256, C, B), dim3(256), 0, st, x, w, bias, y, g);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t mlagg_dwconv3x3_nchw_bwd_workspace_floats(int B, int C, int H, int W, int stride)
+{
+    G g;
+    if (make_g(g, B, C, H, W, stride)) return 0;
+    return (size_t)B * wgrad_slices(g) * C * 10;
+}
+
+extern "C" int mlagg_dwconv3x3_nchw_bwd(const float *x, const float *w, const float *dy, float *dx, float *dw,
+                                        float *dbias, float *workspace, int B, int C, int H, int W, int stride,
+                                        void *stream)
+{
+    if (!x || !w || !dy || !dx || !dw || !workspace) return MLAGG_E_NULLPTR;
+    G g;
+    if (int rc = make_g(g, B, C, H, W, stride)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    {
+        MLAGG_TIMED(K_DWCONV_NCHW_BWD, st);
+        hipLaunchKernelGGL(dwconv_nchw_bwd_data_kernel, dim3((H * W + 255) / 256, C, B), dim3(256), 0, st, dy, w, dx, g);
+        const int ns = wgrad_slices(g);
+        hipLaunchKernelGGL(dwconv_nchw_bwd_weight_kernel, dim3(ns, C, B), dim3(256), 0, st, x, dy, workspace, g);
+        hipLaunchKernelGGL(dwconv_nchw_wgrad_reduce_kernel, dim3((C * 10 + 255) / 256), dim3(256), 0, st, workspace,
+                           B * ns, C, dw, dbias);
+    }
+    return (int)hipGetLastError();
+}

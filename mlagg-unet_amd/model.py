@@ -250,7 +250,9 @@ class MedNeXtBlock(nn.Module):  # reference T:230-324
         self.conv3 = nn.Conv2d(exp_r * cin, cout, 1)
 
     def body(self, x):
-        return self.conv3(F.gelu(self.conv2(self.norm(self.conv1(x)))))
+        # conv1 is depthwise 3x3 (stride 1, or 2 in the down block): K2n instead of MIOpen's naive fallback
+        x1 = ops.dwconv3x3_nchw(x, self.conv1.weight, self.conv1.bias, self.conv1.stride[0])
+        return self.conv3(F.gelu(self.conv2(self.norm(x1))))
 
     def forward(self, x):
         y = self.body(x)
@@ -397,38 +399,25 @@ class SS2D_skip(nn.Module):
         self.out_norm = LayerNorm(self.d_inner)
         self.out_proj = Linear(self.d_inner, d_model, bias=False)
 
-    def core(self, xs_tok: List[torch.Tensor], HW):
-        """xs_tok[i]: (B, H_i*W_i, d_inner) token-major conv outputs -> (B, L_cat, d_inner) sum of the four
-        re-ordered scan directions (reference M:405-473, 534)."""
-        B = xs_tok[0].shape[0]
-        K, dI = 4, self.d_inner
-        seqs, Ls = [], []
-        for xi, (H, W) in zip(xs_tok, HW):
-            L = H * W
-            row = xi.transpose(1, 2)                                              # (B, d, L) row-major order
-            col = xi.view(B, H, W, dI).permute(0, 3, 2, 1).reshape(B, dI, L)      # column-major order
-            both = torch.stack([row, col], dim=1)
-            seqs.append(torch.cat([both, both.flip(-1)], dim=1))                  # (B, 4, d, L)
-            Ls.append(L)
-        xs = torch.cat(seqs, dim=-1).contiguous()
-        Lc = xs.shape[-1]
-        x_dbl = torch.einsum("bkdl,kcd->bkcl", xs, self.x_proj_weight)
-        dts, Bs, Cs = torch.split(x_dbl, [self.dt_rank, self.d_state, self.d_state], dim=2)
-        dts = torch.einsum("bkrl,kdr->bkdl", dts, self.dt_projs_weight)
-        out = ops.selective_scan_fn(
-            xs.view(B, K * dI, Lc), dts.reshape(B, K * dI, Lc), -torch.exp(self.A_logs), Bs.contiguous(),
-            Cs.contiguous(), self.Ds, z=None, delta_bias=self.dt_projs_bias.reshape(-1), delta_softplus=True,
-            return_last_state=False).view(B, K, dI, Lc)
-        merged = []
-        off = 0
-        for (H, W), L in zip(HW, Ls):
-            o = out[..., off:off + L]
-            off += L
-            y = o[:, 0] + o[:, 2].flip(-1)                                         # row-major pair
-            yc = o[:, 1] + o[:, 3].flip(-1)                                        # column-major pair
-            y = y + yc.view(B, dI, W, H).transpose(2, 3).reshape(B, dI, L)
-            merged.append(y)
-        return torch.cat(merged, dim=-1).transpose(1, 2)                           # (B, L_cat, d) view
+    def core(self, xc, HW):
+        """xc: (B, L_cat, d_inner) token-major conv outputs of all scales -> (B, L_cat, d_inner): sum of the four
+        re-ordered scan directions (reference M:405-473 and the 4-way sum at M:534).
+        The projections stay token-major GEMMs -- x_proj for all four directions is one 96 -> 140 Linear on
+        the natural token order, the rank-3 dt projection one block-diagonal 12 -> 384 Linear -- and K1'
+        (cross_scan / cross_merge) does every re-ordering; nothing is stacked, flipped or concatenated."""
+        B, Lc, dI = xc.shape
+        K, R, N = 4, self.dt_rank, self.d_state
+        per = R + 2 * N
+        xdbl = ops.linear(xc, self.x_proj_weight.reshape(K * per, dI))                     # (B, L, 4*35)
+        dtr = xdbl.view(B, Lc, K, per)[..., :R].reshape(B, Lc, K * R)                       # (B, L, 12)
+        dts_tok = ops.linear(dtr, torch.block_diag(*self.dt_projs_weight.unbind(0)))        # (B, L, 4*96)
+        Bs, Cs = ops.cross_scan_bc(xdbl, HW, R, N)                                          # (B, 4, 16, L) each
+        xs = ops.cross_scan(xc, HW, dI, 1)                                                  # (B, 4*96, L)
+        dts = ops.cross_scan(dts_tok, HW, dI, 4)
+        out = ops.selective_scan_fn(xs, dts, -torch.exp(self.A_logs), Bs, Cs, self.Ds, z=None,
+                                    delta_bias=self.dt_projs_bias.reshape(-1), delta_softplus=True,
+                                    return_last_state=False)
+        return ops.cross_merge(out, HW, dI)
 
     def forward(self, x, HW, L_split):
         """x: (B, L_cat, d_model) -> (B, L_cat, d_model)."""
@@ -439,7 +428,7 @@ class SS2D_skip(nn.Module):
             toks.append(ops.dwconv3x3_nlc(x[:, off:off + L], self.conv2d[i].weight, self.conv2d[i].bias, H, W,
                                           silu=True))
             off += L
-        return self.out_proj(self.out_norm(self.core(toks, HW)))
+        return self.out_proj(self.out_norm(self.core(torch.cat(toks, dim=1), HW)))
 
 
 class _DWConv(nn.Module):

@@ -314,3 +314,152 @@ def layer_norm(x, weight, bias, eps=1e-5):
     if _lib.lib().mlagg_layernorm_supported(int(x.shape[-1])):
         return LayerNormFn.apply(x, weight, bias, eps)
     return torch.nn.functional.layer_norm(x, (x.shape[-1],), weight, bias, eps)
+
+
+class DWConv3x3NCHWFn(torch.autograd.Function):
+    """K2n: depthwise 3x3 (stride 1 or 2, padding 1) + bias on NCHW maps."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride):
+        x = _require(x.contiguous(), "x")
+        B, C, H, W = x.shape
+        w = _require(weight.reshape(C, 9).contiguous(), "weight")
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        y = torch.empty(B, C, Ho, Wo, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mlagg_dwconv3x3_nchw_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, C, H, W, int(stride),
+                                                       _stream()), "mlagg_dwconv3x3_nchw_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.meta = (int(stride), bias is not None, weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, has_bias, wshape = ctx.meta
+        B, C, H, W = x.shape
+        dy = _require(dy.contiguous(), "dy")
+        lib = _lib.lib()
+        dx = torch.empty_like(x)
+        dw = torch.empty(C, 9, device=x.device, dtype=torch.float32)
+        db = torch.empty(C, device=x.device, dtype=torch.float32) if has_bias else None
+        ws = torch.empty(lib.mlagg_dwconv3x3_nchw_bwd_workspace_floats(B, C, H, W, stride), device=x.device,
+                         dtype=torch.float32)
+        _lib.check(lib.mlagg_dwconv3x3_nchw_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws), B, C, H,
+                                                W, stride, _stream()), "mlagg_dwconv3x3_nchw_bwd")
+        return dx, dw.reshape(wshape), db, None
+
+
+def dwconv3x3_nchw(x, weight, bias, stride=1):
+    return DWConv3x3NCHWFn.apply(x, weight, bias, stride)
+
+
+def _int_array(vals):
+    import ctypes
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def _xscan(tok, tok_stride, blk_stride, seq, B, HW, CB, nblk, merge):
+    Hs, Ws = _int_array([h for h, _ in HW]), _int_array([w for _, w in HW])
+    lib = _lib.lib()
+    if merge:
+        _lib.check(lib.mlagg_cross_merge(_ptr(seq), tok, tok_stride, blk_stride, B, len(HW), Hs, Ws, CB, nblk, _stream()),
+                   "mlagg_cross_merge")
+    else:
+        _lib.check(lib.mlagg_cross_scan(tok, tok_stride, blk_stride, _ptr(seq), B, len(HW), Hs, Ws, CB, nblk, _stream()),
+                   "mlagg_cross_scan")
+
+
+class CrossScanFn(torch.autograd.Function):
+    """K1' scatter: token-major (B, L_cat, nblk*CB) -> (B, 4*CB, L_cat) scan sequences (nblk = 1: the four
+    directions share the source; nblk = 4: direction k reads channel block k)."""
+
+    @staticmethod
+    def forward(ctx, tok, HW, CB, nblk):
+        tok = _require(tok.contiguous(), "tok")
+        B, Lc, width = tok.shape
+        if Lc != sum(h * w for h, w in HW) or width != nblk * CB:
+            raise RuntimeError(f"cross_scan: bad shape {tuple(tok.shape)} for maps {HW}, CB {CB}, nblk {nblk}")
+        seq = torch.empty(B, 4 * CB, Lc, device=tok.device, dtype=torch.float32)
+        _xscan(tok.data_ptr(), width, CB, seq, B, HW, CB, nblk, merge=False)
+        ctx.meta = (tuple(HW), CB, nblk, width)
+        return seq
+
+    @staticmethod
+    def backward(ctx, dseq):
+        HW, CB, nblk, width = ctx.meta
+        dseq = _require(dseq.contiguous(), "dseq")
+        B, _, Lc = dseq.shape
+        dtok = torch.empty(B, Lc, width, device=dseq.device, dtype=torch.float32)
+        _xscan(dtok.data_ptr(), width, CB, dseq, B, HW, CB, nblk, merge=True)
+        return dtok, None, None, None
+
+
+class CrossMergeFn(torch.autograd.Function):
+    """K1' gather: (B, 4*CB, L_cat) scan-order outputs -> (B, L_cat, CB) token-major sum of the four directions."""
+
+    @staticmethod
+    def forward(ctx, seq, HW, CB):
+        seq = _require(seq.contiguous(), "seq")
+        B, rows, Lc = seq.shape
+        if rows != 4 * CB or Lc != sum(h * w for h, w in HW):
+            raise RuntimeError(f"cross_merge: bad shape {tuple(seq.shape)}")
+        tok = torch.empty(B, Lc, CB, device=seq.device, dtype=torch.float32)
+        _xscan(tok.data_ptr(), CB, CB, seq, B, HW, CB, 1, merge=True)
+        ctx.meta = (tuple(HW), CB)
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        HW, CB = ctx.meta
+        dtok = _require(dtok.contiguous(), "dtok")
+        B, Lc, _ = dtok.shape
+        dseq = torch.empty(B, 4 * CB, Lc, device=dtok.device, dtype=torch.float32)
+        _xscan(dtok.data_ptr(), CB, CB, dseq, B, HW, CB, 1, merge=False)
+        return dseq, None, None
+
+
+class CrossScanBCFn(torch.autograd.Function):
+    """The B and C rows of the scan from the token-major x_proj output (B, L_cat, 4*35): direction k's
+    B is columns [35k+3, 35k+19), C is [35k+19, 35k+35) (split at MambaSkip.py:433).  One backward
+    writes both column ranges of the x_proj gradient (the dt columns are returned zero: their gradient
+    arrives through the dt projection)."""
+
+    @staticmethod
+    def forward(ctx, xdbl, HW, dt_rank, d_state):
+        xdbl = _require(xdbl.contiguous(), "x_dbl")
+        B, Lc, width = xdbl.shape
+        per = dt_rank + 2 * d_state
+        if width != 4 * per:
+            raise RuntimeError("cross_scan_bc: x_dbl must hold 4 directions")
+        Bs = torch.empty(B, 4 * d_state, Lc, device=xdbl.device, dtype=torch.float32)
+        Cs = torch.empty(B, 4 * d_state, Lc, device=xdbl.device, dtype=torch.float32)
+        base = xdbl.data_ptr()
+        _xscan(base + 4 * dt_rank, width, per, Bs, B, HW, d_state, 4, merge=False)
+        _xscan(base + 4 * (dt_rank + d_state), width, per, Cs, B, HW, d_state, 4, merge=False)
+        ctx.meta = (tuple(HW), dt_rank, d_state, width)
+        return Bs.view(B, 4, d_state, Lc), Cs.view(B, 4, d_state, Lc)
+
+    @staticmethod
+    def backward(ctx, dBs, dCs):
+        HW, dt_rank, d_state, width = ctx.meta
+        per = dt_rank + 2 * d_state
+        dBs = _require(dBs.contiguous(), "dBs")
+        dCs = _require(dCs.contiguous(), "dCs")
+        B, Lc = dBs.shape[0], dBs.shape[-1]
+        dx = torch.zeros(B, Lc, width, device=dBs.device, dtype=torch.float32)
+        base = dx.data_ptr()
+        _xscan(base + 4 * dt_rank, width, per, dBs, B, HW, d_state, 4, merge=True)
+        _xscan(base + 4 * (dt_rank + d_state), width, per, dCs, B, HW, d_state, 4, merge=True)
+        return dx, None, None, None
+
+
+def cross_scan(tok, HW, CB, nblk):
+    return CrossScanFn.apply(tok, HW, CB, nblk)
+
+
+def cross_merge(seq, HW, CB):
+    return CrossMergeFn.apply(seq, HW, CB)
+
+
+def cross_scan_bc(xdbl, HW, dt_rank, d_state):
+    return CrossScanBCFn.apply(xdbl, HW, dt_rank, d_state)

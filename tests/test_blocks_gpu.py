@@ -220,3 +220,25 @@ def test_layernorm_matches_torch(rows, C, strided):
     _close(xg.grad, xr.grad.float(), 5e-6, 1e-4, "dx")
     _close(wg.grad, wr.grad.float(), 5e-6, 1e-4, "dgamma")
     _close(bg.grad, br.grad.float(), 5e-6, 1e-4, "dbeta")
+
+
+@gpu
+@pytest.mark.parametrize("C,H,W,stride", [(96, 16, 12, 1), (48, 9, 7, 2), (8, 128, 128, 2), (5, 1, 1, 1), (7, 2, 3, 2)])
+def test_dwconv3x3_nchw_matches_conv2d(C, H, W, stride):
+    from mlagg_unet_amd import ops
+    g = torch.Generator().manual_seed(C * H + stride)
+    B = 2
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, 1, 3, 3, generator=g) * 0.3
+    b = torch.randn(C, generator=g) * 0.1
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, br, stride=stride, padding=1, groups=C)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    xg, wg, bg = [t.clone().to(DEV).requires_grad_(True) for t in (x, w, b)]
+    out = ops.dwconv3x3_nchw(xg, wg, bg, stride)
+    out.backward(gy.to(DEV))
+    _close(out, ref, 1e-5, 1e-5, "y")
+    _close(xg.grad, xr.grad, 1e-5, 1e-4, "dx")
+    _close(wg.grad, wr.grad, 1e-5, 1e-4, "dw")
+    _close(bg.grad, br.grad, 1e-5, 1e-4, "db")
