@@ -85,12 +85,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; MLAGG_DIST_BACKEND=gloo + fewer devices than ranks is the single-GPU rehearsal of
+    # the multi-process path (ranks share the card, collectives go through the host) -- never a result
+    backend = os.environ.get("MLAGG_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     ddp = world > 1
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     import mlagg_unet_amd  # noqa: F401
     from mlagg_unet_amd import _lib, model, profiling, trainer
@@ -107,7 +114,7 @@ def main():
     use_graph = not ddp and not args.no_graph
     opt, sched = trainer.configure_optimizers(net, capturable=use_graph)
     sched.step(0)
-    step_net = trainer.wrap_ddp(net, local_rank) if ddp else net
+    step_net = trainer.wrap_ddp(net, dev_index) if ddp else net
     data, target = trainer.synthetic_batch(args.batch, 1, *IMG, N_CLASSES, seed=1234 + rank, device=dev)
 
     def eager_step():

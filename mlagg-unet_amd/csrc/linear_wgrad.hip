@@ -59,27 +59,50 @@ linear_wgrad_kernel(const float *__restrict__ dy, const float *__restrict__ x, f
     const float *xp = x + (size_t)(m_begin + kh) * g.x_stride + i0 + col;
     constexpr int UNR = 4;
     int m = m_begin;
-    for (; m + 2 * UNR <= m_end; m += 2 * UNR) {       // 4 token pairs per iteration, all rows in range
-        float av[UNR][TO], bv[UNR][TI];
+    // software pipeline: the operands of the NEXT 4 token pairs are in flight while the 36 MFMAs of the
+    // current 4 pairs issue (a wave alone on its SIMD would otherwise wait out every HBM round trip)
+    float av[2][UNR][TO], bv[2][UNR][TI];
+    auto fetch = [&](float (&A)[UNR][TO], float (&Bv)[UNR][TI]) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
 #pragma unroll
-            for (int a = 0; a < TO; ++a) av[u][a] = ld_or_zero(dyp + (size_t)(2 * u) * g.dy_stride + 32 * a, oko[a]);
+            for (int a = 0; a < TO; ++a) A[u][a] = ld_or_zero(dyp + (size_t)(2 * u) * g.dy_stride + 32 * a, oko[a]);
 #pragma unroll
-            for (int b = 0; b < TI; ++b) bv[u][b] = ld_or_zero(xp + (size_t)(2 * u) * g.x_stride + 32 * b, oki[b]);
+            for (int b = 0; b < TI; ++b) Bv[u][b] = ld_or_zero(xp + (size_t)(2 * u) * g.x_stride + 32 * b, oki[b]);
         }
+        dyp += (size_t)(2 * UNR) * g.dy_stride;
+        xp += (size_t)(2 * UNR) * g.x_stride;
+    };
+    auto consume = [&](const float (&A)[UNR][TO], const float (&Bv)[UNR][TI]) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
 #pragma unroll
             for (int a = 0; a < TO; ++a) {
-                bsum[a] += av[u][a];
+                bsum[a] += A[u][a];
 #pragma unroll
                 for (int b = 0; b < TI; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u][a], Bv[u][b], acc[a][b], 0, 0, 0);
             }
         }
-        dyp += (size_t)(2 * UNR) * g.dy_stride;
-        xp += (size_t)(2 * UNR) * g.x_stride;
+    };
+    const int nfull = (m_end - m_begin) / (2 * UNR);       // iterations with all 8 rows in range
+    if (nfull > 0) {
+        fetch(av[0], bv[0]);
+        int it = 0;
+        for (; it + 2 < nfull; it += 2) {
+            fetch(av[1], bv[1]);
+            consume(av[0], bv[0]);
+            fetch(av[0], bv[0]);
+            consume(av[1], bv[1]);
+        }
+        if (it + 1 < nfull) {
+            fetch(av[1], bv[1]);
+            consume(av[0], bv[0]);
+            consume(av[1], bv[1]);
+        } else {
+            consume(av[0], bv[0]);
+        }
+        m += nfull * 2 * UNR;
     }
     for (; m < m_end; m += 2) {                         // tail pairs (second row may be out of range)
         const bool rowok = m + kh < m_end;
@@ -141,7 +164,7 @@ int make_geom(WGeom &g, int M, int O, int I, int dys, int xs)
     g.M = M; g.O = O; g.I = I; g.dy_stride = dys; g.x_stride = xs;
     g.ogroups = (O + TMAX * 32 - 1) / (TMAX * 32);
     g.igroups = (I + TMAX * 32 - 1) / (TMAX * 32);
-    // ~2 waves per SIMD (1024 SIMDs), slabs of an even number of tokens, at least 64
+    // ~2 waves per SIMD (1024 SIMDs); slabs of an even number of tokens, at least 64
     int slab = (int)(((long long)M * g.ogroups * g.igroups + 2047) / 2048);
     slab = ((slab + 7) / 8) * 8;
     if (slab < 64) slab = 64;

@@ -38,6 +38,7 @@ constexpr int UP = ST + 4;   // row pitch of the u / delta / dy tiles (floats): 
 constexpr int BP = 20;       // pitch of the [t][n] B / C tiles
 constexpr int PP = 20;       // pitch of a per-chunk partial row: dA[16], dD, ddelta_bias, pad
 constexpr float LOG2E = 1.4426950408889634f;
+constexpr int BWD_CB = 32;   // channels per workgroup of the backward main kernel (see mlagg_selscan_bwd)
 
 struct ScanGeom {
     int batch, dim, L, G, Hc, CB, nblk, nchunks;
@@ -350,25 +351,41 @@ __global__ void selscan_bwd_local_kernel(const float *__restrict__ delta, const 
 // reduce-scatter style: after the call, for v in [0, NV/16) ... the caller reads the result of value
 // index (k) from the lane whose channel bits select it.  Generic butterfly with ds_bpermute
 // (LDS crossbar pipe, not LDS memory), so the VALU only pays the select + add.
-template <int HALF, int LVL>
-__device__ __forceinline__ void butterfly_level(float *v, int cl)
+__device__ __forceinline__ void swap32(float &a, float &b)
 {
-    const bool upper = (cl >> LVL) & 1;
-#pragma unroll
-    for (int i = 0; i < HALF; ++i) {
-        const float keep = upper ? v[i + HALF] : v[i];
-        const float send = upper ? v[i] : v[i + HALF];
-        v[i] = keep + __shfl_xor(send, 4 << LVL, 64);
-    }
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap16(float &a, float &b)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float row_ror4(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_ror8(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, true));
 }
 
-// 32 values per lane -> 2 per lane, summed over the 16 channels of the wave
-__device__ __forceinline__ void channel_reduce_scatter32(float (&v)[32], int cl)
+// Sum 32 per-lane values over the 16 channels of a wave (lane = 4 * channel + state quad, so the channel is
+// lane bits 2..5).  Lane bits 5 and 4: reduce-scatter with v_permlane32_swap / v_permlane16_swap (the swap
+// hands each half exactly the operand it needs: no selects, no LDS crossbar); lane bits 3 and 2: the four
+// lanes {i, i+4, i+8, i+12} of a DPP row are one orbit of row_ror:4, so two fused DPP adds all-reduce them.
+// Result: v[0..7] hold the channel sums of original values  j + 8 * bit4 + 16 * bit5,  identical in the
+// four lanes of an orbit.
+__device__ __forceinline__ void channel_reduce32(float (&v)[32])
 {
-    butterfly_level<16, 3>(v, cl);
-    butterfly_level<8, 2>(v, cl);
-    butterfly_level<4, 1>(v, cl);
-    butterfly_level<2, 0>(v, cl);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { swap32(v[i], v[i + 16]); v[i] += v[i + 16]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { swap16(v[i], v[i + 8]); v[i] += v[i + 8]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] += row_ror4(v[i]); v[i] += row_ror8(v[i]); }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -496,10 +513,8 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
                 activate_delta(rd, bias, softplus, t0 + 4 * id.s, L);
             *reinterpret_cast<float4 *>(sg + id.cl * UP + 4 * id.s) = rg;
         }
-        if (bcrow) {
-            float *dst = (tid < 64 ? sB : sC) + (4 * (tid & 3)) * BP + ((tid & 63) >> 2);
-            dst[0] = rbc.x; dst[BP] = rbc.y; dst[2 * BP] = rbc.z; dst[3 * BP] = rbc.w;
-        }
+        if (bcrow)      // phase R keeps B / C as [n][t] rows (pitch BP): a state's 16 steps are 4 b128 reads
+            *reinterpret_cast<float4 *>((tid < 64 ? sB : sC) + ((tid & 63) >> 2) * BP + 4 * (tid & 3)) = rbc;
         for (int i = tid; i < 2 * ST * NS; i += blockDim.x) aB[i] = 0.f;   // aB and aC are adjacent
         __syncthreads();
 
@@ -515,23 +530,27 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
             // v[k] : a_k, later the dB term ; v[ST + k] : h_{k-1}, later the dC term
             float v[2 * ST];
             float hh = sub == 3 ? ck[3][0] : (sub == 2 ? ck[2][0] : (sub == 1 ? ck[1][0] : ck[0][0]));
-            const float *sBi = sB + 4 * id.s + i, *sCi = sC + 4 * id.s + i;
+            const float *sBn = sB + (4 * id.s + i) * BP, *sCn = sC + (4 * id.s + i) * BP;   // this state's rows
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 dv = *reinterpret_cast<const float4 *>(sdr + 4 * q);
                 const float4 uv = *reinterpret_cast<const float4 *>(sur + 4 * q);
+                const float4 bb = *reinterpret_cast<const float4 *>(sBn + 4 * q);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = 4 * q + j;
                     const float dlk = f4get(dv, j) * actf;
                     v[ST + k] = hh;
                     v[k] = fast_exp2(dlk * A2[0]);
-                    hh = v[k] * hh + dlk * f4get(uv, j) * sBi[k * BP];
+                    hh = v[k] * hh + dlk * f4get(uv, j) * f4get(bb, j);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);     // keep the three phases of a state apart (register pressure)
             float qq = qc[0], dAi = dAacc[0];
 #pragma unroll
             for (int q = 3; q >= 0; --q) {
+                const float4 cc = *reinterpret_cast<const float4 *>(sCn + 4 * q);
+                const float4 bb = *reinterpret_cast<const float4 *>(sBn + 4 * q);
                 const float4 dv = *reinterpret_cast<const float4 *>(sdr + 4 * q);
                 const float4 uv = *reinterpret_cast<const float4 *>(sur + 4 * q);
                 const float4 gv = *reinterpret_cast<const float4 *>(sgr + 4 * q);
@@ -539,7 +558,7 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
                 for (int j = 3; j >= 0; --j) {
                     const int k = 4 * q + j;
                     const float dlk = f4get(dv, j) * actf, uk = f4get(uv, j), gyk = f4get(gv, j) * actf;
-                    const float Bv = sBi[k * BP], Cv = sCi[k * BP];
+                    const float Bv = f4get(bb, j), Cv = f4get(cc, j);
                     const float ak = v[k], hp = v[ST + k];
                     const float dlu = dlk * uk;
                     const float hk = ak * hp + dlu * Bv;                       // h_k
@@ -555,17 +574,19 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
             }
             qc[0] = qq;
             dAacc[0] = dAi;
-            // sum over the wave's 16 channels; 32 values -> 2 per lane
-            channel_reduce_scatter32(v, id.cl & 15);     // real lane position, also for padding lanes
+            __builtin_amdgcn_sched_barrier(0);
+            // sum over the wave's 16 channels (32 values -> 8, replicated over the 4 low channel lanes);
+            // the lane with low channel bits j adds values 2j and 2j+1 to the workgroup tile
+            channel_reduce32(v);
             {
-                const int c = id.cl & 15;
-                const int base = ((c >> 3) & 1) * 16 + ((c >> 2) & 1) * 8 + ((c >> 1) & 1) * 4 + (c & 1) * 2;
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int vi = base + e;               // [0,16): dB steps, [16,32): dC steps
-                    float *acc = (vi < ST ? aB : aC) + (vi & (ST - 1)) * NS + 4 * id.s + i;
-                    atomicAdd(acc, v[e]);
-                }
+                const int c = id.cl & 15;                       // real lane position, also for padding lanes
+                const int j = c & 3;
+                const float v0 = j == 0 ? v[0] : (j == 1 ? v[2] : (j == 2 ? v[4] : v[6]));
+                const float v1 = j == 0 ? v[1] : (j == 1 ? v[3] : (j == 2 ? v[5] : v[7]));
+                const int base = 2 * j + 8 * ((c >> 2) & 1) + 16 * ((c >> 3) & 1);     // [0,16): dB steps, [16,32): dC
+                float *acc0 = (base < ST ? aB : aC) + (base & (ST - 1)) * NS + 4 * id.s + i;
+                atomicAdd(acc0, v0);
+                atomicAdd(acc0 + NS, v1);                       // base is even: base + 1 stays in the same half
             }
             rot4(A2); rot4(Araw); rot4(qc); rot4(dAacc);
             rot4(ck[0]); rot4(ck[1]); rot4(ck[2]); rot4(ck[3]);
@@ -648,12 +669,12 @@ __global__ void selscan_reduce_partials(const float *__restrict__ part, float *_
     }
 }
 
-int make_geom(ScanGeom &gm, int batch, int dim, int L, int N, int G)
+int make_geom(ScanGeom &gm, int batch, int dim, int L, int N, int G, int max_cb = 128)
 {
     if (N != NS || batch <= 0 || dim <= 0 || L <= 0 || G <= 0 || dim % G != 0) return MLAGG_E_UNSUPPORTED;
     if (batch > 65535) return MLAGG_E_UNSUPPORTED;
     gm.batch = batch; gm.dim = dim; gm.L = L; gm.G = G; gm.Hc = dim / G;
-    gm.nblk = (gm.Hc + 127) / 128;
+    gm.nblk = (gm.Hc + max_cb - 1) / max_cb;
     gm.CB = (gm.Hc + gm.nblk - 1) / gm.nblk;
     gm.nchunks = (L + TC - 1) / TC;
     if ((size_t)G * gm.nblk > 65535) return MLAGG_E_UNSUPPORTED;
@@ -719,7 +740,13 @@ extern "C" int mlagg_selscan_bwd(const float *u, const float *delta, const float
     float *cq = workspace;
     float *part = workspace + (size_t)batch * gm.nchunks * dim * NS;
     const dim3 grid(gm.nchunks, G * gm.nblk, batch), block(block_threads(gm));
-    const int atomic_bc = gm.nblk > 1;
+    // The main kernel runs at 2 waves per SIMD (247 VGPRs).  Workgroups of 32 channels (2 waves) let a CU
+    // hold 4 independent workgroups = 8 waves, 2 per SIMD, instead of one 6-wave workgroup spread 2/2/1/1;
+    // the price is a 3-way float-atomic accumulation of dB/dC across the workgroups of a group.
+    ScanGeom gb;
+    if (int rc = make_geom(gb, batch, dim, L, N, G, BWD_CB)) return rc;
+    const dim3 gridb(gb.nchunks, G * gb.nblk, batch), blockb(block_threads(gb));
+    const int atomic_bc = gb.nblk > 1;
     if (atomic_bc) {
         const size_t bytes = (size_t)batch * G * NS * L * sizeof(float);
         (void)hipMemsetAsync(dB, 0, bytes, st);
@@ -730,9 +757,9 @@ extern "C" int mlagg_selscan_bwd(const float *u, const float *delta, const float
                        delta_softplus); }
     { MLAGG_TIMED(K_SELSCAN_PREFIX, st); hipLaunchKernelGGL(selscan_chunk_prefix, dim3((dim * NS + 255) / 256, batch), dim3(256), 0, st, A, cq, cdsum,
                        gm, 1); }
-    const size_t lds3 = (size_t)(3 * gm.CB * UP + 2 * ST * BP + 2 * ST * NS) * sizeof(float);
-    { MLAGG_TIMED(K_SELSCAN_BWD, st); hipLaunchKernelGGL(selscan_bwd_kernel, grid, block, lds3, st, u, delta, A, B, C, D, delta_bias, dout, cstate,
-                       cq, du, ddelta, dB, dC, part, gm, delta_softplus, atomic_bc); }
+    const size_t lds3 = (size_t)(3 * gb.CB * UP + 2 * ST * BP + 2 * ST * NS) * sizeof(float);
+    { MLAGG_TIMED(K_SELSCAN_BWD, st); hipLaunchKernelGGL(selscan_bwd_kernel, gridb, blockb, lds3, st, u, delta, A, B, C, D, delta_bias, dout, cstate,
+                       cq, du, ddelta, dB, dC, part, gb, delta_softplus, atomic_bc); }
     { MLAGG_TIMED(K_SELSCAN_REDUCE, st); hipLaunchKernelGGL(selscan_reduce_partials, dim3(dim), dim3(256), 0, st, part, dA, dD, ddelta_bias, gm); }
     return (int)hipGetLastError();
 }
