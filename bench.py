@@ -29,6 +29,20 @@ N_CLASSES = 14
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def pmc_traffic(kernel, batch):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950-corrected; collected at batch 10), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)["kernels"].get(kernel)
+    except (OSError, ValueError, KeyError):
+        return None
+    if rec is None or batch != BATCH_PER_GPU:
+        return None
+    return rec["traffic_bytes"]
+
+
 def host_threads():
     """CPU share of this process: the affinity mask, capped at 16 (the GPU box's per-GPU CPU share; its
     os.cpu_count() reports the whole host and oversubscribing it makes torch crawl)."""
@@ -177,7 +191,7 @@ def main():
         alg = profiling.algorithmic_bytes(dominant, args.batch, IMG)
         achieved = alg / (avg_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dominant, args.batch),
                 "avg_launch_ms": round(avg_ms, 4), "launches_timed": res["count"],
                 "algorithmic_bytes_per_launch": alg,
                 "all_kernels_ms_per_step": {k: round(v["ms"], 3) for k, v in sorted(table.items())}}

@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter CSVs (separate passes) into the per-kernel HBM
+traffic table bench.py reads for `roofline.traffic`.
+
+gfx950 corrections (MI355X_MICROARCH.md, section HBM): FETCH_SIZE counts the 128-byte requests of wide
+(16 B/lane) coalesced reads as 64 bytes -> doubled; WRITE_SIZE is exact for 16-byte stores.  Both are
+reported in KiB.
+
+    python tools/pmc_to_json.py gpurun_out/pmc2_FETCH_SIZE gpurun_out/pmc2_WRITE_SIZE > profiles/pmc_traffic.json
+"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def load(d):
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(d + "/*/*_counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            m = re.search(r"([a-z_0-9]+_kernel(?:<(?:true|false|\d+, ?\d+)>)?|selscan_[a-z_]+)", r["Kernel_Name"])
+            if m:
+                out[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+
+res = {}
+for d in sys.argv[1:]:
+    for k, v in load(d).items():
+        for c, vals in v.items():
+            res.setdefault(k, {})[c] = sum(vals) / len(vals)
+kern = {}
+for k, v in sorted(res.items()):
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        fetch, write = 2 * v["FETCH_SIZE"] * 1024, v["WRITE_SIZE"] * 1024
+        kern[k] = {"fetch_bytes_corrected": round(fetch), "write_bytes": round(write), "traffic_bytes": round(fetch + write)}
+json.dump({"workload": "tools/bench_ops.py scan: B=10, D=384, N=16, G=4, L=21760 (BASELINE config 2 MSMM scan)",
+           "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, per-dispatch averages; "
+                     "FETCH_SIZE x2 (gfx950 counts wide coalesced reads at half), both KiB -> bytes",
+           "kernels": kern}, sys.stdout, indent=1)
