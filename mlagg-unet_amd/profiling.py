@@ -52,8 +52,7 @@ def algorithmic_bytes(kernel, batch, img):
         "pooled_attn_fwd_kernel": 8 * dn,          # q in, out (pooled K/V negligible)
         "pooled_attn_bwd1_kernel": 16 * dn,        # q, dout, o_pre in; dq out
         "pooled_attn_bwd2_kernel": 8 * dn,         # q, d(o) in
-        "dwconv_fwd_kernel": 16 * dn,              # x in, y out at C = 96 * 2^i (the MLLA dwc; other callers differ)
-        "dwconv_bwd_data_kernel": 16 * dn,
-        "dwconv_bwd_weight_kernel": 16 * dn,
     }
+    # K2 / K2n / K5w / K6 / K1' are launched with several shapes per step (different callers): they have no
+    # single bytes-per-launch figure and are reported by time only
     return per_module.get(kernel, 0) * batch
