@@ -1,0 +1,72 @@
+"""GPU: the other BASELINE.json configurations as parity / robustness cases (not bench lines).
+
+configs[0] (128x128, batch 2, 14 classes, variant B): one full train step against the CPU oracle.
+configs[2] (224x224, 4 classes: pooled keys P = 49, L_cat = 16660) and configs[4] (512x640 RGB, 8 classes,
+variant A: P = 320 -> 120 KiB of LDS, L_cat = 108800): forward + backward run and stay finite; the
+oracle is too slow there, so the check is size-independent (loss finite, every gradient finite, and
+the logits of a second identical forward agree to 1e-4 -> no uninitialised reads)."""
+import pytest
+import torch
+
+from oracle import mlagg_oracle as O
+
+gpu = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@gpu
+def test_config0_train_step_matches_oracle():
+    from mlagg_unet_amd import model as PM, trainer as TR
+    img = (128, 128)
+    net = PM.build_network_architecture(img, 1, 14, True, "B")
+    O.deterministic_fill_(net.state_dict())
+    ref = O.build_reference_config_model(img, 1, 14, True, "B")
+    ref.load_state_dict(net.state_dict())
+    net = net.to(DEV).eval()         # eval: DropPath off, so both sides are deterministic
+    ref.eval()
+    data, target = O.synthetic_batch(2, 1, *img, 14, seed=1234)
+    out = net(data.to(DEV))
+    want = ref(data)
+    for o, w in zip(out, want):
+        assert float((o.cpu() - w).abs().max()) < 1e-3
+    loss = TR.deep_supervision_loss(out, [t.to(DEV) for t in target])
+    wloss = O.deep_supervision_loss(want, target)
+    assert abs(float(loss.detach()) - float(wloss.detach())) < 1e-4
+    loss.backward()
+    wloss.backward()
+    rg = {n: p.grad for n, p in ref.named_parameters() if p.grad is not None}
+    worst = 0.0
+    for n, p in net.named_parameters():
+        if p.grad is None:
+            assert n == "dummy_tensor"
+            continue
+        a, b = p.grad.cpu().double(), rg[n].double()
+        # absolute floor: gradients that are analytically zero (a bias in front of a per-channel norm) are
+        # pure rounding noise on both sides
+        err, ref_n = float((a - b).norm()), float(b.norm())
+        tol = 5e-3 * ref_n + 2e-5 * a.numel() ** 0.5
+        worst = max(worst, err / (ref_n + 1e-12) if ref_n > 1e-3 else 0.0)
+        assert err <= tol, (n, err, ref_n)
+    print("worst relative gradient error", worst)
+
+
+@gpu
+@pytest.mark.parametrize("img,in_ch,n_cls,variant", [((224, 224), 1, 4, "B"), ((512, 640), 3, 8, "A")])
+def test_other_configs_run_and_are_deterministic(img, in_ch, n_cls, variant):
+    from mlagg_unet_amd import model as PM, trainer as TR
+    torch.manual_seed(0)
+    net = PM.build_network_architecture(img, in_ch, n_cls, True, variant).to(DEV).eval()
+    data, target = TR.synthetic_batch(1, in_ch, *img, n_cls, seed=7, device=DEV)
+    out1 = [o.detach().clone() for o in net(data)]
+    out = net(data)
+    for a, b in zip(out1, out):
+        # not bit-identical: MIOpen may pick a different solver after its first-call search; an
+        # uninitialised read would show up as a gross difference
+        assert torch.isfinite(b).all()
+        assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
+    loss = TR.deep_supervision_loss(out, target)
+    assert torch.isfinite(loss)
+    loss.backward()
+    for n, p in net.named_parameters():
+        if n != "dummy_tensor":
+            assert p.grad is not None and torch.isfinite(p.grad).all(), n
