@@ -126,24 +126,26 @@ class AggregatedAttention(nn.Module):
             # q and kv in ONE GEMM over stacked weights (one read of x, one gradient into x); the kernel
             # takes the q / kv column blocks of the (B, N, 3d) result as strided views
             qkv = ops.linear(x, torch.cat([self.q.weight, self.kv.weight]), torch.cat([self.q.bias, self.kv.bias]))
-            return ops.local_diff_attn(qkv[..., :d], qkv[..., d:], lam, self.subln.weight, self.lepe.weight,
-                                       self.lepe.bias, self.H, self.W, self.num_heads, self.scale)
+            # split (not slicing): its backward is ONE concatenation instead of a zero-fill + copy per slice + adds
+            q, kv = qkv.split([d, 2 * d], dim=-1)
+            return ops.local_diff_attn(q, kv, lam, self.subln.weight, self.lepe.weight, self.lepe.bias,
+                                       self.H, self.W, self.num_heads, self.scale)
         # q, the value half of kv (LePE input; k is discarded at full resolution, T:719) and the 1x1 `sr`
         # conv in ONE GEMM
         w3 = torch.cat([self.q.weight, self.kv.weight[d:], self.sr.weight.view(d, d)])
         b3 = torch.cat([self.q.bias, self.kv.bias[d:], self.sr.bias])
         qvs = ops.linear(x, w3, b3)
-        q, v_full = qvs[..., :d], qvs[..., d:2 * d]
-        s = F.gelu(qvs[..., 2 * d:])
+        q, v_full, s_pre = qvs.split([d, d, d], dim=-1)
+        s = F.gelu(s_pre)
         if self.H % self.sr_ratio == 0 and self.W % self.sr_ratio == 0:
             r = self.sr_ratio
             pooled = s.view(B, self.pool_H, r, self.pool_W, r, d).mean(dim=(2, 4)).reshape(B, -1, d)
         else:
             img = s.view(B, self.H, self.W, d).permute(0, 3, 1, 2)
             pooled = F.adaptive_avg_pool2d(img, (self.pool_H, self.pool_W)).flatten(2).transpose(1, 2)
-        kvp = self.kv(self.norm(pooled))
+        k_pool, v_pool = self.kv(self.norm(pooled)).split([d, d], dim=-1)
         scale = self.scale if self.variant == "B" else self.scale * self.scale
-        o = ops.pooled_diff_attn(q, kvp[..., :d], kvp[..., d:], lam, self.subln.weight, self.num_heads, scale)
+        o = ops.pooled_diff_attn(q, k_pool, v_pool, lam, self.subln.weight, self.num_heads, scale)
         return o + ops.dwconv3x3_nlc(v_full, self.lepe.weight, self.lepe.bias, self.H, self.W, silu=False)
 
 
@@ -172,12 +174,15 @@ class MLLABlock(nn.Module):
         # act_proj and in_proj in ONE GEMM over stacked weights: (B, N, 2C) = [act | in]
         ai = ops.linear(xn, torch.cat([self.act_proj.weight, self.in_proj.weight]),
                         torch.cat([self.act_proj.bias, self.in_proj.bias]))
-        act_res = F.silu(ai[..., :C])
+        h = C // 2
+        act_pre, xa_in, za_in = ai.split([C, h, h], dim=-1)
+        act_res = F.silu(act_pre)
         # depthwise conv per channel half: the halves come out contiguous for the branch projections
         # (a channel slice of a (B, N, C) row would be copied by every Linear that consumes it)
-        h = C // 2
-        xa = ops.dwconv3x3_nlc(ai[..., C:C + h], self.dwc.weight[:h], self.dwc.bias[:h], H, W, silu=True)
-        za = ops.dwconv3x3_nlc(ai[..., C + h:], self.dwc.weight[h:], self.dwc.bias[h:], H, W, silu=True)
+        wa, wz = self.dwc.weight.split([h, h], dim=0)
+        ba, bz = self.dwc.bias.split([h, h], dim=0)
+        xa = ops.dwconv3x3_nlc(xa_in, wa, ba, H, W, silu=True)
+        za = ops.dwconv3x3_nlc(za_in, wz, bz, H, W, silu=True)
         mixed = torch.cat([self.attn[0](xa), self.attn[1](za)], dim=-1)
         dp = self.drop_path if isinstance(self.drop_path, DropPath) else None
         y = self.out_proj(mixed * act_res)
@@ -409,9 +414,8 @@ class SS2D_skip(nn.Module):
         K, R, N = 4, self.dt_rank, self.d_state
         per = R + 2 * N
         xdbl = ops.linear(xc, self.x_proj_weight.reshape(K * per, dI))                     # (B, L, 4*35)
-        dtr = xdbl.view(B, Lc, K, per)[..., :R].reshape(B, Lc, K * R)                       # (B, L, 12)
+        dtr, Bs, Cs = ops.cross_scan_bc(xdbl, HW, R, N)               # (B, L, 12) | (B, 4, 16, L) | (B, 4, 16, L)
         dts_tok = ops.linear(dtr, torch.block_diag(*self.dt_projs_weight.unbind(0)))        # (B, L, 4*96)
-        Bs, Cs = ops.cross_scan_bc(xdbl, HW, R, N)                                          # (B, 4, 16, L) each
         xs = ops.cross_scan(xc, HW, dI, 1)                                                  # (B, 4*96, L)
         dts = ops.cross_scan(dts_tok, HW, dI, 4)
         out = ops.selective_scan_fn(xs, dts, -torch.exp(self.A_logs), Bs, Cs, self.Ds, z=None,
@@ -421,13 +425,9 @@ class SS2D_skip(nn.Module):
 
     def forward(self, x, HW, L_split):
         """x: (B, L_cat, d_model) -> (B, L_cat, d_model)."""
-        x = self.in_proj(x)
-        toks = []
-        off = 0
-        for i, ((H, W), L) in enumerate(zip(HW, L_split)):
-            toks.append(ops.dwconv3x3_nlc(x[:, off:off + L], self.conv2d[i].weight, self.conv2d[i].bias, H, W,
-                                          silu=True))
-            off += L
+        parts = self.in_proj(x).split(list(L_split), dim=1)
+        toks = [ops.dwconv3x3_nlc(xi, self.conv2d[i].weight, self.conv2d[i].bias, H, W, silu=True)
+                for i, (xi, (H, W)) in enumerate(zip(parts, HW))]
         return self.out_proj(self.out_norm(self.core(torch.cat(toks, dim=1), HW)))
 
 
@@ -447,10 +447,9 @@ class ConvolutionalGLU(nn.Module):  # reference M:559-577
         self.fc2 = Linear(hidden, dim)
 
     def forward(self, x, H, W):
-        xv = self.fc1(x)
-        g = ops.dwconv3x3_nlc(xv[..., :self.hidden], self.dwconv.dwconv.weight, self.dwconv.dwconv.bias, H, W,
-                              silu=True)
-        return self.fc2(g * xv[..., self.hidden:])
+        xg, vg = self.fc1(x).split([self.hidden, self.hidden], dim=-1)
+        g = ops.dwconv3x3_nlc(xg, self.dwconv.dwconv.weight, self.dwconv.dwconv.bias, H, W, silu=True)
+        return self.fc2(g * vg)
 
 
 class VSS_Conv_Block(nn.Module):  # reference M:669-753
@@ -473,17 +472,15 @@ class VSS_Conv_Block(nn.Module):  # reference M:669-753
         Ls = [h * w for h, w in HW]
         hd = self.hidden_dim
         # (B, L_cat, 48) token-major concatenation of the first 48 channels of every scale
-        m = torch.cat([t.permute(0, 2, 3, 1)[..., :hd].reshape(B, -1, hd) for t in inputs], dim=1)
+        halves = [t.split([hd, t.shape[1] - hd], dim=1) for t in inputs]       # (mamba 48 | conv rest) per scale
+        m = torch.cat([mh.permute(0, 2, 3, 1).reshape(B, -1, hd) for mh, _ in halves], dim=1)
         m = self.drop_path.residual(m, self.self_attention(self.ln_1(m), HW, Ls))
         m = self.norm2(m)
         outs = []
-        off = 0
-        for i, ((H, W), L) in enumerate(zip(HW, Ls)):
-            mi = m[:, off:off + L]
-            off += L
+        for i, (mi, (H, W)) in enumerate(zip(m.split(Ls, dim=1), HW)):
             mi = self.drop_path.residual(mi, self.mlps[i](mi, H, W))
             mi = mi.reshape(B, H, W, hd).permute(0, 3, 1, 2)
-            outs.append(torch.cat([mi, self.conv_branches[i](inputs[i][:, hd:])], dim=1))
+            outs.append(torch.cat([mi, self.conv_branches[i](halves[i][1])], dim=1))
         return outs
 
 

@@ -419,10 +419,10 @@ class CrossMergeFn(torch.autograd.Function):
 
 
 class CrossScanBCFn(torch.autograd.Function):
-    """The B and C rows of the scan from the token-major x_proj output (B, L_cat, 4*35): direction k's
-    B is columns [35k+3, 35k+19), C is [35k+19, 35k+35) (split at MambaSkip.py:433).  One backward
-    writes both column ranges of the x_proj gradient (the dt columns are returned zero: their gradient
-    arrives through the dt projection)."""
+    """The single consumer of the token-major x_proj output (B, L_cat, 4*35), split as at MambaSkip.py:433:
+    direction k's dt columns [35k, 35k+3) come back compacted as (B, L_cat, 12) for the dt projection, its
+    B columns [35k+3, 35k+19) and C columns [35k+19, 35k+35) as scan-order rows.  One backward assembles the
+    whole x_proj gradient (no per-slice zero-fills and accumulations)."""
 
     @staticmethod
     def forward(ctx, xdbl, HW, dt_rank, d_state):
@@ -437,16 +437,18 @@ class CrossScanBCFn(torch.autograd.Function):
         _xscan(base + 4 * dt_rank, width, per, Bs, B, HW, d_state, 4, merge=False)
         _xscan(base + 4 * (dt_rank + d_state), width, per, Cs, B, HW, d_state, 4, merge=False)
         ctx.meta = (tuple(HW), dt_rank, d_state, width)
-        return Bs.view(B, 4, d_state, Lc), Cs.view(B, 4, d_state, Lc)
+        dtr = xdbl.view(B, Lc, 4, per)[..., :dt_rank].reshape(B, Lc, 4 * dt_rank)
+        return dtr, Bs.view(B, 4, d_state, Lc), Cs.view(B, 4, d_state, Lc)
 
     @staticmethod
-    def backward(ctx, dBs, dCs):
+    def backward(ctx, ddtr, dBs, dCs):
         HW, dt_rank, d_state, width = ctx.meta
         per = dt_rank + 2 * d_state
         dBs = _require(dBs.contiguous(), "dBs")
         dCs = _require(dCs.contiguous(), "dCs")
         B, Lc = dBs.shape[0], dBs.shape[-1]
-        dx = torch.zeros(B, Lc, width, device=dBs.device, dtype=torch.float32)
+        dx = torch.empty(B, Lc, width, device=dBs.device, dtype=torch.float32)
+        dx.view(B, Lc, 4, per)[..., :dt_rank] = ddtr.reshape(B, Lc, 4, dt_rank)
         base = dx.data_ptr()
         _xscan(base + 4 * dt_rank, width, per, dBs, B, HW, d_state, 4, merge=True)
         _xscan(base + 4 * (dt_rank + d_state), width, per, dCs, B, HW, d_state, 4, merge=True)
