@@ -178,6 +178,16 @@ int mlagg_cross_scan(const float *tok, int tok_stride, int blk_stride, float *se
 int mlagg_cross_merge(const float *seq, float *tok, int tok_stride, int blk_stride, int B, int nscale,
                       const int *H, const int *W, int CB, int nblk, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K7: gate of the MLLA block, out (rows, 2h) = concat(a0, a1) * SiLU(act) with a0, a1 (rows, h) contiguous and
+ * act (rows, 2h) at row stride act_stride.  Replaces SiLU + torch.cat + product at
+ * nnUNetTrainer_MLAgg_2D_dt_MS.py:888, 899, 902.  Backward overwrites da0, da1 (rows, h) and dact (rows, 2h).
+ * ------------------------------------------------------------------------------------------ */
+int mlagg_gate_fwd(const float *a0, const float *a1, const float *act, int act_stride, float *out, long rows, int h,
+                   void *stream);
+int mlagg_gate_bwd(const float *dout, int dout_stride, const float *a0, const float *a1, const float *act,
+                   int act_stride, float *da0, float *da1, float *dact, long rows, int h, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -176,16 +176,15 @@ class MLLABlock(nn.Module):
                         torch.cat([self.act_proj.bias, self.in_proj.bias]))
         h = C // 2
         act_pre, xa_in, za_in = ai.split([C, h, h], dim=-1)
-        act_res = F.silu(act_pre)
         # depthwise conv per channel half: the halves come out contiguous for the branch projections
         # (a channel slice of a (B, N, C) row would be copied by every Linear that consumes it)
         wa, wz = self.dwc.weight.split([h, h], dim=0)
         ba, bz = self.dwc.bias.split([h, h], dim=0)
         xa = ops.dwconv3x3_nlc(xa_in, wa, ba, H, W, silu=True)
         za = ops.dwconv3x3_nlc(za_in, wz, bz, H, W, silu=True)
-        mixed = torch.cat([self.attn[0](xa), self.attn[1](za)], dim=-1)
+        gated = ops.gate(self.attn[0](xa), self.attn[1](za), act_pre)       # K7: cat(.) * SiLU(act_proj(.))
         dp = self.drop_path if isinstance(self.drop_path, DropPath) else None
-        y = self.out_proj(mixed * act_res)
+        y = self.out_proj(gated)
         x = dp.residual(x, y) if dp is not None else x + y
         y = self.mlp(self.norm2(x))
         return dp.residual(x, y) if dp is not None else x + y

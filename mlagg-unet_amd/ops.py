@@ -465,3 +465,44 @@ def cross_merge(seq, HW, CB):
 
 def cross_scan_bc(xdbl, HW, dt_rank, d_state):
     return CrossScanBCFn.apply(xdbl, HW, dt_rank, d_state)
+
+
+class GateFn(torch.autograd.Function):
+    """K7: concat(a0, a1) * SiLU(act) (the MLLA block's gate) in one pass each way."""
+
+    @staticmethod
+    def forward(ctx, a0, a1, act):
+        a0 = _require(a0.contiguous(), "a0")
+        a1 = _require(a1.contiguous(), "a1")
+        act2, acts = _rows2d(act, "act")
+        h = a0.shape[-1]
+        rows = a0.numel() // h
+        if a1.shape != a0.shape or act.shape[-1] != 2 * h or act2.shape[0] != rows:
+            raise RuntimeError("gate: shape mismatch")
+        if acts % 4 or act2.data_ptr() % 16:
+            act2 = act2.contiguous()
+            acts = 2 * h
+        out = torch.empty(a0.shape[:-1] + (2 * h,), device=a0.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mlagg_gate_fwd(_ptr(a0), _ptr(a1), _ptr(act2), acts, _ptr(out), rows, h, _stream()),
+                   "mlagg_gate_fwd")
+        ctx.save_for_backward(a0, a1, act2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a0, a1, act2 = ctx.saved_tensors
+        h = a0.shape[-1]
+        rows = a0.numel() // h
+        d2, ds = _rows2d(dout, "dout")
+        if ds % 4 or d2.data_ptr() % 16:
+            d2 = d2.contiguous()
+            ds = 2 * h
+        da0, da1 = torch.empty_like(a0), torch.empty_like(a1)
+        dact = torch.empty(a0.shape[:-1] + (2 * h,), device=a0.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mlagg_gate_bwd(_ptr(d2), ds, _ptr(a0), _ptr(a1), _ptr(act2), act2.stride(0), _ptr(da0),
+                                             _ptr(da1), _ptr(dact), rows, h, _stream()), "mlagg_gate_bwd")
+        return da0, da1, dact
+
+
+def gate(a0, a1, act):
+    return GateFn.apply(a0, a1, act)
