@@ -135,6 +135,12 @@ int mlagg_dwconv3x3_bwd(const float *x, int x_stride, const float *w, const floa
  * backward of the nn.Linear layers at nnUNetTrainer_MLAgg_2D_dt_MS.py:687-690, 887-907 and
  * MambaSkip.py:518, 538, 572-575 (split-K over tokens on fp32 MFMA).  dW / db are overwritten.
  * ------------------------------------------------------------------------------------------ */
+/* K5: the same layers' forward y (M, N) = x (M, K) . w (N, K)^T + bias and input gradient
+ * dx (M, I) = dy (M, O) . w (O, I) on fp32 MFMA (w contiguous; x / y / dy / dx with row strides; K and I % 4 == 0). */
+int mlagg_linear_fwd(const float *x, int x_stride, const float *w, const float *bias, float *y, int y_stride,
+                     int M, int N, int K, void *stream);
+int mlagg_linear_dgrad(const float *dy, int dy_stride, const float *w, float *dx, int dx_stride, int M, int O, int I,
+                       void *stream);
 size_t mlagg_linear_wgrad_workspace_floats(int M, int O, int I);
 int mlagg_linear_wgrad(const float *dy, int dy_stride, const float *x, int x_stride, float *dW, float *db,
                        float *workspace, int M, int O, int I, void *stream);

@@ -53,6 +53,8 @@ SIGNATURES = {
     "mlagg_cross_merge": (_I, [_F, _F, _I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), _I, _I, _S]),
     "mlagg_gate_fwd": (_I, [_F, _F, _F, _I, _F, ctypes.c_long, _I, _S]),
     "mlagg_gate_bwd": (_I, [_F, _I, _F, _F, _F, _I, _F, _F, _F, ctypes.c_long, _I, _S]),
+    "mlagg_linear_fwd": (_I, [_F, _I, _F, _F, _F, _I, _I, _I, _I, _S]),
+    "mlagg_linear_dgrad": (_I, [_F, _I, _F, _F, _I, _I, _I, _I, _S]),
 }
 
 _lib = None

@@ -25,7 +25,8 @@ const char *const kNames[K_COUNT] = {
     "local_attn_bwd_b_kernel", "pooled_attn_fwd_kernel", "pooled_attn_bwd1_kernel",
     "pooled_attn_bwd2_kernel", "dwconv_fwd_kernel", "dwconv_bwd_data_kernel", "dwconv_bwd_weight_kernel", "linear_wgrad_kernel", "layernorm_fwd_kernel",
     "layernorm_bwd_kernel", "dwconv_nchw_fwd_kernel", "dwconv_nchw_bwd (data+weight+reduce)",
-    "cross_scan_kernel<false>", "cross_scan_kernel<true>", "gate_fwd_kernel", "gate_bwd_kernel"};
+    "cross_scan_kernel<false>", "cross_scan_kernel<true>", "gate_fwd_kernel", "gate_bwd_kernel",
+    "linear_mfma_kernel<true>", "linear_mfma_kernel<false>"};
 }  // namespace
 
 // begin/end pairs of one kernel are issued back to back from one host thread (the launcher), so the

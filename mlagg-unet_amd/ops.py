@@ -232,29 +232,55 @@ def _rows2d(t, name):
     return t2, t2.stride(0)
 
 
+def _mfma_rows(t, name):
+    """(..., C) -> (M, C) view usable by the MFMA projection kernels (unit inner stride, 16-byte aligned rows)."""
+    t2, ts = _rows2d(t, name)
+    if ts % 4 or t2.data_ptr() % 16:
+        t2 = t2.contiguous()
+        ts = t2.shape[1]
+    return t2, ts
+
+
 class LinearFn(torch.autograd.Function):
-    """y = x W^T + b.  Forward and dx on the library GEMM (plain dense contraction); dW / db on K5w, the
-    split-K-over-tokens MFMA kernel, when the token count makes it the tall-skinny case."""
+    """y = x W^T + b for token-major activations.  With many tokens (the tall-skinny case of the encoder and
+    the MSMM block) all three GEMMs run on this package's fp32 MFMA kernels: K5 (forward, dx) and K5w (dW, db);
+    small problems go to the library GEMM."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        O, I = weight.shape
+        M = x.numel() // I
+        if M >= WGRAD_MIN_ROWS and I % 4 == 0 and x.is_cuda:
+            x2, xs = _mfma_rows(x, "x")
+            w = _require(weight.contiguous(), "weight")
+            y = torch.empty(x.shape[:-1] + (O,), device=x.device, dtype=torch.float32)
+            _lib.check(_lib.lib().mlagg_linear_fwd(_ptr(x2), xs, _ptr(w), _ptr(bias), _ptr(y), O, M, O, I, _stream()),
+                       "mlagg_linear_fwd")
+            return y
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dx = dW = db = None
+        O, I = weight.shape
+        dy2, dys = _mfma_rows(dy, "dy")
+        M = dy2.shape[0]
+        big = M >= WGRAD_MIN_ROWS
+        lib = _lib.lib()
         if ctx.needs_input_grad[0]:
-            dx = dy.matmul(weight)
+            if big and O % 4 == 0 and I % 4 == 0:
+                w = _require(weight.contiguous(), "weight")
+                dx = torch.empty(x.shape, device=dy.device, dtype=torch.float32)
+                _lib.check(lib.mlagg_linear_dgrad(_ptr(dy2), dys, _ptr(w), _ptr(dx), I, M, O, I, _stream()),
+                           "mlagg_linear_dgrad")
+            else:
+                dx = dy.matmul(weight)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            O, I = weight.shape
-            dy2, dys = _rows2d(dy, "dy")
             x2, xs = _rows2d(x, "x")
-            M = dy2.shape[0]
-            if M >= WGRAD_MIN_ROWS:
-                lib = _lib.lib()
+            if big:
                 dW = torch.empty_like(weight)
                 db = torch.empty(O, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
                 ws = torch.empty(lib.mlagg_linear_wgrad_workspace_floats(M, O, I), device=dy.device,
