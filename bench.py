@@ -91,7 +91,11 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="per-GPU batch (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole step as one hipGraph (trainer.GraphedTrainStep).  Off by default: at "
+                         "config 2 the step is GPU-bound either way (61.58 vs 61.63 ms measured A/B on one box) and "
+                         "eager launches let the roofline kernel be event-timed inside the timed region itself")
+    ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,7 +129,7 @@ def main():
     net = model.build_network_architecture(IMG, 1, N_CLASSES, True, "B").to(dev).train()
     if model.CHANNELS_LAST:
         net = net.to(memory_format=torch.channels_last)
-    use_graph = not ddp and not args.no_graph
+    use_graph = args.graph and not ddp and not args.no_graph
     opt, sched = trainer.configure_optimizers(net, capturable=use_graph)
     sched.step(0)
     step_net = trainer.wrap_ddp(net, dev_index) if ddp else net
