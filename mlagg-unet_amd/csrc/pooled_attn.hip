@@ -246,7 +246,6 @@ pooled_attn_bwd1_kernel(const float *__restrict__ q, const float *__restrict__ k
 // VGPRs, the 4 waves are summed through LDS and the workgroup writes ONE partial block -- no atomics
 // (256 adders per address made the atomic form contention-bound: 0.5 ms per launch in the first profile).
 // pooled_attn_bwd2_reduce_kernel sums the partial blocks.
-constexpr int B2_WAVES = 4;
 constexpr int B2_TILE = 32;                      // tokens per LDS tile of one wave
 constexpr int B2_TILE_FLOATS = B2_TILE * (HD2 + HD2 + 4);
 constexpr int B2_TPB = 512;                      // tokens per workgroup
@@ -257,30 +256,38 @@ pooled_attn_bwd2_kernel(const float *__restrict__ q, const float *__restrict__ k
                         const float *__restrict__ lamp, const float *__restrict__ lse, const float *__restrict__ ws,
                         float *__restrict__ part, Geom g)
 {
-    __shared__ float4 lds4[B2_WAVES * B2_TILE_FLOATS / 4];
+    // A DPP lane pair owns a key: lane r holds map r's 24 k channels, half of v, and the matching halves of
+    // dK / dV (96 persistent VGPRs instead of 192 -> 4 waves per SIMD instead of AGPR spilling at 1).
+    // A wave covers 32 keys; waves 0,1 take keys 0..63 for the first half of the workgroup's tokens,
+    // waves 2,3 the same keys for the second half.
+    __shared__ float4 lds4[2 * B2_TILE_FLOATS / 4 + 2 * HD2 * B2_RED_PITCH / 4 + 4];
     float *lds = reinterpret_cast<float *>(lds4);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *sQ = lds + wave * B2_TILE_FLOATS;           // [tile][48] scaled q
+    const int half = wave >> 1;                         // token half of the workgroup
+    const int r = lane & 1;
+    float *sQ = lds + half * B2_TILE_FLOATS;            // [tile][48] scaled q   (one tile per token half)
     float *sO = sQ + B2_TILE * HD2;                     // [tile][48] d(o)
     float *sS = sO + B2_TILE * HD2;                     // [tile][4]  lse1, lse2, D1, D2
     const int h = blockIdx.y, b = blockIdx.z;
     const int pblocks = (g.P + 63) / 64;
     const int pb = blockIdx.x % pblocks, tb = blockIdx.x / pblocks;
-    const int p = pb * 64 + lane;
+    const int p = pb * 64 + (wave & 1) * 32 + (lane >> 1);
     const bool act = p < g.P;
     const float lam = lamp[0];
-    float kv[HD2], vv[HD2], dk[HD2], dv[HD2];
+    float kr[HD], vh[HD], dk[HD], dv[HD];
 #pragma unroll
-    for (int e = 0; e < HD2; ++e) { kv[e] = 0.f; vv[e] = 0.f; dk[e] = 0.f; dv[e] = 0.f; }
+    for (int e = 0; e < HD; ++e) { kr[e] = 0.f; vh[e] = 0.f; dk[e] = 0.f; dv[e] = 0.f; }
     if (act) {
-        loadv<HD2>(kp + ((size_t)b * g.P + p) * g.kp_stride + h * HD2, kv);
-        loadv<HD2>(vp + ((size_t)b * g.P + p) * g.vp_stride + h * HD2, vv);
+        loadv<HD>(kp + ((size_t)b * g.P + p) * g.kp_stride + h * HD2 + HD * r, kr);
+        loadv<HD>(vp + ((size_t)b * g.P + p) * g.vp_stride + h * HD2 + HD * r, vh);
     }
-    const int t_begin = tb * B2_TPB + wave * (B2_TPB / B2_WAVES);
-    const int t_end = min(t_begin + B2_TPB / B2_WAVES, g.N);
-    for (int t0 = t_begin; t0 < t_end; t0 += B2_TILE) {       // wave-private tiles: no block barrier needed
-        const int nt = min(B2_TILE, t_end - t0);
-        for (int i = lane; i < nt * (HD2 / 4); i += 64) {
+    const int t_begin = tb * B2_TPB + half * (B2_TPB / 2);
+    const int t_end = min(t_begin + B2_TPB / 2, g.N);
+    const int ltid = threadIdx.x & 127;                 // the two waves of a token half stage its tile together
+    for (int t0 = t_begin; t0 < t_begin + B2_TPB / 2; t0 += B2_TILE) {     // uniform trip count: barriers inside
+        const int nt = max(0, min(B2_TILE, t_end - t0));
+        __syncthreads();
+        for (int i = ltid; i < nt * (HD2 / 4); i += 128) {
             const int tt = i / (HD2 / 4), c4 = i - tt * (HD2 / 4);
             const size_t tok = (size_t)b * g.N + t0 + tt;
             float4 a = *reinterpret_cast<const float4 *>(q + tok * g.q_stride + h * HD2 + 4 * c4);
@@ -289,52 +296,56 @@ pooled_attn_bwd2_kernel(const float *__restrict__ q, const float *__restrict__ k
             *reinterpret_cast<float4 *>(sO + tt * HD2 + 4 * c4) =
                 *reinterpret_cast<const float4 *>(ws + (tok * g.nh + h) * WS_PER_UNIT + 4 * c4);
         }
-        if (lane < nt) {
-            const size_t tok = (size_t)b * g.N + t0 + lane;
+        if (ltid < nt) {
+            const size_t tok = (size_t)b * g.N + t0 + ltid;
             const float *wrow = ws + (tok * g.nh + h) * WS_PER_UNIT;
-            *reinterpret_cast<float4 *>(sS + 4 * lane) =
+            *reinterpret_cast<float4 *>(sS + 4 * ltid) =
                 make_float4(lse[(tok * g.nh + h) * 2], lse[(tok * g.nh + h) * 2 + 1], wrow[HD2], wrow[HD2 + 1]);
         }
-        __builtin_amdgcn_s_waitcnt(0);       // wave-local LDS hand-off: writes landed before the reads below
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
         for (int tt = 0; tt < nt; ++tt) {
             const float4 st = *reinterpret_cast<const float4 *>(sS + 4 * tt);
-            const float *qt = sQ + tt * HD2, *ot = sO + tt * HD2;
-            float l1 = 0.f, l2 = 0.f, dw = 0.f;
+            const float *qt = sQ + tt * HD2 + HD * r, *ot = sO + tt * HD2 + HD * r;
+            float la[4] = {0.f, 0.f, 0.f, 0.f}, da[4] = {0.f, 0.f, 0.f, 0.f};
+            float qv[HD], ov[HD];
 #pragma unroll
-            for (int e = 0; e < HD; ++e) { l1 += qt[e] * kv[e]; l2 += qt[HD + e] * kv[HD + e]; }
-#pragma unroll
-            for (int e = 0; e < HD2; ++e) dw += ot[e] * vv[e];
-            const float s1 = __expf(l1 - st.x), s2 = __expf(l2 - st.y);
-            const float w = s1 - lam * s2;
-            const float dl1 = s1 * (dw - st.z);              // dL/d(logit1)
-            const float dl2 = s2 * (-lam * dw - st.w);       // dL/d(logit2)
-#pragma unroll
-            for (int e = 0; e < HD; ++e) {
-                // logit = (scale * q) . k and the q tile is pre-scaled: d(logit)/dk = q tile row
-                dk[e] += dl1 * qt[e];
-                dk[HD + e] += dl2 * qt[HD + e];
+            for (int e = 0; e < HD; e += 4) {
+                const float4 q4 = *reinterpret_cast<const float4 *>(qt + e);
+                const float4 o4 = *reinterpret_cast<const float4 *>(ot + e);
+                qv[e] = q4.x; qv[e + 1] = q4.y; qv[e + 2] = q4.z; qv[e + 3] = q4.w;
+                ov[e] = o4.x; ov[e + 1] = o4.y; ov[e + 2] = o4.z; ov[e + 3] = o4.w;
             }
 #pragma unroll
-            for (int e = 0; e < HD2; ++e) dv[e] += w * ot[e];
+            for (int e = 0; e < HD; e += 4)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { la[j] += qv[e + j] * kr[e + j]; da[j] += ov[e + j] * vh[e + j]; }
+            const float l = (la[0] + la[1]) + (la[2] + la[3]);          // this lane's map logit
+            float dw = (da[0] + da[1]) + (da[2] + da[3]);
+            dw += dpp_xor1(dw);                                          // d(o) . v over all 48 channels
+            const float s = __expf(l - (r ? st.y : st.x));
+            const float so = dpp_xor1(s);
+            const float w = r ? so - lam * s : s - lam * so;             // s1 - lam s2 on both lanes
+            const float dl = r ? s * (-lam * dw - st.w) : s * (dw - st.z);   // dL/d(logit of this lane's map)
+#pragma unroll
+            for (int e = 0; e < HD; ++e) {
+                dk[e] += dl * qv[e];        // q tile is pre-scaled: d(logit)/dk = scaled q row
+                dv[e] += w * ov[e];
+            }
         }
-        __builtin_amdgcn_wave_barrier();
     }
-    // cross-wave sum through LDS, dK then dV; the image is [wave][channel][key] with pitch 65
-    float *red = lds;
+    // sum the two token halves through LDS, dK then dV; image [half][channel 0..47][key 0..63], pitch 65
+    float *red = lds + 2 * B2_TILE_FLOATS;
     float *pbase = part + ((((size_t)b * g.nh + h) * gridDim.x + blockIdx.x) * 2) * (64 * HD2);
+    const int kl = (wave & 1) * 32 + (lane >> 1);       // key inside the 64-key block
 #pragma unroll 1
     for (int kind = 0; kind < 2; ++kind) {
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < HD2; ++e) red[(wave * HD2 + e) * B2_RED_PITCH + lane] = kind ? dv[e] : dk[e];
+        for (int e = 0; e < HD; ++e) red[((half * HD2) + HD * r + e) * B2_RED_PITCH + kl] = kind ? dv[e] : dk[e];
         __syncthreads();
         for (int o = threadIdx.x; o < 64 * HD2; o += 256) {
             const int pp = o / HD2, e = o - pp * HD2;
-            float sum = 0.f;
-#pragma unroll
-            for (int w2 = 0; w2 < B2_WAVES; ++w2) sum += red[(w2 * HD2 + e) * B2_RED_PITCH + pp];
-            pbase[(size_t)kind * (64 * HD2) + o] = sum;
+            pbase[(size_t)kind * (64 * HD2) + o] = red[e * B2_RED_PITCH + pp] + red[(HD2 + e) * B2_RED_PITCH + pp];
         }
     }
 }
