@@ -100,7 +100,8 @@ dwconv_bwd_data_kernel(const float *__restrict__ dy, int dy_stride, const float 
 template <bool SILU>
 __global__ void __launch_bounds__(256)
 dwconv_bwd_weight_kernel(const float *__restrict__ x, int x_stride, const float *__restrict__ dy, int dy_stride,
-                         const float *__restrict__ pre, float *__restrict__ part, int batch, int H, int W, int C)
+                         const float *__restrict__ pre, float *__restrict__ part, float *__restrict__ gbuf, int batch,
+                         int H, int W, int C)
 {
     __shared__ float red[4][10][64];
     const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
@@ -128,7 +129,10 @@ dwconv_bwd_weight_kernel(const float *__restrict__ x, int x_stride, const float 
             col(xx + 1, r);
             const size_t t = (size_t)b * N + (size_t)y * W + xx;
             float gv = dy[t * dy_stride + c];
-            if (SILU) gv *= dsilu_f(pre[t * C + c]);
+            if (SILU) {
+                gv *= dsilu_f(pre[t * C + c]);
+                if (gbuf) gbuf[t * C + c] = gv;      // g = dy * silu'(pre), reused by the data-gradient kernel
+            }
             gb += gv;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
@@ -201,7 +205,8 @@ size_t dwconv_wgrad_workspace_floats(int batch, int H, int W, int C)
 }
 
 void dwconv_wgrad_launch(const float *x, int x_stride, const float *dy, int dy_stride, const float *pre, float *dw,
-                         float *dbias, float *part, int batch, int H, int W, int C, int silu, hipStream_t st)
+                         float *dbias, float *part, int batch, int H, int W, int C, int silu, hipStream_t st,
+                         float *gbuf)
 {
     const int chunks = H;
     const dim3 grid(chunks, (C + 63) / 64, batch);
@@ -209,10 +214,10 @@ void dwconv_wgrad_launch(const float *x, int x_stride, const float *dy, int dy_s
         MLAGG_TIMED(K_DWCONV_BWD_WEIGHT, st);
         if (silu)
             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<true>, grid, dim3(256), 0, st, x, x_stride, dy, dy_stride, pre,
-                               part, batch, H, W, C);
+                               part, gbuf, batch, H, W, C);
         else
             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<false>, grid, dim3(256), 0, st, x, x_stride, dy, dy_stride, pre,
-                               part, batch, H, W, C);
+                               part, gbuf, batch, H, W, C);
         hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3((C * 10 + 63) / 64), dim3(1024), 0, st, part,
                            batch * chunks, C, dw, dbias);
     }
@@ -221,7 +226,8 @@ void dwconv_wgrad_launch(const float *x, int x_stride, const float *dy, int dy_s
 
 extern "C" size_t mlagg_dwconv3x3_bwd_workspace_floats(int batch, int H, int W, int C)
 {
-    return mlagg_internal::dwconv_wgrad_workspace_floats(batch, H, W, C);
+    // partial rows of the weight gradient + the (batch, H*W, C) buffer of dy * silu'(pre)
+    return mlagg_internal::dwconv_wgrad_workspace_floats(batch, H, W, C) + (size_t)batch * H * W * C;
 }
 
 extern "C" int mlagg_dwconv3x3_fwd(const float *x, int x_stride, const float *w, const float *bias, float *y,
@@ -252,14 +258,15 @@ extern "C" int mlagg_dwconv3x3_bwd(const float *x, int x_stride, const float *w,
     const size_t total = (size_t)H * W * (C / 4);
     const dim3 grid((unsigned)((total + 255) / 256), batch), block(256);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // weight gradient first: with SiLU it also emits g = dy * silu'(pre) once per element, so the data
+    // gradient below is a plain 9-tap gather of g instead of 9 x (load dy, load pre, evaluate silu')
+    float *gbuf = silu ? workspace + mlagg_internal::dwconv_wgrad_workspace_floats(batch, H, W, C) : nullptr;
+    mlagg_internal::dwconv_wgrad_launch(x, x_stride, dy, dy_stride, pre, dw, dbias, workspace, batch, H, W, C, silu, st,
+                                        gbuf);
     {
         MLAGG_TIMED(K_DWCONV_BWD_DATA, st);
-        if (silu)
-            hipLaunchKernelGGL(dwconv_bwd_data_kernel<true>, grid, block, 0, st, dy, dy_stride, pre, w, dx, dx_stride, g);
-        else
-            hipLaunchKernelGGL(dwconv_bwd_data_kernel<false>, grid, block, 0, st, dy, dy_stride, pre, w, dx, dx_stride,
-                               g);
+        hipLaunchKernelGGL(dwconv_bwd_data_kernel<false>, grid, block, 0, st, silu ? gbuf : dy, silu ? C : dy_stride,
+                           nullptr, w, dx, dx_stride, g);
     }
-    mlagg_internal::dwconv_wgrad_launch(x, x_stride, dy, dy_stride, pre, dw, dbias, workspace, batch, H, W, C, silu, st);
     return (int)hipGetLastError();
 }
