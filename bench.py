@@ -127,8 +127,6 @@ def main():
     torch.backends.cudnn.benchmark = os.environ.get("MLAGG_MIOPEN_FIND", "0") == "1"
     torch.manual_seed(0)
     net = model.build_network_architecture(IMG, 1, N_CLASSES, True, "B").to(dev).train()
-    if model.CHANNELS_LAST:
-        net = net.to(memory_format=torch.channels_last)
     use_graph = args.graph and not ddp and not args.no_graph
     opt, sched = trainer.configure_optimizers(net, capturable=use_graph)
     sched.step(0)

@@ -23,7 +23,7 @@ const char *const kNames[K_COUNT] = {
     "selscan_fwd_kernel<false>", "selscan_chunk_prefix", "selscan_fwd_kernel<true>", "selscan_bwd_local_kernel",
     "selscan_bwd_kernel", "selscan_reduce_partials", "local_attn_fwd_kernel", "local_attn_bwd_a_kernel",
     "local_attn_bwd_b_kernel", "pooled_attn_fwd_kernel", "pooled_attn_bwd1_kernel",
-    "pooled_attn_bwd2_kernel", "dwconv_fwd_kernel", "dwconv_bwd_data_kernel", "dwconv_bwd_weight_kernel", "linear_wgrad_kernel", "layernorm_fwd_kernel",
+    "pooled_attn_bwd2_kernel", "dwconv_tiled_kernel<fwd>", "dwconv_tiled_kernel<dgrad>", "dwconv_bwd_weight_kernel", "linear_wgrad_kernel", "layernorm_fwd_kernel",
     "layernorm_bwd_kernel", "dwconv_nchw_fwd_kernel", "dwconv_nchw_bwd (data+weight+reduce)",
     "cross_scan_kernel<false>", "cross_scan_kernel<true>", "gate_fwd_kernel", "gate_bwd_kernel",
     "linear_mfma_kernel<true>", "linear_mfma_kernel<false>"};

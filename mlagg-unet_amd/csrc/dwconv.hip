@@ -27,69 +27,60 @@ __device__ __forceinline__ float dsilu_f(float x)
     return s * (1.f + x * (1.f - s));
 }
 
-// one thread: 4 consecutive channels of one token
-template <bool SILU>
+// LDS-tiled 3x3 gather, shared by the forward (FLIP = false: y = bias + sum_j w[j] x[t + off_j], optional
+// SiLU with the pre-activation saved) and the data gradient (FLIP = true: dx = sum_j w[8 - j] g[t + off_j]).
+// A workgroup owns an 8 x 16 token tile and 32 channels: the 10 x 18 halo is read from HBM once as
+// 128-byte channel runs into LDS, each output float4 is then 9 conflict-free ds_read_b128 (two tokens of
+// 8 lanes cover one 256-byte bank row).  Without the tile the 9 taps are 9 L2 round trips per output.
+constexpr int TY = 8, TX = 16, CCH = 32;
+constexpr int HY = TY + 2, HX = TX + 2;
+
+template <bool SILU, bool FLIP>
 __global__ void __launch_bounds__(256)
-dwconv_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-                  float *__restrict__ y, float *__restrict__ pre, Geom g)
+dwconv_tiled_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                    float *__restrict__ y, float *__restrict__ pre, Geom g)
 {
-    const int C4 = g.C >> 2;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float4 tile[HY * HX * (CCH / 4)];
+    const int tiles_x = (g.W + TX - 1) / TX;
+    const int y0 = (blockIdx.x / tiles_x) * TY, x0 = (blockIdx.x % tiles_x) * TX;
+    const int c0 = blockIdx.y * CCH, b = blockIdx.z;
     const int N = g.H * g.W;
-    if (idx >= (size_t)N * C4) return;
-    const int t = (int)(idx / C4), c = (int)(idx - (size_t)t * C4) * 4;
-    const int b = blockIdx.y;
-    const int yy0 = t / g.W, xx0 = t - yy0 * g.W;
-    float4 acc = bias ? *reinterpret_cast<const float4 *>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int c4 = threadIdx.x & 7, c = c0 + 4 * c4;
+    const bool cok = c < g.C;
+    // halo: 180 tokens x 8 float4
+    for (int i = threadIdx.x; i < HY * HX * 8; i += 256) {
+        const int hl = i >> 3, hy = hl / HX, hx = hl - hy * HX;
+        const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cok && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W)
+            v = *reinterpret_cast<const float4 *>(x + ((size_t)b * N + (size_t)yy * g.W + xx) * g.x_stride + c);
+        tile[hl * 8 + c4] = v;
+    }
     float wr[4][9];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int j = 0; j < 9; ++j) wr[e][j] = w[(c + e) * 9 + j];
+        for (int j = 0; j < 9; ++j) wr[e][j] = cok ? w[(c + e) * 9 + (FLIP ? 8 - j : j)] : 0.f;
+    const float4 bv = (!FLIP && bias && cok) ? *reinterpret_cast<const float4 *>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        const int yy = yy0 + j / 3 - 1, xx = xx0 + j % 3 - 1;
-        if (yy < 0 || yy >= g.H || xx < 0 || xx >= g.W) continue;
-        const float4 v = *reinterpret_cast<const float4 *>(x + ((size_t)b * N + (size_t)yy * g.W + xx) * g.x_stride + c);
-        acc.x += wr[0][j] * v.x; acc.y += wr[1][j] * v.y; acc.z += wr[2][j] * v.z; acc.w += wr[3][j] * v.w;
-    }
-    const size_t o = ((size_t)b * N + t) * g.y_stride + c;
-    if (SILU) {
-        if (pre) *reinterpret_cast<float4 *>(pre + ((size_t)b * N + t) * g.C + c) = acc;
-        acc = make_float4(silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w));
-    }
-    *reinterpret_cast<float4 *>(y + o) = acc;
-}
-
-// dx[t] = sum_j w[8 - j] * g[t + off_j],  g = dy (* silu'(pre) when fused)
-template <bool SILU>
-__global__ void __launch_bounds__(256)
-dwconv_bwd_data_kernel(const float *__restrict__ dy, int dy_stride, const float *__restrict__ pre,
-                       const float *__restrict__ w, float *__restrict__ dx, int dx_stride, Geom g)
-{
-    const int C4 = g.C >> 2;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int N = g.H * g.W;
-    if (idx >= (size_t)N * C4) return;
-    const int t = (int)(idx / C4), c = (int)(idx - (size_t)t * C4) * 4;
-    const int b = blockIdx.y;
-    const int yy0 = t / g.W, xx0 = t - yy0 * g.W;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int it = 0; it < (TY * TX * 8) / 256; ++it) {
+        const int tl = (threadIdx.x >> 3) + 32 * it, ty = tl / TX, tx = tl - ty * TX;
+        const int yy = y0 + ty, xx = x0 + tx;
+        if (!cok || yy >= g.H || xx >= g.W) continue;
+        float4 acc = bv;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        const int yy = yy0 + j / 3 - 1, xx = xx0 + j % 3 - 1;
-        if (yy < 0 || yy >= g.H || xx < 0 || xx >= g.W) continue;
-        const size_t ti = (size_t)b * N + (size_t)yy * g.W + xx;
-        float4 gv = *reinterpret_cast<const float4 *>(dy + ti * dy_stride + c);
-        if (SILU) {
-            const float4 p = *reinterpret_cast<const float4 *>(pre + ti * g.C + c);
-            gv.x *= dsilu_f(p.x); gv.y *= dsilu_f(p.y); gv.z *= dsilu_f(p.z); gv.w *= dsilu_f(p.w);
+        for (int j = 0; j < 9; ++j) {
+            const float4 v = tile[((ty + j / 3) * HX + tx + j % 3) * 8 + c4];
+            acc.x += wr[0][j] * v.x; acc.y += wr[1][j] * v.y; acc.z += wr[2][j] * v.z; acc.w += wr[3][j] * v.w;
         }
-        const int jw = 8 - j;
-        acc.x += w[(c + 0) * 9 + jw] * gv.x; acc.y += w[(c + 1) * 9 + jw] * gv.y;
-        acc.z += w[(c + 2) * 9 + jw] * gv.z; acc.w += w[(c + 3) * 9 + jw] * gv.w;
+        const size_t t = (size_t)b * N + (size_t)yy * g.W + xx;
+        if (SILU) {
+            if (pre) *reinterpret_cast<float4 *>(pre + t * g.C + c) = acc;
+            acc = make_float4(silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w));
+        }
+        *reinterpret_cast<float4 *>(y + t * g.y_stride + c) = acc;
     }
-    *reinterpret_cast<float4 *>(dx + ((size_t)b * N + t) * dx_stride + c) = acc;
 }
 
 // dw[c][j] = sum_{b,t} g[t] x[t + off_j], dbias[c] = sum g[t].  Workgroup = (batch b, image row y,
@@ -237,13 +228,15 @@ extern "C" int mlagg_dwconv3x3_fwd(const float *x, int x_stride, const float *w,
     if (!x || !w || !y) return MLAGG_E_NULLPTR;
     Geom g;
     if (int rc = make_geom(g, batch, H, W, C, x_stride, y_stride)) return rc;
-    const size_t total = (size_t)H * W * (C / 4);
-    const dim3 grid((unsigned)((total + 255) / 256), batch), block(256);
+    const dim3 grid(((W + TX - 1) / TX) * ((H + TY - 1) / TY), (C + CCH - 1) / CCH, batch), block(256);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (silu)
-        { MLAGG_TIMED(K_DWCONV_FWD, st); hipLaunchKernelGGL(dwconv_fwd_kernel<true>, grid, block, 0, st, x, w, bias, y, pre, g); }
-    else
-        { MLAGG_TIMED(K_DWCONV_FWD, st); hipLaunchKernelGGL(dwconv_fwd_kernel<false>, grid, block, 0, st, x, w, bias, y, pre, g); }
+    {
+        MLAGG_TIMED(K_DWCONV_FWD, st);
+        if (silu)
+            hipLaunchKernelGGL((dwconv_tiled_kernel<true, false>), grid, block, 0, st, x, w, bias, y, pre, g);
+        else
+            hipLaunchKernelGGL((dwconv_tiled_kernel<false, false>), grid, block, 0, st, x, w, bias, y, pre, g);
+    }
     return (int)hipGetLastError();
 }
 
@@ -255,8 +248,7 @@ extern "C" int mlagg_dwconv3x3_bwd(const float *x, int x_stride, const float *w,
     Geom g;
     if (int rc = make_geom(g, batch, H, W, C, x_stride, dx_stride)) return rc;
     if (dy_stride < C || (dy_stride & 3)) return MLAGG_E_UNSUPPORTED;
-    const size_t total = (size_t)H * W * (C / 4);
-    const dim3 grid((unsigned)((total + 255) / 256), batch), block(256);
+    const dim3 grid(((W + TX - 1) / TX) * ((H + TY - 1) / TY), (C + CCH - 1) / CCH, batch), block(256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     // weight gradient first: with SiLU it also emits g = dy * silu'(pre) once per element, so the data
     // gradient below is a plain 9-tap gather of g instead of 9 x (load dy, load pre, evaluate silu')
@@ -265,8 +257,11 @@ extern "C" int mlagg_dwconv3x3_bwd(const float *x, int x_stride, const float *w,
                                         gbuf);
     {
         MLAGG_TIMED(K_DWCONV_BWD_DATA, st);
-        hipLaunchKernelGGL(dwconv_bwd_data_kernel<false>, grid, block, 0, st, silu ? gbuf : dy, silu ? C : dy_stride,
-                           nullptr, w, dx, dx_stride, g);
+        Geom gd = g;                       // source = g (or dy when no SiLU), destination = dx
+        gd.x_stride = silu ? C : dy_stride;
+        gd.y_stride = dx_stride;
+        hipLaunchKernelGGL((dwconv_tiled_kernel<false, true>), grid, block, 0, st, silu ? gbuf : dy, w, nullptr, dx, nullptr,
+                           gd);
     }
     return (int)hipGetLastError();
 }

@@ -25,11 +25,6 @@ import torch.nn.functional as F
 from . import ops
 
 LAMBDA_INIT = 0.8
-# MLAGG_CHANNELS_LAST=1: keep the convolutional parts in NHWC memory (torch.channels_last) so that the
-# NCHW <-> token-major transposes around the encoder stages and MIOpen's own NCHW->NHWC staging disappear.
-import os  # noqa: E402
-
-CHANNELS_LAST = os.environ.get("MLAGG_CHANNELS_LAST", "0") == "1"
 
 
 class DropPath(nn.Module):
@@ -206,13 +201,13 @@ class BasicLayer(nn.Module):
 
     def forward(self, x):
         B, C, h, w = x.shape
-        # (B, C, H, W) -> token-major (B, N, C).  For a channels_last tensor this is a free view (NHWC memory
-        # IS the token-major layout); for a plain NCHW tensor it is the one transpose copy of the stage.
+        # (B, C, H, W) -> token-major (B, N, C): the one transpose copy of the stage, and back at the end.
+        # (Keeping the convolutional parts in torch.channels_last, which would make both free views, was
+        # measured 2x slower end to end: MIOpen's fp32 NHWC kernels and the NHWC Group/InstanceNorms.)
         t = x.permute(0, 2, 3, 1).reshape(B, h * w, C)
         for blk in self.blocks:
             t = blk.forward_tokens(t)
-        y = t.view(B, h, w, C).permute(0, 3, 1, 2)              # NCHW-shaped view of NHWC memory
-        return y if CHANNELS_LAST else y.contiguous()
+        return t.view(B, h, w, C).permute(0, 3, 1, 2).contiguous()
 
 
 class Project(nn.Module):  # reference T:972-1001
@@ -522,8 +517,6 @@ class MLLA_Uper(nn.Module):  # reference T:1183-1407
             self.out_4 = OutBlock(8 * E, out_channels)
 
     def forward(self, x_in):
-        if CHANNELS_LAST:
-            x_in = x_in.contiguous(memory_format=torch.channels_last)
         hs = self.mlla(x_in)
         hs[1:] = self.mambaskip(hs[1:])
         ds = self.deep_supervision
