@@ -401,7 +401,7 @@ __device__ __forceinline__ void channel_reduce32(float (&v)[32])
 // dB/dC: butterfly over the wave's 16 channels, then ds_add_f32 into the workgroup's [t][n]
 // accumulators, stored once per sub-tile (plain stores when one workgroup covers the group).
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(128, 3)
 selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta, const float *__restrict__ A,
                    const float *__restrict__ Bm, const float *__restrict__ Cm, const float *__restrict__ Dv,
                    const float *__restrict__ dbias, const float *__restrict__ dout,
@@ -550,6 +550,7 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
                     v[k] = fast_exp2(dlk * A2[0]);
                     hh = v[k] * hh + dlk * f4get(uv, j) * f4get(bb, j);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_sched_barrier(0);     // keep the three phases of a state apart (register pressure)
             float qq = qc[0], dAi = dAacc[0];
@@ -577,6 +578,7 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
                     v[k] = gh * dlu;                                            // dB[k][n] term of this channel
                     v[ST + k] = gyk * hk;                                       // dC[k][n] term of this channel
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             qc[0] = qq;
             dAacc[0] = dAi;
