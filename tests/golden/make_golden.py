@@ -210,10 +210,43 @@ def golden_loss():
     print("loss", vals)
 
 
+def golden_sliding_window():
+    """Reference predict_sliding_window_return_logits (sliding_window_prediction.py:118-210) on its CPU branch, with
+    acvl_utils.pad_nd_image (third-party, absent) replaced by the oracle's restatement."""
+    from oracle import inference_oracle as IO
+
+    def pad_nd_image(image, new_shape, mode, kwargs, return_slicer, shape_must_be_divisible_by=None):
+        assert mode == "constant" and return_slicer
+        return IO.pad_nd_image(image, new_shape, kwargs.get("value", 0))
+
+    _mod("acvl_utils")
+    _mod("acvl_utils.cropping_and_padding")
+    _mod("acvl_utils.cropping_and_padding.padding", pad_nd_image=pad_nd_image)
+    S = importlib.import_module("nnunetv2.inference.sliding_window_prediction")
+    net, img, small = IO.sliding_window_case()
+    out = {}
+    for tag, image, mirror in (("mirror", img, (0, 1)), ("plain", img, None), ("padded", small, (1,))):
+        r = S.predict_sliding_window_return_logits(net, image, 3, (32, 32), mirror_axes=mirror, tile_step_size=0.5,
+                                                   use_gaussian=True, perform_everything_on_gpu=False,
+                                                   verbose=False, device=torch.device("cpu"))
+        out[tag] = r.float().numpy()
+    out["gaussian_32"] = S.compute_gaussian((32, 32)).astype(np.float32)
+    out["gaussian_256"] = S.compute_gaussian((256, 256)).astype(np.float32)[::16, ::16]
+    steps = [S.compute_steps_for_sliding_window(a, b, c) for a, b, c in
+             (((40, 50), (32, 32), 0.5), ((512, 640), (256, 256), 0.5), ((256, 256), (256, 256), 0.5), ((300, 257), (256, 256), 0.25))]
+    out["steps"] = np.asarray([v for s_ in steps for ax in s_ for v in ax + [-1]])
+    np.savez_compressed(os.path.join(HERE, "sliding_window.npz"), **out)
+    print("sliding window", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     T, M = import_reference()
+    if "--only-sliding-window" in sys.argv:
+        golden_sliding_window()
+        sys.exit(0)
+    golden_sliding_window()
     golden_loss()
     golden_msmm(M)
     for v in ("B", "A"):
