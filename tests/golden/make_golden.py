@@ -239,14 +239,39 @@ def golden_sliding_window():
     print("sliding window", {k: v.shape for k, v in out.items()})
 
 
+def golden_evaluation():
+    """get_tp_fp_fn_tn (training/loss/dice.py:120-178) driven as validation_step drives it (nnUNetTrainer.py:899-940),
+    and compute_dice_coefficient (evaluation/SurfaceDice.py:481-498) on the oracle's synthetic label volumes."""
+    from oracle import evaluation_oracle as EO
+    D = importlib.import_module("nnunetv2.training.loss.dice")
+    sys.path.insert(0, os.path.join(os.path.dirname(REF), "evaluation"))
+    SD = importlib.import_module("SurfaceDice")
+    g = torch.Generator().manual_seed(41)
+    logits = torch.randn(3, 6, 24, 20, generator=g)
+    target = torch.round(torch.rand(3, 1, 24, 20, generator=g) * 5)
+    seg = logits.argmax(1)[:, None]
+    onehot = torch.zeros(logits.shape, dtype=torch.float32)
+    onehot.scatter_(1, seg, 1)
+    tp, fp, fn, _ = D.get_tp_fp_fn_tn(onehot, target, axes=[0, 2, 3], mask=None)
+    gt, sg = EO.evaluation_case()
+    # both-empty labels: the reference returns np.NaN, an attribute NumPy 2 removed -- recorded as NaN here
+    dsc = [float(SD.compute_dice_coefficient(gt == i, sg == i)) if (gt == i).sum() + (sg == i).sum() else float("nan")
+           for i in range(1, 14)]
+    np.savez_compressed(os.path.join(HERE, "evaluation.npz"), seed=41, tp=tp[1:].numpy(), fp=fp[1:].numpy(),
+                        fn=fn[1:].numpy(), whole_volume_dsc=np.asarray(dsc))
+    print("evaluation", tp[1:].tolist(), dsc[:4])
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     T, M = import_reference()
     if "--only-sliding-window" in sys.argv:
         golden_sliding_window()
+        golden_evaluation()
         sys.exit(0)
     golden_sliding_window()
+    golden_evaluation()
     golden_loss()
     golden_msmm(M)
     for v in ("B", "A"):

@@ -95,3 +95,37 @@ def test_ddp_runs_with_unused_dummy_tensor_and_stays_in_sync():
     assert torch.equal(res[0][0], res[1][0])           # replicas identical after 3 steps
     assert res[0][1] and res[1][1]                     # dummy_tensor never received a gradient
     assert res[0][2] is False                          # attribute set on the module, not on the wrapper
+
+
+def _val_case(rank, world):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import mlagg_unet_amd  # noqa: F401
+    from mlagg_unet_amd import evaluation as EV
+    g = torch.Generator().manual_seed(19)
+    logits = torch.randn(4, 2, 5, 16, 16, generator=g)           # 4 validation iterations of 2 samples, split over ranks
+    target = torch.round(torch.rand(4, 2, 1, 16, 16, generator=g) * 4)
+    outs = []
+    for it in range(2 * rank, 2 * rank + 2):
+        tp, fp, fn = EV.hard_tp_fp_fn(logits[it], target[it])
+        outs.append({"loss": torch.tensor(float(it)), "tp_hard": tp, "fp_hard": fp, "fn_hard": fn})
+    mine = EV.validation_epoch_end(outs)
+    return mine["mean_fg_dice"], mine["dice_per_class_or_region"], mine["val_losses"]
+
+
+def test_validation_epoch_end_reduces_counts_over_ranks():
+    """reference on_validation_epoch_end (nnUNetTrainer.py:950-967) sums tp/fp/fn of all ranks and averages the loss."""
+    import mlagg_unet_amd  # noqa: F401
+    from mlagg_unet_amd import evaluation as EV
+    res = _run(_val_case)
+    g = torch.Generator().manual_seed(19)
+    logits = torch.randn(4, 2, 5, 16, 16, generator=g)
+    target = torch.round(torch.rand(4, 2, 1, 16, 16, generator=g) * 4)
+    outs = []
+    for it in range(4):
+        tp, fp, fn = EV.hard_tp_fp_fn(logits[it], target[it])
+        outs.append({"loss": torch.tensor(float(it)), "tp_hard": tp, "fp_hard": fp, "fn_hard": fn})
+    single = EV.validation_epoch_end(outs)
+    for mean, per_class, loss in res:
+        assert abs(mean - single["mean_fg_dice"]) < 1e-12 and abs(loss - 1.5) < 1e-12
+        assert per_class == single["dice_per_class_or_region"]

@@ -1,0 +1,91 @@
+"""DSC evaluation: oracle vs the reference's get_tp_fp_fn_tn / compute_dice_coefficient
+outputs (tests/golden/evaluation.npz); product (confusion-matrix form) vs the oracle, bit-exact (integer counts)."""
+import os
+
+import numpy as np
+import torch
+
+import mlagg_unet_amd  # noqa: F401
+from mlagg_unet_amd import evaluation as EV
+from oracle import evaluation_oracle as EO
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "evaluation.npz"))
+
+
+def _val_case():
+    g = torch.Generator().manual_seed(int(GOLD["seed"]))
+    logits = torch.randn(3, 6, 24, 20, generator=g)
+    target = torch.round(torch.rand(3, 1, 24, 20, generator=g) * 5)
+    return logits, target
+
+
+def test_hard_counts_match_reference_and_oracle():
+    logits, target = _val_case()
+    o = EO.hard_tp_fp_fn(logits, target)
+    p = EV.hard_tp_fp_fn(logits, target)
+    for got, ora, key in zip(p, o, ("tp", "fp", "fn")):
+        assert np.array_equal(ora, GOLD[key])
+        assert got.dtype == torch.int64 and np.array_equal(got.numpy().astype(np.float32), GOLD[key])
+
+
+def test_epoch_end_matches_oracle_including_absent_class():
+    logits, target = _val_case()
+    target[target == 4] = 3                                # class 4 never in the target ...
+    logits[:, 4] = -50.0                                   # ... and never predicted: 0/0 -> NaN, skipped by nanmean
+    outs_p, outs_o = [], []
+    for k in range(3):
+        lg, tg = logits.roll(k, 0) + 0.1 * k, target
+        tp, fp, fn = EV.hard_tp_fp_fn(lg, tg)
+        outs_p.append({"loss": torch.tensor(0.5 + k), "tp_hard": tp, "fp_hard": fp, "fn_hard": fn})
+        a, b, c = EO.hard_tp_fp_fn(lg, tg)
+        outs_o.append({"loss": 0.5 + k, "tp_hard": a, "fp_hard": b, "fn_hard": c})
+    got = EV.validation_epoch_end(outs_p)
+    mean, per_class, loss = EO.epoch_end(outs_o)
+    assert np.isnan(got["dice_per_class_or_region"][3]) and np.isnan(per_class[3])
+    assert np.allclose(got["dice_per_class_or_region"], per_class, rtol=1e-6, equal_nan=True)
+    assert abs(got["mean_fg_dice"] - mean) < 1e-7 and abs(got["val_losses"] - loss) < 1e-12    # oracle divides in fp32
+
+
+def test_dice_coefficient_and_case_dsc():
+    gt, seg = EO.evaluation_case()
+    ref = GOLD["whole_volume_dsc"]
+    for i in range(1, 14):
+        o = EO.compute_dice_coefficient(gt == i, seg == i)
+        p = EV.compute_dice_coefficient(torch.from_numpy(gt == i), torch.from_numpy(seg == i))
+        assert (np.isnan(o) and np.isnan(p) and np.isnan(ref[i - 1])) or (o == ref[i - 1] and p == ref[i - 1])
+    want = EO.abdomen_case_dsc(gt, seg)
+    got = EV.abdomen_case_dsc(gt, seg)
+    assert list(got.keys()) == list(EV.ABDOMEN_ORGANS)
+    assert np.array_equal(np.asarray(list(got.values()), dtype=float), np.asarray(want), equal_nan=True)
+    assert np.isnan(got["Aorta"])                                      # ground truth on one slice: empty half-open slab
+    assert got["LAG"] == 0 and got["Duodenum"] == 1                    # spurious organ / organ absent from both
+    assert got["IVC"] != round(float(ref[5]), 4)                       # slab rule differs from the whole volume
+    seg2 = seg.copy(); seg2[seg2 == 3] = 200                           # labels beyond the organ list are ignored
+    assert np.array_equal(np.asarray(list(EV.abdomen_case_dsc(gt, seg2).values()), dtype=float),
+                          np.asarray(EO.abdomen_case_dsc(gt, seg2)), equal_nan=True)
+    cols, mean = EV.abdomen_mean_dsc([got, EV.abdomen_case_dsc(gt, gt)])
+    assert cols["Liver"] == (got["Liver"] + 1) / 2 and 0 < mean <= 1
+
+
+def test_validation_step_on_tiny_network():
+    from mlagg_unet_amd import trainer as TR
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = torch.nn.Conv2d(1, 4, 3, padding=1)
+
+        def forward(self, x):
+            y = self.c(x)
+            return [y, y[:, :, ::2, ::2]]
+    torch.manual_seed(3)
+    net = Net()
+    data = torch.rand(2, 1, 16, 16)
+    target = [torch.round(torch.rand(2, 1, 16, 16) * 3), torch.round(torch.rand(2, 1, 8, 8) * 3)]
+    out = EV.validation_step(net, data, target)
+    with torch.no_grad():
+        o = net(data)
+    assert float(out["loss"]) == float(TR.deep_supervision_loss(o, target, batch_dice=True))
+    a, b, c = EO.hard_tp_fp_fn(o[0], target[0])
+    assert np.array_equal(out["tp_hard"].numpy(), a) and np.array_equal(out["fn_hard"].numpy(), c)
+    assert np.array_equal(out["fp_hard"].numpy(), b)
