@@ -188,8 +188,37 @@ class MLLABlock(nn.Module):
         B, C, h, w = x.shape
         if (h, w) != self.input_resolution:
             raise RuntimeError("input feature has wrong size")
-        y = self.forward_tokens(x.flatten(2).transpose(1, 2))
-        return y.transpose(1, 2).reshape(B, C, h, w)
+        return _TokensToMap.apply(self.forward_tokens(_MapToTokens.apply(x)), h, w)
+
+
+class _MapToTokens(torch.autograd.Function):
+    """(B, C, H, W) -> contiguous token-major (B, H*W, C); the gradient comes back as a contiguous NCHW map.
+    Both directions are REAL transposes: permute + reshape alone is a strided view, and every residual add,
+    LayerNorm and Linear of the stage (and their gradients) would then re-transpose it -- 62 us clones and
+    114 us adds per use at stage 0."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, C, h, w = x.shape
+        ctx.hw = (h, w)
+        return x.permute(0, 2, 3, 1).contiguous().view(B, h * w, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, C = g.shape
+        return g.transpose(1, 2).contiguous().view(B, C, *ctx.hw)
+
+
+class _TokensToMap(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, h, w):
+        B, N, C = t.shape
+        return t.view(B, h, w, C).permute(0, 3, 1, 2).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, h, w = g.shape
+        return g.permute(0, 2, 3, 1).contiguous().view(B, h * w, C), None, None
 
 
 class BasicLayer(nn.Module):
@@ -204,10 +233,10 @@ class BasicLayer(nn.Module):
         # (B, C, H, W) -> token-major (B, N, C): the one transpose copy of the stage, and back at the end.
         # (Keeping the convolutional parts in torch.channels_last, which would make both free views, was
         # measured 2x slower end to end: MIOpen's fp32 NHWC kernels and the NHWC Group/InstanceNorms.)
-        t = x.permute(0, 2, 3, 1).reshape(B, h * w, C)
+        t = _MapToTokens.apply(x)
         for blk in self.blocks:
             t = blk.forward_tokens(t)
-        return t.view(B, h, w, C).permute(0, 3, 1, 2).contiguous()
+        return _TokensToMap.apply(t, h, w)
 
 
 class Project(nn.Module):  # reference T:972-1001
@@ -467,13 +496,13 @@ class VSS_Conv_Block(nn.Module):  # reference M:669-753
         hd = self.hidden_dim
         # (B, L_cat, 48) token-major concatenation of the first 48 channels of every scale
         halves = [t.split([hd, t.shape[1] - hd], dim=1) for t in inputs]       # (mamba 48 | conv rest) per scale
-        m = torch.cat([mh.permute(0, 2, 3, 1).reshape(B, -1, hd) for mh, _ in halves], dim=1)
+        m = torch.cat([_MapToTokens.apply(mh) for mh, _ in halves], dim=1)
         m = self.drop_path.residual(m, self.self_attention(self.ln_1(m), HW, Ls))
         m = self.norm2(m)
         outs = []
         for i, (mi, (H, W)) in enumerate(zip(m.split(Ls, dim=1), HW)):
             mi = self.drop_path.residual(mi, self.mlps[i](mi, H, W))
-            mi = mi.reshape(B, H, W, hd).permute(0, 3, 1, 2)
+            mi = _TokensToMap.apply(mi.contiguous(), H, W)      # real transpose: keeps the gradient token-major
             outs.append(torch.cat([mi, self.conv_branches[i](halves[i][1])], dim=1))
         return outs
 
