@@ -194,6 +194,22 @@ int mlagg_gate_fwd(const float *a0, const float *a1, const float *act, int act_s
 int mlagg_gate_bwd(const float *dout, int dout_stride, const float *a0, const float *a1, const float *act,
                    int act_stride, float *da0, float *da1, float *dact, long rows, int h, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K8: small fused ops.
+ * diff_lambda: lam[0] = exp(<q1, k1>) - exp(<q2, k2>) + lambda_init over n-element vectors (the differential-attention
+ * lambda of nnUNetTrainer_MLAgg_2D_dt_MS.py:709-711 / 770-772); saved_exp[2] receives the two exponentials for the
+ * backward, which overwrites dq1, dk1, dq2, dk2 (n each) from dlam[0].
+ * scaled_residual: out = skip + branch * scale[b] for b in [0, batch), per_sample floats per sample (multiple of 4),
+ * everything contiguous -- the residual under timm DropPath (T:903, 907; MambaSkip.py:741, 745), scale = mask / keep.
+ * skip == NULL computes out = branch * scale[b] (the branch gradient).
+ * ------------------------------------------------------------------------------------------ */
+int mlagg_diff_lambda_fwd(const float *q1, const float *k1, const float *q2, const float *k2, float lambda_init, int n,
+                          float *lam, float *saved_exp, void *stream);
+int mlagg_diff_lambda_bwd(const float *dlam, const float *q1, const float *k1, const float *q2, const float *k2,
+                          const float *saved_exp, int n, float *dq1, float *dk1, float *dq2, float *dk2, void *stream);
+int mlagg_scaled_residual(const float *skip, const float *branch, const float *scale, float *out, int batch,
+                          long per_sample, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,9 @@ SIGNATURES = {
     "mlagg_dwconv3x3_nchw_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _S]),
     "mlagg_cross_scan": (_I, [_F, _I, _I, _F, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), _I, _I, _S]),
     "mlagg_cross_merge": (_I, [_F, _F, _I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), _I, _I, _S]),
+    "mlagg_diff_lambda_fwd": (_I, [_F, _F, _F, _F, ctypes.c_float, _I, _F, _F, _S]),
+    "mlagg_diff_lambda_bwd": (_I, [_F, _F, _F, _F, _F, _F, _I, _F, _F, _F, _F, _S]),
+    "mlagg_scaled_residual": (_I, [_F, _F, _F, _F, _I, ctypes.c_long, _S]),
     "mlagg_gate_fwd": (_I, [_F, _F, _F, _I, _F, ctypes.c_long, _I, _S]),
     "mlagg_gate_bwd": (_I, [_F, _I, _F, _F, _F, _I, _F, _F, _F, ctypes.c_long, _I, _S]),
     "mlagg_linear_fwd": (_I, [_F, _I, _F, _F, _F, _I, _I, _I, _I, _S]),

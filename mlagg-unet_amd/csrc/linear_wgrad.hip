@@ -197,8 +197,12 @@ extern "C" int mlagg_linear_wgrad(const float *dy, int dy_stride, const float *x
     WGeom g;
     if (int rc = make_geom(g, M, O, I, dy_stride, x_stride)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    (void)hipMemsetAsync(dW, 0, sizeof(float) * (size_t)O * I, st);
-    if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)O, st);
+    if (db == dW + (size_t)O * I) {                      // adjacent outputs: one fill
+        (void)hipMemsetAsync(dW, 0, sizeof(float) * ((size_t)O * I + O), st);
+    } else {
+        (void)hipMemsetAsync(dW, 0, sizeof(float) * (size_t)O * I, st);
+        if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)O, st);
+    }
     // tiles per wave: full 3x3 groups when a dimension exceeds 96, else exactly what the dimension needs
     const int to = g.ogroups > 1 ? TMAX : (O + 31) / 32;
     const int ti = g.igroups > 1 ? TMAX : (I + 31) / 32;

@@ -1,0 +1,117 @@
+// K8 -- the launch-count killers of the MLLA / MSMM blocks: tiny or purely streaming ops that the eager
+// reference spends 6-15 kernel launches on each.
+//
+//  * diff_lambda: lambda = exp(<lq1, lk1>) - exp(<lq2, lk2>) + lambda_init of the differential attention
+//    (reference nnUNetTrainer_MLAgg_2D_dt_MS.py:709-711, 770-772): 2 mul + 2 sum + 2 exp + sub + add forward and
+//    ~14 kernels backward per attention module, 16 modules -> ~350 launches per train step, here 1 + 1.
+//  * scaled_residual: out = skip + branch * scale[sample] -- the residual connection under stochastic depth
+//    (timm DropPath, T:903, 907; MambaSkip.py:741, 745).  ATen's addcmul with a (B, 1, 1) operand runs its
+//    generic broadcast kernel (103 us for 3 x 63 MB at stage 0); this is a float4 stream.
+//    row_scale: out = x * scale[sample], the branch gradient of the same op.
+#include <hip/hip_runtime.h>
+
+#include "mlagg_hip.h"
+#include "prof.h"
+
+namespace {
+
+__global__ void __launch_bounds__(64)
+diff_lambda_fwd_kernel(const float *__restrict__ q1, const float *__restrict__ k1, const float *__restrict__ q2,
+                       const float *__restrict__ k2, float init, int n, float *__restrict__ lam, float *__restrict__ e)
+{
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        s1 += q1[i] * k1[i];
+        s2 += q2[i] * k2[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off, 64);
+        s2 += __shfl_xor(s2, off, 64);
+    }
+    if (threadIdx.x == 0) {
+        const float e1 = expf(s1), e2 = expf(s2);
+        lam[0] = e1 - e2 + init;
+        e[0] = e1;
+        e[1] = e2;
+    }
+}
+
+__global__ void __launch_bounds__(64)
+diff_lambda_bwd_kernel(const float *__restrict__ dlam, const float *__restrict__ q1, const float *__restrict__ k1,
+                       const float *__restrict__ q2, const float *__restrict__ k2, const float *__restrict__ e, int n,
+                       float *__restrict__ dq1, float *__restrict__ dk1, float *__restrict__ dq2, float *__restrict__ dk2)
+{
+    const float g1 = dlam[0] * e[0], g2 = -dlam[0] * e[1];
+    for (int i = threadIdx.x; i < n; i += 64) {
+        dq1[i] = g1 * k1[i];
+        dk1[i] = g1 * q1[i];
+        dq2[i] = g2 * k2[i];
+        dk2[i] = g2 * q2[i];
+    }
+}
+
+// per4 = floats per sample / 4; RESIDUAL: out = skip + x * scale[b], else out = x * scale[b]
+template <bool RESIDUAL>
+__global__ void __launch_bounds__(256)
+row_scale_kernel(const float *__restrict__ skip, const float *__restrict__ x, const float *__restrict__ scale,
+                 float *__restrict__ out, long per4, long total4)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const float s = scale[i / per4];
+        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+        float4 o = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
+        if (RESIDUAL) {
+            const float4 k = reinterpret_cast<const float4 *>(skip)[i];
+            o.x += k.x; o.y += k.y; o.z += k.z; o.w += k.w;
+        }
+        reinterpret_cast<float4 *>(out)[i] = o;
+    }
+}
+
+int stream_grid(long total4)
+{
+    long blocks = (total4 + 255) / 256;
+    return (int)(blocks < 1 ? 1 : blocks > 8192 ? 8192 : blocks);
+}
+
+}  // namespace
+
+extern "C" int mlagg_diff_lambda_fwd(const float *q1, const float *k1, const float *q2, const float *k2, float lambda_init,
+                                     int n, float *lam, float *saved_exp, void *stream)
+{
+    if (!q1 || !k1 || !q2 || !k2 || !lam || !saved_exp) return MLAGG_E_NULLPTR;
+    if (n <= 0) return MLAGG_E_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(diff_lambda_fwd_kernel, dim3(1), dim3(64), 0, st, q1, k1, q2, k2, lambda_init, n, lam, saved_exp);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mlagg_diff_lambda_bwd(const float *dlam, const float *q1, const float *k1, const float *q2, const float *k2,
+                                     const float *saved_exp, int n, float *dq1, float *dk1, float *dq2, float *dk2,
+                                     void *stream)
+{
+    if (!dlam || !q1 || !k1 || !q2 || !k2 || !saved_exp || !dq1 || !dk1 || !dq2 || !dk2) return MLAGG_E_NULLPTR;
+    if (n <= 0) return MLAGG_E_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(diff_lambda_bwd_kernel, dim3(1), dim3(64), 0, st, dlam, q1, k1, q2, k2, saved_exp, n, dq1, dk1, dq2,
+                       dk2);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mlagg_scaled_residual(const float *skip, const float *branch, const float *scale, float *out, int batch,
+                                     long per_sample, void *stream)
+{
+    if (!branch || !scale || !out) return MLAGG_E_NULLPTR;
+    if (batch <= 0 || per_sample <= 0 || (per_sample & 3)) return MLAGG_E_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long per4 = per_sample >> 2, total4 = per4 * batch;
+    MLAGG_TIMED(K_ROW_SCALE, st);
+    if (skip)
+        hipLaunchKernelGGL(row_scale_kernel<true>, dim3(stream_grid(total4)), dim3(256), 0, st, skip, branch, scale, out,
+                           per4, total4);
+    else
+        hipLaunchKernelGGL(row_scale_kernel<false>, dim3(stream_grid(total4)), dim3(256), 0, st, skip, branch, scale, out,
+                           per4, total4);
+    return (int)hipGetLastError();
+}

@@ -27,6 +27,41 @@ from . import ops
 LAMBDA_INIT = 0.8
 
 
+class _DropPathPool:
+    """All stochastic-depth masks of one forward pass from ONE bernoulli launch.  The reference draws a fresh
+    (B, 1, 1) mask per DropPath call (timm): 19 x (bernoulli_, div_) launches per step at config 2.  The first
+    training forward records the order of keep probabilities; later forwards draw an (n_calls, B) table up front
+    and hand out rows in that order."""
+
+    active = None
+
+    def __init__(self):
+        self.order, self.keep, self.masks, self.pos, self.recording = [], None, None, 0, False
+
+    def begin(self, batch, device):
+        if not self.order:
+            self.recording = True
+        else:
+            if self.keep is None or self.keep.device != device or self.keep.shape[1] != batch:
+                self.keep = torch.tensor(self.order, device=device, dtype=torch.float32)[:, None].expand(-1, batch).contiguous()
+            self.masks = torch.bernoulli(self.keep).div_(self.keep)
+            self.pos = 0
+        _DropPathPool.active = self
+
+    def end(self):
+        self.recording = False
+        _DropPathPool.active = None
+
+    def next(self, keep, batch):
+        if self.recording:
+            self.order.append(keep)
+            return None
+        if self.pos >= len(self.order) or self.order[self.pos] != keep or self.masks.shape[1] != batch:
+            raise RuntimeError("DropPath call order changed between forward passes")
+        self.pos += 1
+        return self.masks[self.pos - 1]
+
+
 class DropPath(nn.Module):
     """Per-sample stochastic depth (timm semantics; reference T:868, M:688)."""
 
@@ -35,21 +70,29 @@ class DropPath(nn.Module):
         self.drop_prob = float(p)
 
     def scale_mask(self, x):
-        """Per-sample keep mask already divided by the keep probability, or None when inactive."""
+        """Per-sample keep mask (B,) already divided by the keep probability, or None when inactive."""
         if self.drop_prob == 0.0 or not self.training:
             return None
         keep = 1.0 - self.drop_prob
-        mask = torch.empty((x.shape[0],) + (1,) * (x.dim() - 1), device=x.device, dtype=x.dtype).bernoulli_(keep)
-        return mask.div_(keep)
+        pool = _DropPathPool.active
+        if pool is not None:
+            row = pool.next(keep, x.shape[0])
+            if row is not None:
+                return row
+        return torch.empty(x.shape[0], device=x.device, dtype=x.dtype).bernoulli_(keep).div_(keep)
 
     def forward(self, x):
         m = self.scale_mask(x)
-        return x if m is None else x * m
+        return x if m is None else x * m.view((-1,) + (1,) * (x.dim() - 1))
 
     def residual(self, skip, branch):
-        """skip + drop_path(branch) as one fused multiply-add."""
+        """skip + drop_path(branch) in one pass (K8)."""
         m = self.scale_mask(branch)
-        return skip + branch if m is None else torch.addcmul(skip, branch, m)
+        if m is None:
+            return skip + branch
+        if branch.is_cuda and (branch.numel() // branch.shape[0]) % 4 == 0:
+            return ops.scaled_residual(skip, branch, m)
+        return torch.addcmul(skip, branch, m.view((-1,) + (1,) * (branch.dim() - 1)))
 
 
 class Linear(nn.Linear):
@@ -109,9 +152,7 @@ class AggregatedAttention(nn.Module):
         self.lepe = nn.Conv2d(dim, dim, 3, padding=1, groups=dim)
 
     def lambda_full(self):
-        l1 = torch.exp(torch.sum(self.lambda_q1 * self.lambda_k1))
-        l2 = torch.exp(torch.sum(self.lambda_q2 * self.lambda_k2))
-        return l1 - l2 + LAMBDA_INIT
+        return ops.diff_lambda(self.lambda_q1, self.lambda_k1, self.lambda_q2, self.lambda_k2, LAMBDA_INIT)
 
     def forward(self, x):
         """x: (B, N, dim) (may be a channel slice of a wider row) -> (B, N, dim)."""
@@ -539,6 +580,7 @@ class MLLA_Uper(nn.Module):  # reference T:1183-1407
         self.out_0 = OutBlock(E // 2, out_channels)
         # unused in forward (reference T:1362); excluded from DDP reduction, see trainer.wrap_ddp
         self.dummy_tensor = nn.Parameter(torch.tensor([1.0]))
+        self._dp_pool = _DropPathPool()
         if deep_supervision:
             self.out_1 = OutBlock(E, out_channels)
             self.out_2 = OutBlock(2 * E, out_channels)
@@ -546,6 +588,15 @@ class MLLA_Uper(nn.Module):  # reference T:1183-1407
             self.out_4 = OutBlock(8 * E, out_channels)
 
     def forward(self, x_in):
+        if not self.training:
+            return self._forward(x_in)
+        self._dp_pool.begin(x_in.shape[0], x_in.device)
+        try:
+            return self._forward(x_in)
+        finally:
+            self._dp_pool.end()
+
+    def _forward(self, x_in):
         hs = self.mlla(x_in)
         hs[1:] = self.mambaskip(hs[1:])
         ds = self.deep_supervision

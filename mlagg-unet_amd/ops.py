@@ -281,8 +281,10 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             x2, xs = _rows2d(x, "x")
             if big:
-                dW = torch.empty_like(weight)
-                db = torch.empty(O, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
+                # dW | db in one allocation: the kernel zero-fills both with a single memset
+                buf = torch.empty(O * I + (O if ctx.has_bias else 0), device=dy.device, dtype=torch.float32)
+                dW = buf[:O * I].view(O, I)
+                db = buf[O * I:] if ctx.has_bias else None
                 ws = torch.empty(lib.mlagg_linear_wgrad_workspace_floats(M, O, I), device=dy.device,
                                  dtype=torch.float32)
                 _lib.check(lib.mlagg_linear_wgrad(_ptr(dy2), dys, _ptr(x2), xs, _ptr(dW), _ptr(db), _ptr(ws), M, O, I,
@@ -532,3 +534,67 @@ class GateFn(torch.autograd.Function):
 
 def gate(a0, a1, act):
     return GateFn.apply(a0, a1, act)
+
+
+class DiffLambdaFn(torch.autograd.Function):
+    """K8: lambda = exp(<q1, k1>) - exp(<q2, k2>) + lambda_init of the differential attention, one launch each way."""
+
+    @staticmethod
+    def forward(ctx, q1, k1, q2, k2, lambda_init):
+        vs = [_require(v.contiguous(), "lambda vector") for v in (q1, k1, q2, k2)]
+        n = vs[0].numel()
+        if any(v.numel() != n for v in vs):
+            raise RuntimeError("diff_lambda: the four vectors differ in length")
+        out = torch.empty(3, device=q1.device, dtype=torch.float32)            # [lambda, exp1, exp2]
+        _lib.check(_lib.lib().mlagg_diff_lambda_fwd(*(_ptr(v) for v in vs), float(lambda_init), n, _ptr(out),
+                                                    out.data_ptr() + 4, _stream()), "mlagg_diff_lambda_fwd")
+        ctx.save_for_backward(*vs, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, dlam):
+        q1, k1, q2, k2, out = ctx.saved_tensors
+        n = q1.numel()
+        dlam = _require(dlam.reshape(1).contiguous(), "dlambda")
+        g = torch.empty(4, n, device=q1.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mlagg_diff_lambda_bwd(_ptr(dlam), _ptr(q1), _ptr(k1), _ptr(q2), _ptr(k2), out.data_ptr() + 4, n,
+                                                    _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _stream()),
+                   "mlagg_diff_lambda_bwd")
+        return g[0].view_as(q1), g[1].view_as(k1), g[2].view_as(q2), g[3].view_as(k2), None
+
+
+def diff_lambda(q1, k1, q2, k2, lambda_init):
+    return DiffLambdaFn.apply(q1, k1, q2, k2, lambda_init)
+
+
+class ScaledResidualFn(torch.autograd.Function):
+    """K8: skip + branch * scale[sample] (residual under stochastic depth), float4 streams both ways."""
+
+    @staticmethod
+    def forward(ctx, skip, branch, scale):
+        skip = _require(skip.contiguous(), "skip")
+        branch = _require(branch.contiguous(), "branch")
+        scale = _require(scale.reshape(-1).contiguous(), "scale")
+        B = scale.numel()
+        if skip.shape != branch.shape or skip.shape[0] != B:
+            raise RuntimeError("scaled_residual: shape mismatch")
+        per = skip.numel() // B
+        out = torch.empty_like(skip)
+        _lib.check(_lib.lib().mlagg_scaled_residual(_ptr(skip), _ptr(branch), _ptr(scale), _ptr(out), B, per, _stream()),
+                   "mlagg_scaled_residual")
+        ctx.save_for_backward(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (scale,) = ctx.saved_tensors
+        g = _require(g.contiguous(), "grad")
+        B = scale.numel()
+        db = torch.empty_like(g)
+        _lib.check(_lib.lib().mlagg_scaled_residual(None, _ptr(g), _ptr(scale), _ptr(db), B, g.numel() // B, _stream()),
+                   "mlagg_scaled_residual")
+        return g, db, None
+
+
+def scaled_residual(skip, branch, scale):
+    return ScaledResidualFn.apply(skip, branch, scale)

@@ -242,3 +242,59 @@ def test_dwconv3x3_nchw_matches_conv2d(C, H, W, stride):
     _close(xg.grad, xr.grad, 1e-5, 1e-4, "dx")
     _close(wg.grad, wr.grad, 1e-5, 1e-4, "dw")
     _close(bg.grad, br.grad, 1e-5, 1e-4, "db")
+
+
+@gpu
+def test_diff_lambda_matches_torch():
+    """K8: lambda = exp(<q1,k1>) - exp(<q2,k2>) + lambda_init (reference T:709-711), forward and gradients."""
+    from mlagg_unet_amd import ops
+    g = torch.Generator().manual_seed(12)
+    vs = [(torch.randn(24, generator=g) * 0.5).to(DEV).requires_grad_(True) for _ in range(4)]
+    ref = [v.detach().clone().requires_grad_(True) for v in vs]
+    lam = ops.diff_lambda(*vs, 0.8)
+    want = torch.exp(torch.sum(ref[0] * ref[1])) - torch.exp(torch.sum(ref[2] * ref[3])) + 0.8
+    assert abs(float(lam) - float(want)) < 1e-6
+    (lam * 1.7).backward()
+    (want * 1.7).backward()
+    for a, b in zip(vs, ref):
+        assert float((a.grad - b.grad).abs().max()) < 1e-6
+
+
+@gpu
+def test_scaled_residual_matches_addcmul():
+    from mlagg_unet_amd import ops
+    g = torch.Generator().manual_seed(13)
+    skip = torch.randn(5, 37, 48, generator=g).to(DEV).requires_grad_(True)
+    br = torch.randn(5, 37, 48, generator=g).to(DEV).requires_grad_(True)
+    scale = torch.tensor([0.0, 1.25, 1.25, 0.0, 1.25], device=DEV)
+    out = ops.scaled_residual(skip, br, scale)
+    want = torch.addcmul(skip.detach(), br.detach(), scale.view(5, 1, 1))
+    assert torch.equal(out, want) or float((out - want).abs().max()) < 1e-6
+    gy = torch.randn(5, 37, 48, generator=g).to(DEV)
+    out.backward(gy)
+    assert torch.equal(skip.grad, gy)
+    assert float((br.grad - gy * scale.view(5, 1, 1)).abs().max()) == 0.0
+
+
+@gpu
+def test_drop_path_pool_draws_all_masks_in_one_launch():
+    """Training-mode forward: the first pass records the DropPath call order, later passes take their masks from one
+    (n_calls, B) table; per-call keep probabilities follow the reference schedule (T:1096, 1235)."""
+    from mlagg_unet_amd import model as PM
+    torch.manual_seed(0)
+    m = PM.build_network_architecture((64, 64), 1, 3, True, "B").to(DEV).train()
+    x = torch.rand(4, 1, 64, 64, device=DEV)
+    m(x)
+    pool = m._dp_pool
+    # 8 encoder blocks x 2 residuals, the first block has rate 0 (no mask): 14 calls; MSMM block: 1 + 4 calls at 0.1
+    assert len(pool.order) == 19 and abs(pool.order[-1] - 0.9) < 1e-12
+    assert all(abs(a - b) < 1e-6 for a, b in zip(pool.order[:2], [1 - 0.1 / 7] * 2))
+    out1 = m(x)[0]
+    assert pool.masks.shape == (19, 4) and pool.pos == 19
+    vals = torch.unique(pool.masks[-1])
+    assert all(float(v) == 0.0 or abs(float(v) - 1 / 0.9) < 1e-6 for v in vals)
+    out2 = m(x)[0]
+    assert torch.isfinite(out1).all() and not torch.equal(out1, out2)          # fresh masks every pass
+    m.eval()
+    with torch.no_grad():
+        assert float((m(x)[0] - m(x)[0]).abs().max()) < 1e-4                   # no masks in eval
