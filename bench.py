@@ -118,13 +118,11 @@ def main():
             dist.init_process_group(backend)
 
     import mlagg_unet_amd  # noqa: F401
-    from mlagg_unet_amd import _lib, model, profiling, trainer
+    from mlagg_unet_amd import _lib, miopen_tuning, model, profiling, trainer
 
     _lib.lib()                                              # fail loudly if the HIP library is missing
-    # The reference sets cudnn.benchmark=True (run_training.py:123-125).  On ROCm that is MIOpen's exhaustive
-    # find mode, which compiles every candidate solver at first use (minutes on a fresh box with an empty
-    # user perf-db); the default immediate mode picks from the shipped kernel database instead.
-    torch.backends.cudnn.benchmark = os.environ.get("MLAGG_MIOPEN_FIND", "0") == "1"
+    # The reference sets cudnn.benchmark=True (run_training.py:123-125); here: the committed result of that search
+    miopen_db = miopen_tuning.use_tuned_convolutions()
     torch.manual_seed(0)
     net = model.build_network_architecture(IMG, 1, N_CLASSES, True, "B").to(dev).train()
     use_graph = args.graph and not ddp and not args.no_graph
@@ -217,7 +215,8 @@ def main():
                                    "14 classes, attention variant B (BASELINE.json configs[1])",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "final_loss": round(float(loss), 5),
-                       "launch": "hipGraph replay of the whole step" if use_graph else "eager"},
+                       "launch": "hipGraph replay of the whole step" if use_graph else "eager",
+                       "miopen": "tuned find-db (mlagg-unet_amd/miopen_db)" if miopen_db else "immediate mode"},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,37 @@
+"""Convolution solver selection for the MIOpen-backed layers of the path (stem, decoder, MSMM conv branches).
+
+The reference turns on ``cudnn.benchmark`` (run_training.py:123-125).  On ROCm that flag is MIOpen's exhaustive find:
+every candidate solver of every convolution is compiled and timed at first use -- about 20 minutes for the 114
+convolution problems of the 256x256 train step on a fresh box with an empty user database.  The result of that search
+(a find-db and a perf-db, ~100 KB of text, produced once with MLAGG_MIOPEN_FIND=1 as tools/miopen_find.sh shows) is
+kept next to this file; ``use_tuned_convolutions`` points MIOpen at a private copy of it and selects FAST find mode:
+problems in the database get their measured-best solver, anything else falls back to MIOpen's immediate-mode
+heuristic instead of a search.  Worth 2.6 % of the step at config 2 (55.9 -> 54.5 ms).
+"""
+import glob
+import os
+import shutil
+import tempfile
+
+import torch
+
+DB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_db")
+
+
+def use_tuned_convolutions():
+    """Call before the first convolution of the process.  Returns the database directory in use (None: exhaustive
+    find requested through MLAGG_MIOPEN_FIND=1, or tuning disabled through MLAGG_MIOPEN_TUNED=0)."""
+    if os.environ.get("MLAGG_MIOPEN_FIND", "0") == "1":
+        torch.backends.cudnn.benchmark = True              # full search; MIOPEN_USER_DB_PATH is the caller's business
+        return None
+    files = glob.glob(os.path.join(DB_DIR, "*.txt"))
+    if os.environ.get("MLAGG_MIOPEN_TUNED", "1") != "1" or not files:
+        torch.backends.cudnn.benchmark = False
+        return None
+    private = tempfile.mkdtemp(prefix="mlagg_miopen_db_")  # per process: MIOpen rewrites the files it opens
+    for f in files:
+        shutil.copy(f, private)
+    os.environ["MIOPEN_USER_DB_PATH"] = private
+    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")       # database hit -> tuned solver, miss -> heuristic, never a search
+    torch.backends.cudnn.benchmark = True
+    return private
