@@ -65,6 +65,22 @@ int mlagg_selscan_bwd(const float *u, const float *delta, const float *A, const 
                       float *ddelta_bias, float *workspace,
                       int batch, int dim, int L, int N, int G, int delta_softplus, void *stream);
 
+/* K1, low-rank delta form: the scan with SS2D_skip's dt projection folded in.  Replaces the pair
+ *   dts = einsum("b k r l, k d r -> b k d l", dts_r, dt_projs_weight)            (MambaSkip.py:430-436)
+ *   selective_scan_fn(xs, dts, As, Bs, Cs, Ds, delta_bias=..., delta_softplus=True)  (MambaSkip.py:445-451)
+ * dtr (batch, G, R, L): the rank-R rows of group g (scan order); Wdt (dim, R): row d = projection of channel d
+ * (dt_projs_weight viewed as (K*d_inner, R)); 1 <= R <= 4.  delta (batch, dim, L) never exists in memory.
+ * Backward overwrites du (batch, dim, L), ddtr (batch, G, R, L), dWdt (dim, R), dA, dB, dC and, when non-NULL,
+ * dD, ddelta_bias; chunk_state / workspace sizes as for mlagg_selscan_fwd / _bwd. */
+int mlagg_selscan_lowrank_fwd(const float *u, const float *dtr, const float *Wdt, int R, const float *A, const float *B,
+                              const float *C, const float *D, const float *delta_bias, float *out, float *chunk_state,
+                              int batch, int dim, int L, int N, int G, int delta_softplus, void *stream);
+int mlagg_selscan_lowrank_bwd(const float *u, const float *dtr, const float *Wdt, int R, const float *A, const float *B,
+                              const float *C, const float *D, const float *delta_bias, const float *dout,
+                              const float *chunk_state, float *du, float *ddtr, float *dWdt, float *dA, float *dB,
+                              float *dC, float *dD, float *ddelta_bias, float *workspace, int batch, int dim, int L,
+                              int N, int G, int delta_softplus, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * K3: 3x3-window differential attention + RMSNorm + LePE, the `local=True` branch of
  * AggregatedAttention.forward (mlagg/.../nnUNetTrainer_MLAgg_2D_dt_MS.py:693-717, 779-782).

@@ -29,6 +29,8 @@ SIGNATURES = {
     "mlagg_selscan_fwd": (_I, [_F] * 9 + [_I] * 6 + [_S]),
     "mlagg_selscan_bwd_workspace_floats": (_SZ, [_I, _I, _I, _I]),
     "mlagg_selscan_bwd": (_I, [_F] * 17 + [_I] * 6 + [_S]),
+    "mlagg_selscan_lowrank_fwd": (_I, [_F] * 3 + [_I] + [_F] * 7 + [_I] * 6 + [_S]),
+    "mlagg_selscan_lowrank_bwd": (_I, [_F] * 3 + [_I] + [_F] * 16 + [_I] * 6 + [_S]),
     "mlagg_local_attn_fwd": (_I, [_F, _I, _F, _I, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _FL, _S]),
     "mlagg_local_attn_bwd_workspace_floats": (_SZ, [_I, _I, _I, _I]),
     "mlagg_local_attn_bwd": (_I, [_F, _I, _F, _I, _F, _F, _F, _F, _I, _F, _I, _F, _I, _F, _F, _F, _F, _F,

@@ -36,7 +36,8 @@ constexpr int TC = 64;    // steps per chunk
 constexpr int NSUB = TC / ST;
 constexpr int UP = ST + 4;   // row pitch of the u / delta / dy tiles (floats): conflict-free b128 reads
 constexpr int BP = 20;       // pitch of the [t][n] B / C tiles
-constexpr int PP = 20;       // pitch of a per-chunk partial row: dA[16], dD, ddelta_bias, pad
+constexpr int PP = 24;       // pitch of a per-chunk partial row: dA[16], dD, ddelta_bias, dWdt[4], pad
+constexpr int RMAX = 4;      // largest supported rank of the low-rank delta projection
 constexpr float LOG2E = 1.4426950408889634f;
 // Channels per workgroup.  A group has 96 channels, but 32-channel workgroups (2 waves) measured fastest for
 // every pass: forward 0.49 -> 0.34 ms and 0.62 -> 0.43 ms, backward main 3.6 -> 2.55 ms at config 2.  Small
@@ -122,6 +123,32 @@ __device__ __forceinline__ float4 activate_delta(float4 raw, float bias, int sof
     return make_float4(r[0], r[1], r[2], r[3]);
 }
 
+
+// Low-rank delta (LR kernels): the fused form of SS2D_skip's `einsum("b k r l, k d r -> b k d l", dts, dt_projs_weight)`
+// (reference MambaSkip.py:430-436).  The R rank rows dtr (B, G, R, L) of the workgroup's group are fetched per
+// 16-step sub-tile by the first 4*R threads (one float4 each), parked in LDS as sR[r][t], and every lane forms
+// raw delta = sum_r Wdt[d][r] * dtr[r][t] for its channel and its 4 steps.  delta itself never exists in memory.
+__device__ __forceinline__ float4 load_rank_rows(const float *__restrict__ dtr_rows, int R, int tid, int t0, int L, bool vec)
+{
+    return tid < 4 * R ? load4(dtr_rows + (size_t)(tid >> 2) * L, t0 + 4 * (tid & 3), L, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ void stage_rank_rows(float *__restrict__ sR, int R, int tid, const float4 &v)
+{
+    if (tid < 4 * R) *reinterpret_cast<float4 *>(sR + (tid >> 2) * ST + 4 * (tid & 3)) = v;
+}
+__device__ __forceinline__ float4 lowrank_delta(const float *__restrict__ sR, int R, int s, const float (&w)[RMAX])
+{
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) {
+        if (i < R) {
+            const float4 rv = *reinterpret_cast<const float4 *>(sR + i * ST + 4 * s);
+            a.x += w[i] * rv.x; a.y += w[i] * rv.y; a.z += w[i] * rv.z; a.w += w[i] * rv.w;
+        }
+    }
+    return a;
+}
+
 __device__ __forceinline__ void rot4(float (&x)[4])
 {
     const float t = x[0];
@@ -152,8 +179,9 @@ __device__ __forceinline__ LaneId lane_id(const ScanGeom &gm)
 // forward pass 1 (FINAL = false): chunk from zero state -> (end state, sum delta')
 // forward pass 3 (FINAL = true) : chunk from its entry state -> y
 // ------------------------------------------------------------------------------------------
-template <bool FINAL>
-__global__ void selscan_fwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
+template <bool FINAL, bool LR>
+__global__ void __launch_bounds__(128) selscan_fwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
+                                   const float *__restrict__ Wdt, int R,
                                    const float *__restrict__ A, const float *__restrict__ Bm,
                                    const float *__restrict__ Cm, const float *__restrict__ Dv,
                                    const float *__restrict__ dbias, float *__restrict__ out,
@@ -165,12 +193,16 @@ __global__ void selscan_fwd_kernel(const float *__restrict__ u, const float *__r
     float *sd = su + gm.CB * UP;
     float *sB = sd + gm.CB * UP;
     float *sC = sB + ST * BP;
+    float *sR = sC + ST * BP;          // LR: two buffers of RMAX x ST rank rows
 
     const LaneId id = lane_id(gm);
     const int tid = threadIdx.x, L = gm.L;
     const bool vec = (L & 3) == 0;
     const float *urow = u + ((size_t)id.b * gm.dim + id.d) * L;
-    const float *drow = delta + ((size_t)id.b * gm.dim + id.d) * L;
+    const float *drow = LR ? delta + (((size_t)id.b * gm.G + id.g) * R) * L : delta + ((size_t)id.b * gm.dim + id.d) * L;
+    float wdt[RMAX] = {0.f, 0.f, 0.f, 0.f};
+    if (LR && id.act)
+        for (int i = 0; i < R; ++i) wdt[i] = Wdt[(size_t)id.d * R + i];
     const float *bcrow = nullptr;
     if (tid < 64)
         bcrow = Bm + (((size_t)id.b * gm.G + id.g) * NS + (tid >> 2)) * L;
@@ -196,14 +228,19 @@ __global__ void selscan_fwd_kernel(const float *__restrict__ u, const float *__r
     // Every load of the chunk is issued up front (4 sub-tiles x {u, delta, B|C} = 12 float4 per lane in
     // flight): the kernel is latency-bound on 64-byte row segments, so memory-level parallelism, not
     // LDS capacity, is what the chunk needs; LDS still only ever holds one 16-step sub-tile.
-    float4 pu[NSUB], pd[NSUB], pbc[NSUB];
+    float4 pu[NSUB], pd[NSUB], pbc[NSUB];         // pd: the lane's delta segment, or (LR) one rank-row segment
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
         const int t0 = tc0 + sub * ST;
         pu[sub] = pd[sub] = pbc[sub] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (id.act) { pu[sub] = load4(urow, t0 + 4 * id.s, L, vec); pd[sub] = load4(drow, t0 + 4 * id.s, L, vec); }
+        if (LR) pd[sub] = load_rank_rows(drow, R, tid, t0, L, vec);
+        if (id.act) {
+            pu[sub] = load4(urow, t0 + 4 * id.s, L, vec);
+            if (!LR) pd[sub] = load4(drow, t0 + 4 * id.s, L, vec);
+        }
         if (bcrow) pbc[sub] = load4(bcrow, t0 + 4 * (tid & 3), L, vec);
     }
+    if (LR) stage_rank_rows(sR, R, tid, pd[0]);       // rank rows run one sub-tile ahead of the barriers below
 
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
@@ -212,8 +249,10 @@ __global__ void selscan_fwd_kernel(const float *__restrict__ u, const float *__r
         if (id.act) {
             *reinterpret_cast<float4 *>(su + id.cl * UP + 4 * id.s) = pu[sub];
             *reinterpret_cast<float4 *>(sd + id.cl * UP + 4 * id.s) =
-                activate_delta(pd[sub], bias, softplus, t0 + 4 * id.s, L);
+                activate_delta(LR ? lowrank_delta(sR + (sub & 1) * RMAX * ST, R, id.s, wdt) : pd[sub], bias, softplus,
+                               t0 + 4 * id.s, L);
         }
+        if (LR && sub + 1 < NSUB) stage_rank_rows(sR + ((sub + 1) & 1) * RMAX * ST, R, tid, pd[sub + 1]);
         if (bcrow) {
             float *dst = (tid < 64 ? sB : sC) + (4 * (tid & 3)) * BP + ((tid & 63) >> 2);
             dst[0] = pbc[sub].x; dst[BP] = pbc[sub].y; dst[2 * BP] = pbc[sub].z; dst[3 * BP] = pbc[sub].w;
@@ -282,7 +321,9 @@ __global__ void selscan_chunk_prefix(const float *__restrict__ A, float *__restr
 // chunk end; the value at the chunk start is the affine offset of the chunk (slope is the same
 // exp(A * dsum_c) as forward).
 // ------------------------------------------------------------------------------------------
-__global__ void selscan_bwd_local_kernel(const float *__restrict__ delta, const float *__restrict__ A,
+template <bool LR>
+__global__ void __launch_bounds__(128) selscan_bwd_local_kernel(const float *__restrict__ delta, const float *__restrict__ Wdt, int R,
+                                         const float *__restrict__ A,
                                          const float *__restrict__ Cm, const float *__restrict__ dbias,
                                          const float *__restrict__ dout, float *__restrict__ cq, ScanGeom gm,
                                          int softplus)
@@ -291,12 +332,16 @@ __global__ void selscan_bwd_local_kernel(const float *__restrict__ delta, const 
     float *sg = reinterpret_cast<float *>(smem4);
     float *sd = sg + gm.CB * UP;
     float *sC = sd + gm.CB * UP;
+    float *sR = sC + ST * BP;          // LR: two buffers of RMAX x ST rank rows
 
     const LaneId id = lane_id(gm);
     const int tid = threadIdx.x, L = gm.L;
     const bool vec = (L & 3) == 0;
     const float *grow = dout + ((size_t)id.b * gm.dim + id.d) * L;
-    const float *drow = delta + ((size_t)id.b * gm.dim + id.d) * L;
+    const float *drow = LR ? delta + (((size_t)id.b * gm.G + id.g) * R) * L : delta + ((size_t)id.b * gm.dim + id.d) * L;
+    float wdt[RMAX] = {0.f, 0.f, 0.f, 0.f};
+    if (LR && id.act)
+        for (int i = 0; i < R; ++i) wdt[i] = Wdt[(size_t)id.d * R + i];
     const float *crow = tid < 64 ? Cm + (((size_t)id.b * gm.G + id.g) * NS + (tid >> 2)) * L : nullptr;
     const float bias = (dbias && id.act) ? dbias[id.d] : 0.f;
 
@@ -312,9 +357,14 @@ __global__ void selscan_bwd_local_kernel(const float *__restrict__ delta, const 
     for (int sub = 0; sub < NSUB; ++sub) {
         const int t0 = tc0 + sub * ST;
         pg[sub] = pd[sub] = pc[sub] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (id.act) { pg[sub] = load4(grow, t0 + 4 * id.s, L, vec); pd[sub] = load4(drow, t0 + 4 * id.s, L, vec); }
+        if (LR) pd[sub] = load_rank_rows(drow, R, tid, t0, L, vec);
+        if (id.act) {
+            pg[sub] = load4(grow, t0 + 4 * id.s, L, vec);
+            if (!LR) pd[sub] = load4(drow, t0 + 4 * id.s, L, vec);
+        }
         if (crow) pc[sub] = load4(crow, t0 + 4 * (tid & 3), L, vec);
     }
+    if (LR) stage_rank_rows(sR + ((NSUB - 1) & 1) * RMAX * ST, R, tid, pd[NSUB - 1]);
 #pragma unroll
     for (int sub = NSUB - 1; sub >= 0; --sub) {
         const int t0 = tc0 + sub * ST;
@@ -322,8 +372,10 @@ __global__ void selscan_bwd_local_kernel(const float *__restrict__ delta, const 
         if (id.act) {
             *reinterpret_cast<float4 *>(sg + id.cl * UP + 4 * id.s) = pg[sub];
             *reinterpret_cast<float4 *>(sd + id.cl * UP + 4 * id.s) =
-                activate_delta(pd[sub], bias, softplus, t0 + 4 * id.s, L);
+                activate_delta(LR ? lowrank_delta(sR + (sub & 1) * RMAX * ST, R, id.s, wdt) : pd[sub], bias, softplus,
+                               t0 + 4 * id.s, L);
         }
+        if (LR && sub > 0) stage_rank_rows(sR + ((sub - 1) & 1) * RMAX * ST, R, tid, pd[sub - 1]);
         if (crow) {
             float *dst = sC + (4 * (tid & 3)) * BP + (tid >> 2);
             dst[0] = pc[sub].x; dst[BP] = pc[sub].y; dst[2 * BP] = pc[sub].z; dst[3 * BP] = pc[sub].w;
@@ -394,6 +446,18 @@ __device__ __forceinline__ void channel_reduce32(float (&v)[32])
     for (int i = 0; i < 8; ++i) { v[i] += row_ror4(v[i]); v[i] += row_ror8(v[i]); }
 }
 
+// Same reduce-scatter for 16 values per lane: afterwards v[c & 3] of the lane with wave-channel c (lane bits 2..5)
+// is the sum over the wave's 16 channels of original value index c, for the lane's own state quad / step quad s.
+__device__ __forceinline__ void channel_reduce16(float (&v)[16])
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { swap32(v[i], v[i + 8]); v[i] += v[i + 8]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { swap16(v[i], v[i + 4]); v[i] += v[i + 4]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] += row_ror4(v[i]); v[i] += row_ror8(v[i]); }
+}
+
 // ------------------------------------------------------------------------------------------
 // backward pass 3: per chunk -- forward sweep to recover the states entering sub-tiles 1..3
 // (register checkpoints), then sub-tiles in reverse: per state, re-run 16 steps forward keeping
@@ -401,8 +465,10 @@ __device__ __forceinline__ void channel_reduce32(float (&v)[32])
 // dB/dC: butterfly over the wave's 16 channels, then ds_add_f32 into the workgroup's [t][n]
 // accumulators, stored once per sub-tile (plain stores when one workgroup covers the group).
 // ------------------------------------------------------------------------------------------
+template <bool LR>
 __global__ void __launch_bounds__(128, 3)
-selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta, const float *__restrict__ A,
+selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta, const float *__restrict__ Wdt, int R,
+                   const float *__restrict__ A,
                    const float *__restrict__ Bm, const float *__restrict__ Cm, const float *__restrict__ Dv,
                    const float *__restrict__ dbias, const float *__restrict__ dout,
                    const float *__restrict__ cstate, const float *__restrict__ cq, float *__restrict__ du,
@@ -417,12 +483,27 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
     float *sC = sB + ST * BP;
     float *aB = sC + ST * BP;      // [t][n] accumulators, pitch NS
     float *aC = aB + ST * NS;
+    float *aR = aC + ST * NS;      // LR: [r][t] accumulators of d(dtr), pitch ST (adjacent to aB / aC: zeroed together)
+    float *sR = aR + RMAX * ST;    // LR: the sub-tile's dtr rows [r][t]
+    float *sW = sR + RMAX * ST;    // LR: per-thread {Wdt[d][0..3], dWdt accumulators[0..3]} -- kept out of the register budget
 
     const LaneId id = lane_id(gm);
     const int tid = threadIdx.x, L = gm.L;
     const bool vec = (L & 3) == 0;
     const size_t rowoff = ((size_t)id.b * gm.dim + id.d) * L;
-    const float *urow = u + rowoff, *drow = delta + rowoff, *grow = dout + rowoff;
+    const float *urow = u + rowoff, *grow = dout + rowoff;
+    const float *drow = LR ? delta + (((size_t)id.b * gm.G + id.g) * R) * L : delta + rowoff;
+    if (LR) {
+        float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (id.act) {
+            w4.x = Wdt[(size_t)id.d * R];
+            if (R > 1) w4.y = Wdt[(size_t)id.d * R + 1];
+            if (R > 2) w4.z = Wdt[(size_t)id.d * R + 2];
+            if (R > 3) w4.w = Wdt[(size_t)id.d * R + 3];
+        }
+        *reinterpret_cast<float4 *>(sW + 8 * tid) = w4;                       // private slot: no barrier needed
+        *reinterpret_cast<float4 *>(sW + 8 * tid + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const float *bcrow = nullptr;
     if (tid < 64)
         bcrow = Bm + (((size_t)id.b * gm.G + id.g) * NS + (tid >> 2)) * L;
@@ -446,9 +527,13 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
     }
 
     // ---- phase F: forward sweep over sub-tiles 0 .. NSUB-2, checkpointing entry states ----
-    float4 pu, pd, pbc;
+    float4 pu, pd, pbc;                    // pd: the lane's delta segment, or (LR) one rank-row segment
     pu = pd = pbc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (id.act) { pu = load4(urow, tc0 + 4 * id.s, L, vec); pd = load4(drow, tc0 + 4 * id.s, L, vec); }
+    if (LR) pd = load_rank_rows(drow, R, tid, tc0, L, vec);
+    if (id.act) {
+        pu = load4(urow, tc0 + 4 * id.s, L, vec);
+        if (!LR) pd = load4(drow, tc0 + 4 * id.s, L, vec);
+    }
     if (tid < 64) pbc = load4(bcrow, tc0 + 4 * (tid & 3), L, vec);
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
@@ -457,10 +542,19 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
         if (sub == NSUB - 1) break;
         const int t0 = tc0 + sub * ST;
         __syncthreads();
+        if (LR) {                                   // rank rows first: the activation below reads them
+            stage_rank_rows(sR, R, tid, pd);
+            __syncthreads();
+        }
         if (id.act) {
             *reinterpret_cast<float4 *>(su + id.cl * UP + 4 * id.s) = pu;
-            *reinterpret_cast<float4 *>(sd + id.cl * UP + 4 * id.s) =
-                activate_delta(pd, bias, softplus, t0 + 4 * id.s, L);
+            float4 raw = pd;
+            if (LR) {
+                const float4 w4 = *reinterpret_cast<const float4 *>(sW + 8 * tid);
+                const float wv[RMAX] = {w4.x, w4.y, w4.z, w4.w};
+                raw = lowrank_delta(sR, R, id.s, wv);
+            }
+            *reinterpret_cast<float4 *>(sd + id.cl * UP + 4 * id.s) = activate_delta(raw, bias, softplus, t0 + 4 * id.s, L);
         }
         if (tid < 64) {
             float *dst = sB + (4 * (tid & 3)) * BP + (tid >> 2);
@@ -469,7 +563,11 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
         __syncthreads();
         if (sub + 2 < NSUB) {
             const int t = t0 + ST;
-            if (id.act) { pu = load4(urow, t + 4 * id.s, L, vec); pd = load4(drow, t + 4 * id.s, L, vec); }
+            if (LR) pd = load_rank_rows(drow, R, tid, t, L, vec);
+            if (id.act) {
+                pu = load4(urow, t + 4 * id.s, L, vec);
+                if (!LR) pd = load4(drow, t + 4 * id.s, L, vec);
+            }
             if (tid < 64) pbc = load4(bcrow, t + 4 * (tid & 3), L, vec);
         }
         if (id.act) {
@@ -506,22 +604,32 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
     for (int sub = NSUB - 1; sub >= 0; --sub) {
         const int t0 = tc0 + sub * ST;
         float4 ru = make_float4(0.f, 0.f, 0.f, 0.f), rd = ru, rg = ru, rbc = ru;
+        if (LR) rd = load_rank_rows(drow, R, tid, t0, L, vec);
         if (id.act) {
             ru = load4(urow, t0 + 4 * id.s, L, vec);
-            rd = load4(drow, t0 + 4 * id.s, L, vec);
+            if (!LR) rd = load4(drow, t0 + 4 * id.s, L, vec);
             rg = load4(grow, t0 + 4 * id.s, L, vec);
         }
         if (bcrow) rbc = load4(bcrow, t0 + 4 * (tid & 3), L, vec);
         __syncthreads();
+        if (LR) {                                   // rank rows first: the activation below (and the dWdt products
+            stage_rank_rows(sR, R, tid, rd);        // at the end of the sub-tile) read them
+            __syncthreads();
+        }
         if (id.act) {
             *reinterpret_cast<float4 *>(su + id.cl * UP + 4 * id.s) = ru;
-            *reinterpret_cast<float4 *>(sd + id.cl * UP + 4 * id.s) =
-                activate_delta(rd, bias, softplus, t0 + 4 * id.s, L);
+            float4 raw = rd;
+            if (LR) {
+                const float4 w4 = *reinterpret_cast<const float4 *>(sW + 8 * tid);
+                const float wv[RMAX] = {w4.x, w4.y, w4.z, w4.w};
+                raw = lowrank_delta(sR, R, id.s, wv);
+            }
+            *reinterpret_cast<float4 *>(sd + id.cl * UP + 4 * id.s) = activate_delta(raw, bias, softplus, t0 + 4 * id.s, L);
             *reinterpret_cast<float4 *>(sg + id.cl * UP + 4 * id.s) = rg;
         }
         if (bcrow)      // phase R keeps B / C as [n][t] rows (pitch BP): a state's 16 steps are 4 b128 reads
             *reinterpret_cast<float4 *>((tid < 64 ? sB : sC) + ((tid & 63) >> 2) * BP + 4 * (tid & 3)) = rbc;
-        for (int i = tid; i < 2 * ST * NS; i += blockDim.x) aB[i] = 0.f;   // aB and aC are adjacent
+        for (int i = tid; i < 2 * ST * NS + (LR ? RMAX * ST : 0); i += blockDim.x) aB[i] = 0.f;   // aB, aC, aR are adjacent
         __syncthreads();
 
         float ddl[ST], duu[ST];
@@ -626,8 +734,34 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
                     dbacc += odd[j];
                     dDacc += gyj * uj;
                 }
-                store4(ddelta + rowoff, t0 + 4 * id.s, L, vec, make_float4(odd[0], odd[1], odd[2], odd[3]));
+                if (!LR) store4(ddelta + rowoff, t0 + 4 * id.s, L, vec, make_float4(odd[0], odd[1], odd[2], odd[3]));
                 store4(du + rowoff, t0 + 4 * id.s, L, vec, make_float4(odu[0], odu[1], odu[2], odu[3]));
+            }
+            if (LR) {
+                __builtin_amdgcn_sched_barrier(0);
+                // d(raw delta) of (channel, steps 4s..4s+3) is in odd[] (zero in padding lanes).
+                //   dWdt[d][r]  += sum_t odd * dtr[r][t]          -> per-lane accumulators, reduced with dA
+                //   d(dtr)[r][t] = sum_d odd * Wdt[d][r]          -> sum over the wave's 16 channels, then LDS / global adds
+                float pv[16];
+                const float4 w4 = *reinterpret_cast<const float4 *>(sW + 8 * tid);
+                float4 dw = *reinterpret_cast<const float4 *>(sW + 8 * tid + 4);
+                const float wv[RMAX] = {w4.x, w4.y, w4.z, w4.w};
+                float dwv[RMAX] = {dw.x, dw.y, dw.z, dw.w};
+#pragma unroll
+                for (int i = 0; i < RMAX; ++i) {
+                    if (i < R) {
+                        const float4 rv = *reinterpret_cast<const float4 *>(sR + i * ST + 4 * id.s);
+                        dwv[i] += odd[0] * rv.x + odd[1] * rv.y + odd[2] * rv.z + odd[3] * rv.w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pv[4 * i + j] = odd[j] * wv[i];
+                }
+                *reinterpret_cast<float4 *>(sW + 8 * tid + 4) = make_float4(dwv[0], dwv[1], dwv[2], dwv[3]);
+                channel_reduce16(pv);
+                const int c = id.cl & 15, j = c & 3;                 // this lane owns value index c = 4 * r + step
+                const float val = j == 0 ? pv[0] : (j == 1 ? pv[1] : (j == 2 ? pv[2] : pv[3]));
+                if ((c >> 2) < R) atomicAdd(aR + (c >> 2) * ST + 4 * id.s + j, val);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
@@ -643,6 +777,15 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
                 if (atomic_bc) atomicAdd(dst, val); else *dst = val;
             }
         }
+        if (LR) {
+            for (int i = tid; i < R * ST; i += blockDim.x) {
+                const int r = i / ST, k = i - r * ST;
+                if (t0 + k < L) {
+                    float *dst = ddelta + (((size_t)id.b * gm.G + id.g) * R + r) * L + t0 + k;   // ddelta = d(dtr) here
+                    if (atomic_bc) atomicAdd(dst, aR[i]); else *dst = aR[i];
+                }
+            }
+        }
     }
     // per-chunk partial sums of dA (16 per channel), dD, ddelta_bias -> selscan_reduce_partials
     {
@@ -650,30 +793,42 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
         if (id.act) {
             float *prow = part + srow * PP;
             *reinterpret_cast<float4 *>(prow + 4 * id.s) = make_float4(dAacc[0], dAacc[1], dAacc[2], dAacc[3]);
-            if (id.s == 0) { prow[NS] = dDs; prow[NS + 1] = dbs; }
+            float dWs[RMAX] = {0.f, 0.f, 0.f, 0.f};
+            if (LR) {
+                const float4 dw = *reinterpret_cast<const float4 *>(sW + 8 * tid + 4);
+                dWs[0] = quad_sum(dw.x); dWs[1] = quad_sum(dw.y); dWs[2] = quad_sum(dw.z); dWs[3] = quad_sum(dw.w);
+            }
+            if (id.s == 0) {
+                *reinterpret_cast<float4 *>(prow + NS) = make_float4(dDs, dbs, dWs[0], dWs[1]);
+                *reinterpret_cast<float4 *>(prow + NS + 4) = make_float4(dWs[2], dWs[3], 0.f, 0.f);
+            }
         }
     }
 }
 
-// part[b][chunk][d][PP] -> dA[d][16], dD[d], ddbias[d]; one workgroup of 256 per channel
+// part[b][chunk][d][PP] -> dA[d][16], dD[d], ddbias[d], dWdt[d][R]; one workgroup of 256 per channel
 __global__ void selscan_reduce_partials(const float *__restrict__ part, float *__restrict__ dA,
-                                        float *__restrict__ dD, float *__restrict__ ddbias, ScanGeom gm)
+                                        float *__restrict__ dD, float *__restrict__ ddbias, float *__restrict__ dWdt,
+                                        int R, ScanGeom gm)
 {
+    constexpr int NC = 22, NR = 11;                              // 11 row-lanes x 22 columns = 242 threads
     const int d = blockIdx.x;
-    const int j = threadIdx.x % 18, r0 = threadIdx.x / 18;      // 14 row-lanes x 18 columns = 252 threads
-    __shared__ float red[14][18];
+    const int j = threadIdx.x % NC, r0 = threadIdx.x / NC;
+    __shared__ float red[NR][NC];
     float acc = 0.f;
     const int rows = gm.batch * gm.nchunks;
-    if (r0 < 14)
-        for (int r = r0; r < rows; r += 14) acc += part[((size_t)r * gm.dim + d) * PP + j];
-    if (r0 < 14) red[r0][j] = acc;
+    if (r0 < NR)
+        for (int r = r0; r < rows; r += NR) acc += part[((size_t)r * gm.dim + d) * PP + j];
+    if (r0 < NR) red[r0][j] = acc;
     __syncthreads();
-    if (threadIdx.x < 18) {
+    if (threadIdx.x < NC) {
         float s = 0.f;
-        for (int r = 0; r < 14; ++r) s += red[r][threadIdx.x];
-        if (threadIdx.x < NS) dA[d * NS + threadIdx.x] = s;
-        else if (threadIdx.x == NS) { if (dD) dD[d] = s; }
-        else { if (ddbias) ddbias[d] = s; }
+        for (int r = 0; r < NR; ++r) s += red[r][threadIdx.x];
+        const int c = threadIdx.x;
+        if (c < NS) dA[d * NS + c] = s;
+        else if (c == NS) { if (dD) dD[d] = s; }
+        else if (c == NS + 1) { if (ddbias) ddbias[d] = s; }
+        else if (dWdt && c - NS - 2 < R) dWdt[(size_t)d * R + c - NS - 2] = s;
     }
 }
 
@@ -709,26 +864,80 @@ extern "C" size_t mlagg_selscan_bwd_workspace_floats(int batch, int dim, int L, 
     return (size_t)batch * nchunks * dim * (N + PP);
 }
 
-extern "C" int mlagg_selscan_fwd(const float *u, const float *delta, const float *A, const float *B,
-                                 const float *C, const float *D, const float *delta_bias, float *out,
-                                 float *chunk_state, int batch, int dim, int L, int N, int G,
-                                 int delta_softplus, void *stream)
+namespace {
+
+template <bool LR>
+int scan_forward(const float *u, const float *delta, const float *Wdt, int R, const float *A, const float *B,
+                 const float *C, const float *D, const float *delta_bias, float *out, float *chunk_state, int batch,
+                 int dim, int L, int N, int G, int delta_softplus, void *stream)
 {
-    if (!u || !delta || !A || !B || !C || !out || !chunk_state) return MLAGG_E_NULLPTR;
     ScanGeom gm;
     if (int rc = make_geom(gm, batch, dim, L, N, G, SCAN_CB)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     float *cstate = chunk_state;
     float *cdsum = chunk_state + (size_t)batch * gm.nchunks * dim * NS;
     const dim3 grid(gm.nchunks, G * gm.nblk, batch), block(block_threads(gm));
-    const size_t lds = (size_t)(2 * gm.CB * UP + 2 * ST * BP) * sizeof(float);
-    { MLAGG_TIMED(K_SELSCAN_FWD_LOCAL, st); hipLaunchKernelGGL(selscan_fwd_kernel<false>, grid, block, lds, st, u, delta, A, B, C, D, delta_bias, out,
-                       cstate, cdsum, gm, delta_softplus); }
+    const size_t lds = (size_t)(2 * gm.CB * UP + 2 * ST * BP + (LR ? 2 * RMAX * ST : 0)) * sizeof(float);
+    { MLAGG_TIMED(K_SELSCAN_FWD_LOCAL, st); hipLaunchKernelGGL((selscan_fwd_kernel<false, LR>), grid, block, lds, st, u, delta, Wdt, R, A, B, C, D,
+                       delta_bias, out, cstate, cdsum, gm, delta_softplus); }
     { MLAGG_TIMED(K_SELSCAN_PREFIX, st); hipLaunchKernelGGL(selscan_chunk_prefix, dim3((dim * NS + 255) / 256, batch), dim3(256), 0, st, A, cstate,
                        cdsum, gm, 0); }
-    { MLAGG_TIMED(K_SELSCAN_FWD_FINAL, st); hipLaunchKernelGGL(selscan_fwd_kernel<true>, grid, block, lds, st, u, delta, A, B, C, D, delta_bias, out,
-                       cstate, cdsum, gm, delta_softplus); }
+    { MLAGG_TIMED(K_SELSCAN_FWD_FINAL, st); hipLaunchKernelGGL((selscan_fwd_kernel<true, LR>), grid, block, lds, st, u, delta, Wdt, R, A, B, C, D,
+                       delta_bias, out, cstate, cdsum, gm, delta_softplus); }
     return (int)hipGetLastError();
+}
+
+// ddelta: (B, dim, L) gradient of delta, or -- LR -- (B, G, R, L) gradient of the rank-R rows
+template <bool LR>
+int scan_backward(const float *u, const float *delta, const float *Wdt, int R, const float *A, const float *B,
+                  const float *C, const float *D, const float *delta_bias, const float *dout, const float *chunk_state,
+                  float *du, float *ddelta, float *dWdt, float *dA, float *dB, float *dC, float *dD, float *ddelta_bias,
+                  float *workspace, int batch, int dim, int L, int N, int G, int delta_softplus, void *stream)
+{
+    ScanGeom gm;
+    if (int rc = make_geom(gm, batch, dim, L, N, G, SCAN_CB)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float *cstate = chunk_state;
+    const float *cdsum = chunk_state + (size_t)batch * gm.nchunks * dim * NS;
+    float *cq = workspace;
+    float *part = workspace + (size_t)batch * gm.nchunks * dim * NS;
+    const dim3 grid(gm.nchunks, G * gm.nblk, batch), block(block_threads(gm));
+    // The main kernel runs at 3 waves per SIMD.  Workgroups of 32 channels (2 waves) let a CU hold independent
+    // workgroups instead of one 6-wave workgroup spread 2/2/1/1; the price is a 3-way float-atomic accumulation
+    // of dB / dC (and d(dtr)) across the workgroups of a group.
+    ScanGeom gb;
+    if (int rc = make_geom(gb, batch, dim, L, N, G, BWD_CB)) return rc;
+    const dim3 gridb(gb.nchunks, G * gb.nblk, batch), blockb(block_threads(gb));
+    const int atomic_bc = gb.nblk > 1;
+    if (atomic_bc) {
+        const size_t bytes = (size_t)batch * G * NS * L * sizeof(float);
+        (void)hipMemsetAsync(dB, 0, bytes, st);
+        (void)hipMemsetAsync(dC, 0, bytes, st);
+        if (LR) (void)hipMemsetAsync(ddelta, 0, (size_t)batch * G * R * L * sizeof(float), st);
+    }
+    const size_t lds1 = (size_t)(2 * gm.CB * UP + ST * BP + (LR ? 2 * RMAX * ST : 0)) * sizeof(float);
+    { MLAGG_TIMED(K_SELSCAN_BWD_LOCAL, st); hipLaunchKernelGGL(selscan_bwd_local_kernel<LR>, grid, block, lds1, st, delta, Wdt, R, A, C, delta_bias,
+                       dout, cq, gm, delta_softplus); }
+    { MLAGG_TIMED(K_SELSCAN_PREFIX, st); hipLaunchKernelGGL(selscan_chunk_prefix, dim3((dim * NS + 255) / 256, batch), dim3(256), 0, st, A, cq, cdsum,
+                       gm, 1); }
+    const size_t lds3 = (size_t)(3 * gb.CB * UP + 2 * ST * BP + 2 * ST * NS + (LR ? 2 * RMAX * ST + 8 * 128 : 0)) * sizeof(float);
+    { MLAGG_TIMED(K_SELSCAN_BWD, st); hipLaunchKernelGGL(selscan_bwd_kernel<LR>, gridb, blockb, lds3, st, u, delta, Wdt, R, A, B, C, D, delta_bias,
+                       dout, cstate, cq, du, ddelta, dB, dC, part, gb, delta_softplus, atomic_bc); }
+    { MLAGG_TIMED(K_SELSCAN_REDUCE, st); hipLaunchKernelGGL(selscan_reduce_partials, dim3(dim), dim3(256), 0, st, part, dA, dD, ddelta_bias,
+                       LR ? dWdt : nullptr, R, gm); }
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int mlagg_selscan_fwd(const float *u, const float *delta, const float *A, const float *B,
+                                 const float *C, const float *D, const float *delta_bias, float *out,
+                                 float *chunk_state, int batch, int dim, int L, int N, int G,
+                                 int delta_softplus, void *stream)
+{
+    if (!u || !delta || !A || !B || !C || !out || !chunk_state) return MLAGG_E_NULLPTR;
+    return scan_forward<false>(u, delta, nullptr, 0, A, B, C, D, delta_bias, out, chunk_state, batch, dim, L, N, G,
+                               delta_softplus, stream);
 }
 
 extern "C" int mlagg_selscan_bwd(const float *u, const float *delta, const float *A, const float *B,
@@ -740,34 +949,32 @@ extern "C" int mlagg_selscan_bwd(const float *u, const float *delta, const float
     if (!u || !delta || !A || !B || !C || !dout || !chunk_state || !du || !ddelta || !dA || !dB || !dC ||
         !workspace)
         return MLAGG_E_NULLPTR;
-    ScanGeom gm;
-    if (int rc = make_geom(gm, batch, dim, L, N, G, SCAN_CB)) return rc;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const float *cstate = chunk_state;
-    const float *cdsum = chunk_state + (size_t)batch * gm.nchunks * dim * NS;
-    float *cq = workspace;
-    float *part = workspace + (size_t)batch * gm.nchunks * dim * NS;
-    const dim3 grid(gm.nchunks, G * gm.nblk, batch), block(block_threads(gm));
-    // The main kernel runs at 2 waves per SIMD (247 VGPRs).  Workgroups of 32 channels (2 waves) let a CU
-    // hold 4 independent workgroups = 8 waves, 2 per SIMD, instead of one 6-wave workgroup spread 2/2/1/1;
-    // the price is a 3-way float-atomic accumulation of dB/dC across the workgroups of a group.
-    ScanGeom gb;
-    if (int rc = make_geom(gb, batch, dim, L, N, G, BWD_CB)) return rc;
-    const dim3 gridb(gb.nchunks, G * gb.nblk, batch), blockb(block_threads(gb));
-    const int atomic_bc = gb.nblk > 1;
-    if (atomic_bc) {
-        const size_t bytes = (size_t)batch * G * NS * L * sizeof(float);
-        (void)hipMemsetAsync(dB, 0, bytes, st);
-        (void)hipMemsetAsync(dC, 0, bytes, st);
-    }
-    const size_t lds1 = (size_t)(2 * gm.CB * UP + ST * BP) * sizeof(float);
-    { MLAGG_TIMED(K_SELSCAN_BWD_LOCAL, st); hipLaunchKernelGGL(selscan_bwd_local_kernel, grid, block, lds1, st, delta, A, C, delta_bias, dout, cq, gm,
-                       delta_softplus); }
-    { MLAGG_TIMED(K_SELSCAN_PREFIX, st); hipLaunchKernelGGL(selscan_chunk_prefix, dim3((dim * NS + 255) / 256, batch), dim3(256), 0, st, A, cq, cdsum,
-                       gm, 1); }
-    const size_t lds3 = (size_t)(3 * gb.CB * UP + 2 * ST * BP + 2 * ST * NS) * sizeof(float);
-    { MLAGG_TIMED(K_SELSCAN_BWD, st); hipLaunchKernelGGL(selscan_bwd_kernel, gridb, blockb, lds3, st, u, delta, A, B, C, D, delta_bias, dout, cstate,
-                       cq, du, ddelta, dB, dC, part, gb, delta_softplus, atomic_bc); }
-    { MLAGG_TIMED(K_SELSCAN_REDUCE, st); hipLaunchKernelGGL(selscan_reduce_partials, dim3(dim), dim3(256), 0, st, part, dA, dD, ddelta_bias, gm); }
-    return (int)hipGetLastError();
+    return scan_backward<false>(u, delta, nullptr, 0, A, B, C, D, delta_bias, dout, chunk_state, du, ddelta, nullptr, dA,
+                                dB, dC, dD, ddelta_bias, workspace, batch, dim, L, N, G, delta_softplus, stream);
+}
+
+extern "C" int mlagg_selscan_lowrank_fwd(const float *u, const float *dtr, const float *Wdt, int R, const float *A,
+                                         const float *B, const float *C, const float *D, const float *delta_bias,
+                                         float *out, float *chunk_state, int batch, int dim, int L, int N, int G,
+                                         int delta_softplus, void *stream)
+{
+    if (!u || !dtr || !Wdt || !A || !B || !C || !out || !chunk_state) return MLAGG_E_NULLPTR;
+    if (R < 1 || R > RMAX) return MLAGG_E_UNSUPPORTED;
+    return scan_forward<true>(u, dtr, Wdt, R, A, B, C, D, delta_bias, out, chunk_state, batch, dim, L, N, G,
+                              delta_softplus, stream);
+}
+
+extern "C" int mlagg_selscan_lowrank_bwd(const float *u, const float *dtr, const float *Wdt, int R, const float *A,
+                                         const float *B, const float *C, const float *D, const float *delta_bias,
+                                         const float *dout, const float *chunk_state, float *du, float *ddtr,
+                                         float *dWdt, float *dA, float *dB, float *dC, float *dD, float *ddelta_bias,
+                                         float *workspace, int batch, int dim, int L, int N, int G, int delta_softplus,
+                                         void *stream)
+{
+    if (!u || !dtr || !Wdt || !A || !B || !C || !dout || !chunk_state || !du || !ddtr || !dWdt || !dA || !dB || !dC ||
+        !workspace)
+        return MLAGG_E_NULLPTR;
+    if (R < 1 || R > RMAX) return MLAGG_E_UNSUPPORTED;
+    return scan_backward<true>(u, dtr, Wdt, R, A, B, C, D, delta_bias, dout, chunk_state, du, ddtr, dWdt, dA, dB, dC, dD,
+                               ddelta_bias, workspace, batch, dim, L, N, G, delta_softplus, stream);
 }

@@ -471,20 +471,20 @@ class SS2D_skip(nn.Module):
     def core(self, xc, HW):
         """xc: (B, L_cat, d_inner) token-major conv outputs of all scales -> (B, L_cat, d_inner): sum of the four
         re-ordered scan directions (reference M:405-473 and the 4-way sum at M:534).
-        The projections stay token-major GEMMs -- x_proj for all four directions is one 96 -> 140 Linear on
-        the natural token order, the rank-3 dt projection one block-diagonal 12 -> 384 Linear -- and K1'
-        (cross_scan / cross_merge) does every re-ordering; nothing is stacked, flipped or concatenated."""
+        x_proj for all four directions is one token-major 96 -> 140 Linear on the natural token order, K1'
+        (cross_scan / cross_merge) does every re-ordering, and the rank-3 dt projection lives inside K1;
+        nothing is stacked, flipped or concatenated."""
         B, Lc, dI = xc.shape
         K, R, N = 4, self.dt_rank, self.d_state
         per = R + 2 * N
         xdbl = ops.linear(xc, self.x_proj_weight.reshape(K * per, dI))                     # (B, L, 4*35)
-        dtr, Bs, Cs = ops.cross_scan_bc(xdbl, HW, R, N)               # (B, L, 12) | (B, 4, 16, L) | (B, 4, 16, L)
-        dts_tok = ops.linear(dtr, torch.block_diag(*self.dt_projs_weight.unbind(0)))        # (B, L, 4*96)
+        dtr, Bs, Cs = ops.cross_scan_bc(xdbl, HW, R, N)               # (B, 4, 3, L) | (B, 4, 16, L) | (B, 4, 16, L)
         xs = ops.cross_scan(xc, HW, dI, 1)                                                  # (B, 4*96, L)
-        dts = ops.cross_scan(dts_tok, HW, dI, 4)
-        out = ops.selective_scan_fn(xs, dts, -torch.exp(self.A_logs), Bs, Cs, self.Ds, z=None,
-                                    delta_bias=self.dt_projs_bias.reshape(-1), delta_softplus=True,
-                                    return_last_state=False)
+        # delta = softplus(dt_projs_weight . dtr + bias) is formed inside K1: the (B, 4*96, L) delta tensor of
+        # reference M:436 (334 MB at config 2) and its gradient never exist
+        out = ops.selective_scan_lowrank_fn(xs, dtr, self.dt_projs_weight.reshape(K * dI, R), -torch.exp(self.A_logs),
+                                            Bs, Cs, self.Ds, delta_bias=self.dt_projs_bias.reshape(-1),
+                                            delta_softplus=True)
         return ops.cross_merge(out, HW, dI)
 
     def forward(self, x, HW, L_split):

@@ -77,6 +77,57 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
     return SelectiveScanFn.apply(u, delta, A, B, C, D, delta_bias, delta_softplus)
 
 
+class SelectiveScanLowRankFn(torch.autograd.Function):
+    """K1 with the rank-R delta projection folded in: delta = softplus(Wdt[d] . dtr[b, g(d), :, l] + delta_bias[d]) is formed
+    inside the scan kernels, i.e. SS2D_skip's ``einsum("b k r l, k d r -> b k d l", dts, dt_projs_weight)`` +
+    ``selective_scan_fn(..., delta_bias, delta_softplus=True)`` (reference MambaSkip.py:430-451) as one op.  The
+    (B, 4*96, L) delta tensor and its gradient (334 MB each at config 2) are never materialised."""
+
+    @staticmethod
+    def forward(ctx, u, dtr, Wdt, A, B, C, D, delta_bias, delta_softplus):
+        b, d, L = u.shape
+        n, g, R = A.shape[1], B.shape[1], dtr.shape[2]
+        u = _require(u.contiguous(), "u")
+        dtr = _require(dtr.contiguous(), "dtr", (b, g, R, L))
+        Wdt = _require(Wdt.contiguous(), "Wdt", (d, R))
+        A = _require(A.contiguous(), "A", (d, n))
+        B = _require(B.contiguous(), "B", (b, g, n, L))
+        C = _require(C.contiguous(), "C", (b, g, n, L))
+        D = None if D is None else _require(D.contiguous(), "D", (d,))
+        delta_bias = None if delta_bias is None else _require(delta_bias.contiguous(), "delta_bias", (d,))
+        lib = _lib.lib()
+        out = torch.empty_like(u)
+        state = torch.empty(lib.mlagg_selscan_state_floats(b, d, L, n), device=u.device, dtype=torch.float32)
+        _lib.check(lib.mlagg_selscan_lowrank_fwd(_ptr(u), _ptr(dtr), _ptr(Wdt), R, _ptr(A), _ptr(B), _ptr(C), _ptr(D),
+                                                 _ptr(delta_bias), _ptr(out), _ptr(state), b, d, L, n, g,
+                                                 int(bool(delta_softplus)), _stream()), "mlagg_selscan_lowrank_fwd")
+        ctx.save_for_backward(u, dtr, Wdt, A, B, C, D, delta_bias, state)
+        ctx.delta_softplus = bool(delta_softplus)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        u, dtr, Wdt, A, B, C, D, delta_bias, state = ctx.saved_tensors
+        b, d, L = u.shape
+        n, g, R = A.shape[1], B.shape[1], dtr.shape[2]
+        dout = _require(dout.contiguous(), "dout", (b, d, L))
+        lib = _lib.lib()
+        du, ddtr, dW = torch.empty_like(u), torch.empty_like(dtr), torch.empty_like(Wdt)
+        dA, dB, dC = torch.empty_like(A), torch.empty_like(B), torch.empty_like(C)
+        dD = None if D is None else torch.empty_like(D)
+        dbias = None if delta_bias is None else torch.empty_like(delta_bias)
+        ws = torch.empty(lib.mlagg_selscan_bwd_workspace_floats(b, d, L, n), device=u.device, dtype=torch.float32)
+        _lib.check(lib.mlagg_selscan_lowrank_bwd(_ptr(u), _ptr(dtr), _ptr(Wdt), R, _ptr(A), _ptr(B), _ptr(C), _ptr(D),
+                                                 _ptr(delta_bias), _ptr(dout), _ptr(state), _ptr(du), _ptr(ddtr), _ptr(dW),
+                                                 _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD), _ptr(dbias), _ptr(ws), b, d, L, n, g,
+                                                 int(ctx.delta_softplus), _stream()), "mlagg_selscan_lowrank_bwd")
+        return du, ddtr, dW, dA, dB, dC, dD, dbias, None
+
+
+def selective_scan_lowrank_fn(u, dtr, Wdt, A, B, C, D=None, delta_bias=None, delta_softplus=False):
+    return SelectiveScanLowRankFn.apply(u, dtr, Wdt, A, B, C, D, delta_bias, delta_softplus)
+
+
 def _rows(t, name):
     """(B, N, C) view whose last dim is contiguous and whose batch/token dims collapse to one row
     stride (true for fresh Linear outputs and their channel slices); returns (tensor, row_stride)."""
@@ -448,9 +499,9 @@ class CrossMergeFn(torch.autograd.Function):
 
 class CrossScanBCFn(torch.autograd.Function):
     """The single consumer of the token-major x_proj output (B, L_cat, 4*35), split as at MambaSkip.py:433:
-    direction k's dt columns [35k, 35k+3) come back compacted as (B, L_cat, 12) for the dt projection, its
-    B columns [35k+3, 35k+19) and C columns [35k+19, 35k+35) as scan-order rows.  One backward assembles the
-    whole x_proj gradient (no per-slice zero-fills and accumulations)."""
+    direction k's dt columns [35k, 35k+3), B columns [35k+3, 35k+19) and C columns [35k+19, 35k+35) all come back as
+    scan-order rows -- (B, 4, 3, L_cat), (B, 4, 16, L_cat), (B, 4, 16, L_cat) -- for the low-rank selective scan.
+    One backward assembles the whole x_proj gradient (no per-slice zero-fills and accumulations)."""
 
     @staticmethod
     def forward(ctx, xdbl, HW, dt_rank, d_state):
@@ -464,9 +515,10 @@ class CrossScanBCFn(torch.autograd.Function):
         base = xdbl.data_ptr()
         _xscan(base + 4 * dt_rank, width, per, Bs, B, HW, d_state, 4, merge=False)
         _xscan(base + 4 * (dt_rank + d_state), width, per, Cs, B, HW, d_state, 4, merge=False)
+        dtr = torch.empty(B, 4 * dt_rank, Lc, device=xdbl.device, dtype=torch.float32)
+        _xscan(base, width, per, dtr, B, HW, dt_rank, 4, merge=False)
         ctx.meta = (tuple(HW), dt_rank, d_state, width)
-        dtr = xdbl.view(B, Lc, 4, per)[..., :dt_rank].reshape(B, Lc, 4 * dt_rank)
-        return dtr, Bs.view(B, 4, d_state, Lc), Cs.view(B, 4, d_state, Lc)
+        return dtr.view(B, 4, dt_rank, Lc), Bs.view(B, 4, d_state, Lc), Cs.view(B, 4, d_state, Lc)
 
     @staticmethod
     def backward(ctx, ddtr, dBs, dCs):
@@ -475,9 +527,10 @@ class CrossScanBCFn(torch.autograd.Function):
         dBs = _require(dBs.contiguous(), "dBs")
         dCs = _require(dCs.contiguous(), "dCs")
         B, Lc = dBs.shape[0], dBs.shape[-1]
+        ddtr = _require(ddtr.contiguous(), "ddtr")
         dx = torch.empty(B, Lc, width, device=dBs.device, dtype=torch.float32)
-        dx.view(B, Lc, 4, per)[..., :dt_rank] = ddtr.reshape(B, Lc, 4, dt_rank)
         base = dx.data_ptr()
+        _xscan(base, width, per, ddtr, B, HW, dt_rank, 4, merge=True)
         _xscan(base + 4 * dt_rank, width, per, dBs, B, HW, d_state, 4, merge=True)
         _xscan(base + 4 * (dt_rank + d_state), width, per, dCs, B, HW, d_state, 4, merge=True)
         return dx, None, None, None

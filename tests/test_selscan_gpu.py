@@ -83,3 +83,56 @@ def test_selscan_rejects_bad_arguments():
         selective_scan_fn(u, u, A, Bm, Bm, None, None, None, True)
     with pytest.raises(RuntimeError):               # CPU tensors: no fallback
         selective_scan_fn(u.cpu(), u.cpu(), torch.zeros(8, 16), torch.zeros(1, 1, 16, 16), torch.zeros(1, 1, 16, 16))
+
+
+LR_CASES = [
+    # (b, G, Hc, L, R)
+    (2, 4, 96, 5440, 3),       # BASELINE config 1 shape, the model's rank (dt_rank = ceil(48 / 16))
+    (1, 4, 96, 200, 3),        # ragged last chunk
+    (2, 2, 20, 130, 2),        # partial wave, L % 4 != 0, rank 2
+    (1, 1, 160, 77, 4),        # group wider than one workgroup (atomic dB / dC / d(dtr)), rank 4
+    (1, 3, 8, 1, 1),           # single step, rank 1
+]
+
+
+@gpu
+@pytest.mark.parametrize("b,G,Hc,L,R", LR_CASES)
+def test_selscan_lowrank_matches_oracle(b, G, Hc, L, R):
+    """K1 with the dt projection folded in == einsum("b k r l, k d r -> b k d l") + selective scan of the oracle
+    (reference MambaSkip.py:430-451), forward and every gradient (d(dtr) and dWdt by the chain rule from the oracle's
+    d(delta))."""
+    from mlagg_unet_amd.ops import selective_scan_lowrank_fn
+    u, _, A, B, C, D, bias, dout = _case(b, G, Hc, L, seed=5)
+    g = torch.Generator().manual_seed(50 + L)
+    d = G * Hc
+    dtr = torch.randn(b, G, R, L, generator=g)
+    Wdt = torch.randn(d, R, generator=g) * 0.4
+    delta = torch.einsum("bgrl,gdr->bgdl", dtr, Wdt.view(G, Hc, R)).reshape(b, d, L).contiguous()
+    dev = torch.device("cuda:0")
+    args = [t.to(dev).requires_grad_(True) if t is not None else None for t in (u, dtr, Wdt, A, B, C, D, bias)]
+    y = selective_scan_lowrank_fn(*args[:6], args[6], args[7], True)
+    y_ref = CO.selscan_fwd(_np(u), _np(delta), _np(A), _np(B), _np(C), _np(D), _np(bias), True)
+    scale = np.abs(y_ref).max()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref, atol=1e-4 * scale, rtol=1e-4)
+    y.backward(dout.to(dev))
+    du, ddelta, dA, dB, dC, dD, dbias = CO.selscan_bwd(_np(u), _np(delta), _np(A), _np(B), _np(C), _np(D), _np(bias),
+                                                       _np(dout), True)
+    dd = np.asarray(ddelta, dtype=np.float64).reshape(b, G, Hc, L)
+    ddtr = np.einsum("bgdl,gdr->bgrl", dd, Wdt.double().numpy().reshape(G, Hc, R))
+    dW = np.einsum("bgdl,bgrl->gdr", dd, dtr.double().numpy()).reshape(d, R)
+    for name, t, r in zip(("du", "ddtr", "dWdt", "dA", "dB", "dC", "dD", "dbias"), args,
+                          (du, ddtr, dW, dA, dB, dC, dD, dbias)):
+        got = t.grad.cpu().numpy()
+        s = max(np.abs(r).max(), 1e-6)
+        np.testing.assert_allclose(got, r, atol=3e-4 * s, rtol=1e-3, err_msg=name)
+
+
+@gpu
+def test_selscan_lowrank_rejects_rank_above_4():
+    from mlagg_unet_amd.ops import selective_scan_lowrank_fn
+    dev = torch.device("cuda:0")
+    u = torch.zeros(1, 8, 16, device=dev)
+    with pytest.raises(RuntimeError):
+        selective_scan_lowrank_fn(u, torch.zeros(1, 1, 5, 16, device=dev), torch.zeros(8, 5, device=dev),
+                                  -torch.ones(8, 16, device=dev), torch.zeros(1, 1, 16, 16, device=dev),
+                                  torch.zeros(1, 1, 16, 16, device=dev))
