@@ -35,6 +35,25 @@ def scan(B=10, L=21760):
     return step
 
 
+def scanlr(B=10, L=21760, R=3):
+    """K1 as the model runs it: rank-3 delta projection inside the scan (BASELINE config 2 MSMM shapes)."""
+    g = torch.Generator(device=DEV).manual_seed(0)
+    D, G, N = 384, 4, 16
+    u = torch.randn(B, D, L, device=DEV, generator=g).requires_grad_(True)
+    dtr = torch.randn(B, G, R, L, device=DEV, generator=g).requires_grad_(True)
+    Wdt = (torch.randn(D, R, device=DEV, generator=g) * 0.3).requires_grad_(True)
+    A = (-torch.exp(torch.randn(D, N, device=DEV, generator=g) * 0.3 + 1)).requires_grad_(True)
+    Bm = torch.randn(B, G, N, L, device=DEV, generator=g).requires_grad_(True)
+    Cm = torch.randn(B, G, N, L, device=DEV, generator=g).requires_grad_(True)
+    Dv = torch.randn(D, device=DEV, generator=g).requires_grad_(True)
+    bias = (torch.randn(D, device=DEV, generator=g) - 3).requires_grad_(True)
+    gy = torch.randn(B, D, L, device=DEV, generator=g)
+
+    def step():
+        ops.selective_scan_lowrank_fn(u, dtr, Wdt, A, Bm, Cm, Dv, bias, True).backward(gy)
+    return step
+
+
 def local(B=10, H=128, W=128, nh=1):
     g = torch.Generator(device=DEV).manual_seed(0)
     d = 48 * nh
@@ -92,7 +111,7 @@ def wgrad(M=163840, O=96, I=96):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["scan", "local", "pooled", "dwconv", "wgrad"])
+    ap.add_argument("what", choices=["scan", "scanlr", "local", "pooled", "dwconv", "wgrad"])
     ap.add_argument("--iters", type=int, default=10)
     a = ap.parse_args()
     fn = globals()[a.what]()

@@ -16,13 +16,18 @@ import re
 import sys
 
 
+# rocprof's template spellings of the low-rank scan kernels -> the library's profile names (bench.py looks these up)
+LIB_NAMES = {"selscan_fwd_kernel<false, true>": "selscan_fwd_kernel<false>", "selscan_fwd_kernel<true, true>": "selscan_fwd_kernel<true>",
+             "selscan_bwd_kernel<true>": "selscan_bwd_kernel", "selscan_bwd_local_kernel<true>": "selscan_bwd_local_kernel"}
+
+
 def load(d):
     out = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(d + "/*/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            m = re.search(r"([a-z_0-9]+_kernel(?:<(?:true|false|\d+, ?\d+)>)?|selscan_[a-z_]+)", r["Kernel_Name"])
+            m = re.search(r"([a-z_0-9]+_kernel(?:<(?:true|false|\d+)(?:, ?(?:true|false|\d+))?>)?|selscan_[a-z_]+)", r["Kernel_Name"])
             if m:
-                out[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                out[LIB_NAMES.get(m.group(1), m.group(1))][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return out
 
 
@@ -36,7 +41,7 @@ for k, v in sorted(res.items()):
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         fetch, write = 2 * v["FETCH_SIZE"] * 1024, v["WRITE_SIZE"] * 1024
         kern[k] = {"fetch_bytes_corrected": round(fetch), "write_bytes": round(write), "traffic_bytes": round(fetch + write)}
-json.dump({"workload": "tools/bench_ops.py scan: B=10, D=384, N=16, G=4, L=21760 (BASELINE config 2 MSMM scan)",
+json.dump({"workload": "tools/bench_ops.py scanlr: B=10, D=384, N=16, G=4, R=3, L=21760 (BASELINE config 2 MSMM scan, low-rank delta form)",
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, per-dispatch averages; "
                      "FETCH_SIZE x2 (gfx950 counts wide coalesced reads at half), both KiB -> bytes",
            "kernels": kern}, sys.stdout, indent=1)
