@@ -6,7 +6,7 @@ nnUNetTrainer_MLAgg_2D_dt_MS`` trains the MI355X network with unchanged plans, l
 nnunetv2 is not importable in the build container (its dependencies are absent offline), so the class
 is produced by a factory that receives the base class.
 """
-from . import model, trainer
+from . import evaluation, miopen_tuning, model, trainer
 
 
 def make_trainer_class(nnUNetTrainer, variant="B"):
@@ -22,6 +22,8 @@ def make_trainer_class(nnUNetTrainer, variant="B"):
             self.num_iterations_per_epoch = 250
             self.num_val_iterations_per_epoch = 50
             self.num_epochs = 500
+            # run_training.py:123-125 sets cudnn.benchmark (MIOpen's exhaustive find); here: the committed find-db
+            miopen_tuning.use_tuned_convolutions()
 
         @staticmethod
         def build_network_architecture(plans_manager, dataset_json, configuration_manager, num_input_channels,
@@ -39,6 +41,19 @@ def make_trainer_class(nnUNetTrainer, variant="B"):
 
         def configure_optimizers(self):                                             # reference T:137-147
             return trainer.configure_optimizers(self.network, self.initial_lr, self.weight_decay)
+
+        def validation_step(self, batch):                                           # reference B:880-942
+            data = batch["data"].to(self.device, non_blocking=True)
+            target = batch["target"]
+            target = [t.to(self.device, non_blocking=True) for t in target] if isinstance(target, list) else \
+                target.to(self.device, non_blocking=True)
+            return evaluation.validation_step(self.network, data, target, self.configuration_manager.batch_dice,
+                                              self.is_ddp)
+
+        def on_validation_epoch_end(self, val_outputs):                             # reference B:944-978
+            res = evaluation.validation_epoch_end(val_outputs)
+            for key in ("mean_fg_dice", "dice_per_class_or_region", "val_losses"):
+                self.logger.log(key, res[key], self.current_epoch)
 
         def plot_network_architecture(self):
             pass
