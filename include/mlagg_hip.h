@@ -226,6 +226,22 @@ int mlagg_diff_lambda_bwd(const float *dlam, const float *q1, const float *k1, c
 int mlagg_scaled_residual(const float *skip, const float *branch, const float *scale, float *out, int batch,
                           long per_sample, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K9: Dice + cross-entropy statistics and gradient of one deep-supervision level.  Replaces softmax, one-hot scatter,
+ * masked products, spatial sums, log_softmax + nll and all their backward kernels of DC_and_CE_loss
+ * (loss/compound_losses.py:31-57, loss/dice.py:73-117, loss/robust_ce_loss.py:12-16).
+ * logits (B, C, HW) fp32, 2 <= C <= mlagg_dice_ce_max_classes(); target (B, HW) float labels in [0, C).
+ * stats: ACCUMULATES (caller zero-fills) stats_ip[b][0][c] = sum_p softmax_c [y == c], stats_ip[b][1][c] = sum_p softmax_c,
+ * stats_g[b][c] = sum_p [y == c], ce_sum[0] = sum_{b,p} -log softmax_y.
+ * grad: dlogits = d(loss)/d(logits) for upstream gradients g_ip (B, 2, C) of stats_ip and g_ce[0] of ce_sum (device scalars:
+ * no host synchronisation).
+ * ------------------------------------------------------------------------------------------ */
+int mlagg_dice_ce_max_classes(void);
+int mlagg_dice_ce_stats(const float *logits, const float *target, float *stats_ip, float *stats_g, float *ce_sum, int B, int C,
+                        long HW, void *stream);
+int mlagg_dice_ce_grad(const float *logits, const float *target, const float *g_ip, const float *g_ce, float *dlogits, int B,
+                       int C, long HW, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -651,3 +651,58 @@ class ScaledResidualFn(torch.autograd.Function):
 
 def scaled_residual(skip, branch, scale):
     return ScaledResidualFn.apply(skip, branch, scale)
+
+
+class DiceCEStatsFn(torch.autograd.Function):
+    """K9: per-level Dice / cross-entropy statistics of ALL deep-supervision levels (one kernel per level each way).
+
+    ``DiceCEStatsFn.apply(n_levels, *logits, *targets)`` -> (ip (L, B, 2, C): intersect and sum_pred per sample and class,
+    gt (L, B, C): label counts, ce (L,): summed -log softmax of the label); gradients flow to the logits from ip and ce."""
+
+    @staticmethod
+    def forward(ctx, n, *tensors):
+        logits, targets = tensors[:n], tensors[n:]
+        B, C = logits[0].shape[:2]
+        dev = logits[0].device
+        lib = _lib.lib()
+        if C > lib.mlagg_dice_ce_max_classes():
+            raise RuntimeError(f"dice_ce_stats: at most {lib.mlagg_dice_ce_max_classes()} classes")
+        buf = torch.zeros(n * B * 3 * C + n, device=dev, dtype=torch.float32)       # ONE fill for all levels
+        ip = buf[:n * B * 2 * C].view(n, B, 2, C)
+        gt = buf[n * B * 2 * C:n * B * 3 * C].view(n, B, C)
+        ce = buf[n * B * 3 * C:]
+        saved = []
+        for i, (z, t) in enumerate(zip(logits, targets)):
+            z = _require(z.contiguous(), "logits")
+            t = _require(t.contiguous(), "target")
+            if z.shape[:2] != (B, C) or t.numel() * C != z.numel():
+                raise RuntimeError("dice_ce_stats: logits / target shapes of a level do not match")
+            hw = z.numel() // (B * C)
+            _lib.check(lib.mlagg_dice_ce_stats(_ptr(z), _ptr(t), _ptr(ip[i]), _ptr(gt[i]), ce.data_ptr() + 4 * i, B, C, hw,
+                                               _stream()), "mlagg_dice_ce_stats")
+            saved += [z, t]
+        ctx.save_for_backward(*saved)
+        ctx.n = n
+        ctx.mark_non_differentiable(gt)
+        return ip, gt, ce
+
+    @staticmethod
+    def backward(ctx, g_ip, g_gt, g_ce):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        B, C = saved[0].shape[:2]
+        lib = _lib.lib()
+        g_ip = torch.zeros(n, B, 2, C, device=saved[0].device) if g_ip is None else _require(g_ip.contiguous(), "g_ip")
+        g_ce = torch.zeros(n, device=saved[0].device) if g_ce is None else _require(g_ce.contiguous(), "g_ce")
+        grads = []
+        for i in range(n):
+            z, t = saved[2 * i], saved[2 * i + 1]
+            dz = torch.empty_like(z)
+            _lib.check(lib.mlagg_dice_ce_grad(_ptr(z), _ptr(t), _ptr(g_ip[i]), g_ce.data_ptr() + 4 * i, _ptr(dz), B, C,
+                                              z.numel() // (B * C), _stream()), "mlagg_dice_ce_grad")
+            grads.append(dz)
+        return (None, *grads, *([None] * n))
+
+
+def dice_ce_stats(logits, targets):
+    return DiceCEStatsFn.apply(len(logits), *logits, *targets)

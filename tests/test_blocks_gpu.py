@@ -298,3 +298,37 @@ def test_drop_path_pool_draws_all_masks_in_one_launch():
     m.eval()
     with torch.no_grad():
         assert float((m(x)[0] - m(x)[0]).abs().max()) < 1e-4                   # no masks in eval
+
+
+@gpu
+@pytest.mark.parametrize("ncls,size,batch_dice", [(14, 64, True), (14, 64, False), (4, 40, True), (2, 24, False)])
+def test_fused_dice_ce_loss_matches_eager(ncls, size, batch_dice):
+    """K9 + the vectorised level algebra == the level-by-level torch composition of DC_and_CE_loss (the form pinned to
+    the reference's loss classes by tests/golden/loss.npz on the CPU), value and gradient of every level."""
+    from mlagg_unet_amd import trainer as TR
+    g = torch.Generator().manual_seed(21)
+    outs = [(torch.randn(3, ncls, size >> s, (size >> s) + (3 if s == 0 else 0), generator=g) * 2).to(DEV) for s in range(5)]
+    tgts = [torch.round(torch.rand(3, 1, o.shape[2], o.shape[3], generator=g) * (ncls - 1)).to(DEV) for o in outs]
+    a = [o.clone().requires_grad_(True) for o in outs]
+    b = [o.clone().requires_grad_(True) for o in outs]
+    fused = TR.deep_supervision_loss(a, tgts, batch_dice=batch_dice)
+    eager = TR.deep_supervision_loss_eager(b, tgts, batch_dice=batch_dice)
+    assert abs(float(fused) - float(eager)) < 2e-6 * max(1.0, abs(float(eager)))
+    fused.backward()
+    eager.backward()
+    for x, y in zip(a, b):
+        assert float((x.grad - y.grad).abs().max()) < 1e-7 + 1e-5 * float(y.grad.abs().max())
+
+
+@gpu
+def test_fused_loss_extreme_logits_stay_finite():
+    from mlagg_unet_amd import trainer as TR
+    z = torch.zeros(1, 3, 8, 8, device=DEV)
+    z[:, 0] = 200.0                                    # label's logit 200 below the max: exp underflows, CE must not
+    t = torch.ones(1, 1, 8, 8, device=DEV)
+    zz = z.clone().requires_grad_(True)
+    loss = TR.deep_supervision_loss([zz], [t])
+    want = TR.deep_supervision_loss_eager([z], [t])
+    assert torch.isfinite(loss) and abs(float(loss) - float(want)) < 1e-3
+    loss.backward()
+    assert torch.isfinite(zz.grad).all()
