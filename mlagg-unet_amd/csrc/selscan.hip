@@ -486,6 +486,7 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
     float *aR = aC + ST * NS;      // LR: [r][t] accumulators of d(dtr), pitch ST (adjacent to aB / aC: zeroed together)
     float *sR = aR + RMAX * ST;    // LR: the sub-tile's dtr rows [r][t]
     float *sW = sR + RMAX * ST;    // LR: per-thread {Wdt[d][0..3], dWdt accumulators[0..3]} -- kept out of the register budget
+    float *sZ = sW + (LR ? 8 * 128 : 0);   // one all-zero row: what the padding lanes of a partial wave read as u / delta / dy
 
     const LaneId id = lane_id(gm);
     const int tid = threadIdx.x, L = gm.L;
@@ -526,6 +527,7 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
         h[0] = h0.x; h[1] = h0.y; h[2] = h0.z; h[3] = h0.w;
     }
 
+    if (tid < UP) sZ[tid] = 0.f;           // visible after the first barrier below
     // ---- phase F: forward sweep over sub-tiles 0 .. NSUB-2, checkpointing entry states ----
     float4 pu, pd, pbc;                    // pd: the lane's delta segment, or (LR) one rank-row segment
     pu = pd = pbc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -635,8 +637,8 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
         float ddl[ST], duu[ST];
 #pragma unroll
         for (int k = 0; k < ST; ++k) { ddl[k] = 0.f; duu[k] = 0.f; }
-        const float actf = id.act ? 1.f : 0.f;
-        const float *sdr = sd + clr * UP, *sur = su + clr * UP, *sgr = sg + clr * UP;
+        // padding lanes read the zero row: their arithmetic runs on zeros without any masking multiplies
+        const float *sdr = id.act ? sd + clr * UP : sZ, *sur = id.act ? su + clr * UP : sZ, *sgr = id.act ? sg + clr * UP : sZ;
         // The lane's 4 states, one at a time.  The loop is NOT unrolled (register budget); the
         // per-state register arrays are rotated so that index 0 is always the current state.
 #pragma unroll 1
@@ -653,7 +655,7 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = 4 * q + j;
-                    const float dlk = f4get(dv, j) * actf;
+                    const float dlk = f4get(dv, j);
                     v[ST + k] = hh;
                     v[k] = fast_exp2(dlk * A2[0]);
                     hh = v[k] * hh + dlk * f4get(uv, j) * f4get(bb, j);
@@ -672,17 +674,18 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
 #pragma unroll
                 for (int j = 3; j >= 0; --j) {
                     const int k = 4 * q + j;
-                    const float dlk = f4get(dv, j) * actf, uk = f4get(uv, j), gyk = f4get(gv, j) * actf;
+                    const float dlk = f4get(dv, j), uk = f4get(uv, j), gyk = f4get(gv, j);
                     const float Bv = f4get(bb, j), Cv = f4get(cc, j);
                     const float ak = v[k], hp = v[ST + k];
                     const float dlu = dlk * uk;
                     const float hk = ak * hp + dlu * Bv;                       // h_k
                     const float gh = qq + gyk * Cv;                             // dL/dh_k
-                    const float t1 = gh * hp * ak;                              // dL/da_k * a_k
-                    ddl[k] += t1 * Araw[0] + gh * Bv * uk;
-                    duu[k] += gh * dlk * Bv;
+                    const float gB = gh * Bv;
+                    qq = ak * gh;                                               // carried to step k-1
+                    const float t1 = qq * hp;                                   // dL/da_k * a_k
+                    ddl[k] += t1 * Araw[0] + gB * uk;
+                    duu[k] += gB * dlk;
                     dAi += t1 * dlk;
-                    qq = ak * gh;
                     v[k] = gh * dlu;                                            // dB[k][n] term of this channel
                     v[ST + k] = gyk * hk;                                       // dC[k][n] term of this channel
                 }
@@ -920,7 +923,7 @@ int scan_backward(const float *u, const float *delta, const float *Wdt, int R, c
                        dout, cq, gm, delta_softplus); }
     { MLAGG_TIMED(K_SELSCAN_PREFIX, st); hipLaunchKernelGGL(selscan_chunk_prefix, dim3((dim * NS + 255) / 256, batch), dim3(256), 0, st, A, cq, cdsum,
                        gm, 1); }
-    const size_t lds3 = (size_t)(3 * gb.CB * UP + 2 * ST * BP + 2 * ST * NS + (LR ? 2 * RMAX * ST + 8 * 128 : 0)) * sizeof(float);
+    const size_t lds3 = (size_t)(3 * gb.CB * UP + 2 * ST * BP + 2 * ST * NS + (LR ? 2 * RMAX * ST + 8 * 128 : 0) + UP) * sizeof(float);
     { MLAGG_TIMED(K_SELSCAN_BWD, st); hipLaunchKernelGGL(selscan_bwd_kernel<LR>, gridb, blockb, lds3, st, u, delta, Wdt, R, A, B, C, D, delta_bias,
                        dout, cstate, cq, du, ddelta, dB, dC, part, gb, delta_softplus, atomic_bc); }
     { MLAGG_TIMED(K_SELSCAN_REDUCE, st); hipLaunchKernelGGL(selscan_reduce_partials, dim3(dim), dim3(256), 0, st, part, dA, dD, ddelta_bias,
