@@ -436,10 +436,10 @@ __device__ __forceinline__ float row_ror8(float v)
 // lanes {i, i+4, i+8, i+12} of a DPP row are one orbit of row_ror:4, so two fused DPP adds all-reduce them.
 // Result: v[0..7] hold the channel sums of original values  j + 8 * bit4 + 16 * bit5,  identical in the
 // four lanes of an orbit.
-__device__ __forceinline__ void channel_reduce32(float (&v)[32])
+__device__ __forceinline__ void channel_reduce32(float (&v)[33])      // dB terms v[0..15], dC terms v[17..32]
 {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { swap32(v[i], v[i + 16]); v[i] += v[i + 16]; }
+    for (int i = 0; i < 16; ++i) { swap32(v[i], v[i + 17]); v[i] += v[i + 17]; }
 #pragma unroll
     for (int i = 0; i < 8; ++i) { swap16(v[i], v[i + 8]); v[i] += v[i + 8]; }
 #pragma unroll
@@ -484,9 +484,10 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
     float *aB = sC + ST * BP;      // [t][n] accumulators, pitch NS
     float *aC = aB + ST * NS;
     float *aR = aC + ST * NS;      // LR: [r][t] accumulators of d(dtr), pitch ST (adjacent to aB / aC: zeroed together)
-    float *sR = aR + RMAX * ST;    // LR: the sub-tile's dtr rows [r][t]
-    float *sW = sR + RMAX * ST;    // LR: per-thread {Wdt[d][0..3], dWdt accumulators[0..3]} -- kept out of the register budget
+    float *sR = aR + (LR ? RMAX * ST : 0);    // LR: the sub-tile's dtr rows [r][t]
+    float *sW = sR + (LR ? RMAX * ST : 0);    // LR: per-thread {Wdt[d][0..3], dWdt accumulators[0..3]} -- kept out of the register budget
     float *sZ = sW + (LR ? 8 * 128 : 0);   // one all-zero row: what the padding lanes of a partial wave read as u / delta / dy
+    float *sx = sZ + UP;                   // phase R: delta' * u per (channel, step) -- state-independent, formed once
 
     const LaneId id = lane_id(gm);
     const int tid = threadIdx.x, L = gm.L;
@@ -626,7 +627,9 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
                 const float wv[RMAX] = {w4.x, w4.y, w4.z, w4.w};
                 raw = lowrank_delta(sR, R, id.s, wv);
             }
-            *reinterpret_cast<float4 *>(sd + id.cl * UP + 4 * id.s) = activate_delta(raw, bias, softplus, t0 + 4 * id.s, L);
+            const float4 da = activate_delta(raw, bias, softplus, t0 + 4 * id.s, L);
+            *reinterpret_cast<float4 *>(sd + id.cl * UP + 4 * id.s) = da;
+            *reinterpret_cast<float4 *>(sx + id.cl * UP + 4 * id.s) = make_float4(da.x * ru.x, da.y * ru.y, da.z * ru.z, da.w * ru.w);
             *reinterpret_cast<float4 *>(sg + id.cl * UP + 4 * id.s) = rg;
         }
         if (bcrow)      // phase R keeps B / C as [n][t] rows (pitch BP): a state's 16 steps are 4 b128 reads
@@ -634,34 +637,37 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
         for (int i = tid; i < 2 * ST * NS + (LR ? RMAX * ST : 0); i += blockDim.x) aB[i] = 0.f;   // aB, aC, aR are adjacent
         __syncthreads();
 
-        float ddl[ST], duu[ST];
+        // per step, summed over the lane's 4 states:  sT = sum t1 * A  and  sG = sum gh * B;  then
+        // d(delta')[k] = sT + u_k * sG  and  du[k] = delta'_k * sG  (u, delta' do not depend on the state)
+        float sT[ST], sG[ST];
 #pragma unroll
-        for (int k = 0; k < ST; ++k) { ddl[k] = 0.f; duu[k] = 0.f; }
+        for (int k = 0; k < ST; ++k) { sT[k] = 0.f; sG[k] = 0.f; }
         // padding lanes read the zero row: their arithmetic runs on zeros without any masking multiplies
-        const float *sdr = id.act ? sd + clr * UP : sZ, *sur = id.act ? su + clr * UP : sZ, *sgr = id.act ? sg + clr * UP : sZ;
+        const float *sdr = id.act ? sd + clr * UP : sZ, *sgr = id.act ? sg + clr * UP : sZ, *sxr = id.act ? sx + clr * UP : sZ;
         // The lane's 4 states, one at a time.  The loop is NOT unrolled (register budget); the
         // per-state register arrays are rotated so that index 0 is always the current state.
 #pragma unroll 1
         for (int i = 0; i < 4; ++i) {
-            // v[k] : a_k, later the dB term ; v[ST + k] : h_{k-1}, later the dC term
-            float v[2 * ST];
+            // v[k] : a_k, later the dB term ;  v[ST + k], k = 0..16 : h_{k-1} (v[2 ST] = h_15); the dC term of step k
+            // overwrites v[ST + 1 + k] (= h_k, not needed below step k)
+            float v[2 * ST + 1];
             float hh = sub == 3 ? ck[3][0] : (sub == 2 ? ck[2][0] : (sub == 1 ? ck[1][0] : ck[0][0]));
             const float *sBn = sB + (4 * id.s + i) * BP, *sCn = sC + (4 * id.s + i) * BP;   // this state's rows
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 dv = *reinterpret_cast<const float4 *>(sdr + 4 * q);
-                const float4 uv = *reinterpret_cast<const float4 *>(sur + 4 * q);
+                const float4 xv = *reinterpret_cast<const float4 *>(sxr + 4 * q);
                 const float4 bb = *reinterpret_cast<const float4 *>(sBn + 4 * q);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = 4 * q + j;
-                    const float dlk = f4get(dv, j);
                     v[ST + k] = hh;
-                    v[k] = fast_exp2(dlk * A2[0]);
-                    hh = v[k] * hh + dlk * f4get(uv, j) * f4get(bb, j);
+                    v[k] = fast_exp2(f4get(dv, j) * A2[0]);
+                    hh = v[k] * hh + f4get(xv, j) * f4get(bb, j);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            v[2 * ST] = hh;
             __builtin_amdgcn_sched_barrier(0);     // keep the three phases of a state apart (register pressure)
             float qq = qc[0], dAi = dAacc[0];
 #pragma unroll
@@ -669,25 +675,21 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
                 const float4 cc = *reinterpret_cast<const float4 *>(sCn + 4 * q);
                 const float4 bb = *reinterpret_cast<const float4 *>(sBn + 4 * q);
                 const float4 dv = *reinterpret_cast<const float4 *>(sdr + 4 * q);
-                const float4 uv = *reinterpret_cast<const float4 *>(sur + 4 * q);
+                const float4 xv = *reinterpret_cast<const float4 *>(sxr + 4 * q);
                 const float4 gv = *reinterpret_cast<const float4 *>(sgr + 4 * q);
 #pragma unroll
                 for (int j = 3; j >= 0; --j) {
                     const int k = 4 * q + j;
-                    const float dlk = f4get(dv, j), uk = f4get(uv, j), gyk = f4get(gv, j);
-                    const float Bv = f4get(bb, j), Cv = f4get(cc, j);
-                    const float ak = v[k], hp = v[ST + k];
-                    const float dlu = dlk * uk;
-                    const float hk = ak * hp + dlu * Bv;                       // h_k
-                    const float gh = qq + gyk * Cv;                             // dL/dh_k
-                    const float gB = gh * Bv;
+                    const float gyk = f4get(gv, j);
+                    const float ak = v[k], hp = v[ST + k], hk = v[ST + k + 1];
+                    const float gh = qq + gyk * f4get(cc, j);                   // dL/dh_k
                     qq = ak * gh;                                               // carried to step k-1
                     const float t1 = qq * hp;                                   // dL/da_k * a_k
-                    ddl[k] += t1 * Araw[0] + gB * uk;
-                    duu[k] += gB * dlk;
-                    dAi += t1 * dlk;
-                    v[k] = gh * dlu;                                            // dB[k][n] term of this channel
-                    v[ST + k] = gyk * hk;                                       // dC[k][n] term of this channel
+                    sT[k] += t1 * Araw[0];
+                    sG[k] += gh * f4get(bb, j);
+                    dAi += t1 * f4get(dv, j);
+                    v[k] = gh * f4get(xv, j);                                   // dB[k][n] term of this channel
+                    v[ST + k + 1] = gyk * hk;                                   // dC[k][n] term of this channel
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -717,8 +719,8 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float a = quad_sum(ddl[4 * q + j]);
-                    const float b2 = quad_sum(duu[4 * q + j]);
+                    const float a = quad_sum(sT[4 * q + j]);
+                    const float b2 = quad_sum(sG[4 * q + j]);
                     if (id.s == q) { odd[j] = a; odu[j] = b2; }
                 }
             }
@@ -732,8 +734,8 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
                     // d softplus(x)/dx = sigmoid(x) = 1 - exp(-softplus(x)); 1 when softplus is off
                     const float sp = softplus ? (1.f - __expf(-dlj)) : 1.f;
                     const bool inr = (t0 + 4 * id.s + j) < L;
-                    odd[j] = inr ? odd[j] * sp : 0.f;
-                    odu[j] = odu[j] + Dd * gyj;
+                    odd[j] = inr ? (odd[j] + uj * odu[j]) * sp : 0.f;           // (sT + u * sG) * softplus'
+                    odu[j] = dlj * odu[j] + Dd * gyj;                           // delta' * sG + D * dy
                     dbacc += odd[j];
                     dDacc += gyj * uj;
                 }
@@ -923,7 +925,7 @@ int scan_backward(const float *u, const float *delta, const float *Wdt, int R, c
                        dout, cq, gm, delta_softplus); }
     { MLAGG_TIMED(K_SELSCAN_PREFIX, st); hipLaunchKernelGGL(selscan_chunk_prefix, dim3((dim * NS + 255) / 256, batch), dim3(256), 0, st, A, cq, cdsum,
                        gm, 1); }
-    const size_t lds3 = (size_t)(3 * gb.CB * UP + 2 * ST * BP + 2 * ST * NS + (LR ? 2 * RMAX * ST + 8 * 128 : 0) + UP) * sizeof(float);
+    const size_t lds3 = (size_t)(3 * gb.CB * UP + 2 * ST * BP + 2 * ST * NS + (LR ? 2 * RMAX * ST + 8 * 128 : 0) + UP + gb.CB * UP) * sizeof(float);
     { MLAGG_TIMED(K_SELSCAN_BWD, st); hipLaunchKernelGGL(selscan_bwd_kernel<LR>, gridb, blockb, lds3, st, u, delta, Wdt, R, A, B, C, D, delta_bias,
                        dout, cstate, cq, du, ddelta, dB, dC, part, gb, delta_softplus, atomic_bc); }
     { MLAGG_TIMED(K_SELSCAN_REDUCE, st); hipLaunchKernelGGL(selscan_reduce_partials, dim3(dim), dim3(256), 0, st, part, dA, dD, ddelta_bias,
