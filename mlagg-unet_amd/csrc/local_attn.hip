@@ -155,11 +155,24 @@ __device__ __forceinline__ void front_half(const Geom &g, const Unit &u, const f
     for (int e = 0; e < PER; ++e) f.o[e] = 0.f;
 }
 
+// LePE weights of the workgroup's head, transposed to [tap][channel] in LDS: a lane's 12 channels of one tap are
+// three ds_read_b128 (the untransposed global layout cost 108 scattered dword loads per lane).
+__device__ __forceinline__ void stage_lepe(float (*swt)[HD2], const float *__restrict__ lepe_w, int head)
+{
+    for (int i = threadIdx.x; i < 9 * HD2; i += blockDim.x) {
+        const int c = i / 9, j = i - 9 * c;
+        swt[j][c] = lepe_w[(head * HD2 + c) * 9 + j];
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(256)
 local_attn_fwd_kernel(const float *__restrict__ q, const float *__restrict__ kv, const float *__restrict__ lamp,
                       const float *__restrict__ subln_w, const float *__restrict__ lepe_w,
                       const float *__restrict__ lepe_b, float *__restrict__ out, Geom g)
 {
+    __shared__ float swt[9][HD2];
+    stage_lepe(swt, lepe_w, blockIdx.y);
     const Unit u = unit_id(g);
     if (!u.act) return;            // whole quads leave together; no block-level sync below
     const float lam = lamp[0];
@@ -174,12 +187,13 @@ local_attn_fwd_kernel(const float *__restrict__ q, const float *__restrict__ kv,
     for (int j = 0; j < 9; ++j) {
         if (!((f.valid >> j) & 1)) continue;
         const int yy = u.y + j / 3 - 1, xx = u.x + j % 3 - 1;
-        float vx[PER];
+        float vx[PER], wj[PER];
         load12(kv + ((size_t)u.b * N + (size_t)yy * g.W + xx) * g.kv_stride + g.d + cbase, vx);
+        load12(&swt[j][PER * u.r], wj);
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
             f.o[e] += f.Aw[j] * vx[e];
-            lp[e] += lepe_w[(cbase + e) * 9 + j] * vx[e];
+            lp[e] += wj[e] * vx[e];
         }
     }
     float ss = 0.f;
@@ -308,6 +322,8 @@ local_attn_bwd_b_kernel(const float *__restrict__ q, const float *__restrict__ l
                         const float *__restrict__ dout, int dout_stride, const float *__restrict__ ws,
                         float *__restrict__ dkv, int dkv_stride, Geom g)
 {
+    __shared__ float swt[9][HD2];
+    stage_lepe(swt, lepe_w, blockIdx.y);
     const Unit u = unit_id(g);
     if (!u.act) return;
     const int N = g.H * g.W;
@@ -326,13 +342,14 @@ local_attn_bwd_b_kernel(const float *__restrict__ q, const float *__restrict__ l
         const float *wrow = ws + (ti * g.nh + u.h) * WS_PER_UNIT;
         const float Ai = wrow[jw];
         const float dli = wrow[(u.r < 2 ? 9 : 18) + jw];
-        float dOi[PER], qi[PER], dyi[PER];
+        float dOi[PER], qi[PER], dyi[PER], wj[PER];
         load12(wrow + 28 + PER * u.r, dOi);
         load12(q + ti * g.q_stride + cbase, qi);
         load12(dout + ti * dout_stride + cbase, dyi);
+        load12(&swt[jw][PER * u.r], wj);
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
-            dv[e] += Ai * dOi[e] + lepe_w[(cbase + e) * 9 + jw] * dyi[e];
+            dv[e] += Ai * dOi[e] + wj[e] * dyi[e];
             dk[e] += dli * qi[e];
         }
     }
