@@ -262,6 +262,61 @@ def golden_evaluation():
     print("evaluation", tp[1:].tolist(), dsc[:4])
 
 
+def golden_dataloader():
+    """nnUNetDataLoader2D.generate_train_batch of the reference (training/dataloading/data_loader_2d.py:7-86 on
+    base_data_loader.py and nnunet_dataset.py) on the oracle's synthetic preprocessed folder, numpy seeded.  Stand-ins: the
+    batchgenerators DataLoader base class (its get_indices for infinite=True restated) and file helpers, LabelManager."""
+    import pickle
+    import tempfile
+    import typing
+    from oracle import dataloading_oracle as DO
+
+    class DataLoader:
+        def __init__(self, data, batch_size, num_threads_in_multithreaded=1, seed_for_shuffle=None, return_incomplete=False,
+                     shuffle=True, infinite=False, sampling_probabilities=None):
+            self._data, self.batch_size, self.infinite = data, batch_size, infinite
+            self.sampling_probabilities, self.indices = sampling_probabilities, None
+
+        def get_indices(self):
+            assert self.infinite
+            return np.random.choice(self.indices, self.batch_size, replace=True, p=self.sampling_probabilities)
+
+    def load_pickle(f):
+        with open(f, "rb") as fh:
+            return pickle.load(fh)
+
+    _mod("batchgenerators")
+    _mod("batchgenerators.dataloading")
+    _mod("batchgenerators.dataloading.data_loader", DataLoader=DataLoader)
+    _mod("batchgenerators.utilities")
+    _mod("batchgenerators.utilities.file_and_folder_operations", join=os.path.join, isfile=os.path.isfile,
+         load_pickle=load_pickle, subfiles=None, List=typing.List, os=os)
+    _mod("nnunetv2.configuration", default_num_processes=1)
+    _mod("nnunetv2.utilities.label_handling")
+    _mod("nnunetv2.utilities.label_handling.label_handling", LabelManager=object)
+    D2 = importlib.import_module("nnunetv2.training.dataloading.data_loader_2d")
+    DS = importlib.import_module("nnunetv2.training.dataloading.nnunet_dataset")
+
+    class LM:
+        all_labels = [0, 1, 2, 3]
+        has_ignore_label = False
+
+    out = {}
+    for tag, unpack, patch, final, bs, fg in (("npz", False, (40, 48), (32, 32), 4, 0.33), ("npy", True, (32, 32), (32, 32), 5, 0.5)):
+        folder = tempfile.mkdtemp()
+        DO.write_synthetic_dataset(folder, unpack=unpack)
+        dl = D2.nnUNetDataLoader2D(DS.nnUNetDataset(folder), bs, patch, final, LM(), oversample_foreground_percent=fg,
+                                   sampling_probabilities=None, pad_sides=None)
+        np.random.seed(7)
+        for it in range(3):
+            b = dl.generate_train_batch()
+            out[f"{tag}_data_{it}"] = b["data"]
+            out[f"{tag}_seg_{it}"] = b["seg"]
+            out[f"{tag}_keys_{it}"] = np.asarray([str(k) for k in b["keys"]])
+    np.savez_compressed(os.path.join(HERE, "dataloader.npz"), **out)
+    print("dataloader", {k: v.shape for k, v in out.items() if k.endswith("_0")})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -269,9 +324,11 @@ if __name__ == "__main__":
     if "--only-sliding-window" in sys.argv:
         golden_sliding_window()
         golden_evaluation()
+        golden_dataloader()
         sys.exit(0)
     golden_sliding_window()
     golden_evaluation()
+    golden_dataloader()
     golden_loss()
     golden_msmm(M)
     for v in ("B", "A"):

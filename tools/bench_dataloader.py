@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""Does the train step hold its synthetic-batch throughput with the real-data input path attached?
+Writes a synthetic preprocessed 2-D dataset (unpacked .npy, AbdomenMR-like slice sizes) under --dir, then measures
+(a) the loader alone (batches/s per thread count), (b) train steps fed by PrefetchLoader vs resident synthetic batches.
+    python tools/bench_dataloader.py [--dir /tmp/mlagg_ds] [--cases 12] [--steps 20] [--workers 6]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import mlagg_unet_amd  # noqa: E402,F401
+from mlagg_unet_amd import dataloading as DL  # noqa: E402
+from mlagg_unet_amd import miopen_tuning, model, trainer  # noqa: E402
+from oracle import dataloading_oracle as DO  # noqa: E402  (dataset writer only)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dir", default="/tmp/mlagg_ds")
+    ap.add_argument("--cases", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--workers", type=int, default=6)
+    a = ap.parse_args()
+    if not os.path.isdir(a.dir) or not os.listdir(a.dir):
+        DO.write_synthetic_dataset(a.dir, n_cases=a.cases, unpack=True, small=False, labels=tuple(range(1, 14)))
+    ds = DL.Dataset(a.dir)
+    B, patch = 10, (256, 256)
+    labels = list(range(14))
+    for nw in (1, a.workers):
+        dl = DL.DataLoader2D(ds, B, patch, patch, labels, 0.33, rng=np.random.RandomState(0))
+        t0 = time.perf_counter()
+        if nw == 1:
+            for _ in range(20):
+                dl.generate_train_batch()
+            n = 20
+        else:
+            pf = DL.PrefetchLoader(dl, "cpu", num_workers=nw, depth=8)
+            for _ in range(60):
+                pf.next()
+            pf.close()
+            n = 60
+        dt = time.perf_counter() - t0
+        print(f"loader alone, {nw} thread(s): {n / dt:.1f} batches/s = {n * B / dt:.0f} images/s", flush=True)
+
+    dev = torch.device("cuda:0")
+    miopen_tuning.use_tuned_convolutions()
+    torch.manual_seed(0)
+    net = model.build_network_architecture(patch, 1, 14, True, "B").to(dev).train()
+    opt, _ = trainer.configure_optimizers(net)
+    data, target = trainer.synthetic_batch(B, 1, *patch, 14, device=dev)
+    for _ in range(4):
+        trainer.train_step(net, opt, data, target)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        trainer.train_step(net, opt, data, target)
+    torch.cuda.synchronize()
+    syn = (time.perf_counter() - t0) / a.steps
+    dl = DL.DataLoader2D(ds, B, patch, patch, labels, 0.33)
+    pf = DL.PrefetchLoader(dl, dev, num_workers=a.workers, depth=6)
+    for _ in range(3):
+        trainer.train_step(net, opt, *pf.next())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        trainer.train_step(net, opt, *pf.next())
+    torch.cuda.synchronize()
+    real = (time.perf_counter() - t0) / a.steps
+    pf.close()
+    print(f"train step, resident synthetic batch : {syn * 1e3:.2f} ms  ({B / syn:.1f} images/s)")
+    print(f"train step, PrefetchLoader ({a.workers} threads): {real * 1e3:.2f} ms  ({B / real:.1f} images/s)")
+
+
+if __name__ == "__main__":
+    main()
