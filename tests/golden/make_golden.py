@@ -149,6 +149,34 @@ def golden_full_model(T, variant):
     print("full model", variant, float(loss), [tuple(o.shape) for o in out])
 
 
+def golden_full_model_256(T):
+    """The reference network itself at the HEADLINE size of BASELINE config 2 (1 x 1 x 256 x 256, 14 classes, variant B):
+    logits of the five heads (full resolution sub-sampled 4x4 to keep the fixture small, plus per-class sums of the full
+    maps), the deep-supervision loss and every parameter-gradient norm.  ~2 minutes of CPU time (Python-loop scan over
+    L_cat = 21760 steps)."""
+    FLASH_SCALE["value"] = 1.0
+    img = (256, 256)
+    m = ref_model(T, img).eval()
+    data, target = O.synthetic_batch(1, 1, *img, 14, seed=4321)
+    out = m(data)
+    from nnunetv2.training.loss.compound_losses import DC_and_CE_loss
+    from nnunetv2.training.loss.deep_supervision import DeepSupervisionWrapper
+    from nnunetv2.training.loss.dice import MemoryEfficientSoftDiceLoss
+    base = DC_and_CE_loss({'batch_dice': True, 'smooth': 1e-5, 'do_bg': False, 'ddp': False}, {}, weight_ce=1,
+                          weight_dice=1, ignore_label=None, dice_class=MemoryEfficientSoftDiceLoss)
+    w = np.array([1 / (2 ** i) for i in range(5)])
+    loss = DeepSupervisionWrapper(base, w / w.sum())(out, target)
+    loss.backward()
+    names, norms = grad_summary(m)
+    np.savez_compressed(
+        os.path.join(HERE, "full_model_256_variantB.npz"), img=np.asarray(img), data_seed=4321, loss=float(loss),
+        grad_names=np.asarray(names), grad_norms=norms,
+        out0_sub=out[0].detach().numpy()[:, :, ::4, ::4], out0_class_sums=out[0].detach().double().sum((0, 2, 3)).numpy(),
+        out0_abs_max=float(out[0].detach().abs().max()),
+        **{f"out{i}": o.detach().numpy() for i, o in enumerate(out) if i > 0})
+    print("full model 256", float(loss), [tuple(o.shape) for o in out])
+
+
 def golden_mllablock(T, variant):
     FLASH_SCALE["value"] = None if variant == "A" else 1.0
     for tag, dim, res, heads, sr in (("s0", 96, (16, 16), 2, 4), ("s2", 384, (6, 8), 8, 2)):
@@ -321,6 +349,9 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     T, M = import_reference()
+    if "--only-256" in sys.argv:
+        golden_full_model_256(T)
+        sys.exit(0)
     if "--only-sliding-window" in sys.argv:
         golden_sliding_window()
         golden_evaluation()
@@ -334,3 +365,4 @@ if __name__ == "__main__":
     for v in ("B", "A"):
         golden_mllablock(T, v)
         golden_full_model(T, v)
+    golden_full_model_256(T)

@@ -70,3 +70,30 @@ def test_other_configs_run_and_are_deterministic(img, in_ch, n_cls, variant):
     for n, p in net.named_parameters():
         if n != "dummy_tensor":
             assert p.grad is not None and torch.isfinite(p.grad).all(), n
+
+
+@gpu
+def test_headline_size_matches_reference_golden():
+    """BASELINE config 2's image size, against the REFERENCE network's own outputs (tests/golden/full_model_256_variantB.npz):
+    logits of all five heads < 1e-3 (north_star tolerance), loss, and every parameter-gradient norm."""
+    import os
+    import numpy as np
+    from mlagg_unet_amd import model as PM, trainer as TR
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "full_model_256_variantB.npz"))
+    img = tuple(int(v) for v in g["img"])
+    m = PM.build_network_architecture(img, 1, 14, True, "B")
+    O.deterministic_fill_(m.state_dict())
+    m = m.to(DEV).eval()
+    data, target = O.synthetic_batch(1, 1, *img, 14, seed=int(g["data_seed"]))
+    out = m(data.to(DEV))
+    assert float((out[0].detach().cpu()[:, :, ::4, ::4] - torch.from_numpy(g["out0_sub"])).abs().max()) < 1e-3
+    sums = out[0].detach().double().sum((0, 2, 3)).cpu().numpy()
+    assert np.allclose(sums, g["out0_class_sums"], rtol=1e-4, atol=1.0)
+    for i in range(1, 5):
+        assert float((out[i].detach().cpu() - torch.from_numpy(g[f"out{i}"])).abs().max()) < 1e-3, i
+    loss = TR.deep_supervision_loss(out, [t.to(DEV) for t in target], batch_dice=True)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4
+    loss.backward()
+    norms = {n: float(p.grad.double().norm()) for n, p in m.named_parameters() if p.grad is not None}
+    for n, ref in zip(g["grad_names"], g["grad_norms"]):
+        assert abs(norms[str(n)] - ref) <= 5e-3 * max(ref, 1e-3), (n, norms[str(n)], ref)

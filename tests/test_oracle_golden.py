@@ -46,6 +46,23 @@ def test_full_model_matches_reference(golden_dir, variant):
             np.testing.assert_allclose(p.grad.numpy(), g[key], atol=2e-5, rtol=2e-3, err_msg=key)
 
 
+def test_full_model_headline_size_matches_reference(golden_dir):
+    """BASELINE config 2's image size (256 x 256, L_cat = 21760): oracle forward + loss against the reference network's own
+    outputs (forward only on the CPU: the backward is covered at 64 x 64 above and on the GPU at this size)."""
+    g = _load(golden_dir, "full_model_256_variantB.npz")
+    m = O.build_reference_config_model(tuple(g["img"]), variant="B").eval()
+    O.deterministic_fill_(m.state_dict())
+    data, target = O.synthetic_batch(1, 1, *g["img"], 14, seed=int(g["data_seed"]))
+    with torch.no_grad():
+        out = m(data)
+        loss = O.deep_supervision_loss(out, target, batch_dice=True)
+    np.testing.assert_allclose(out[0].numpy()[:, :, ::4, ::4], g["out0_sub"], atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(out[0].double().sum((0, 2, 3)).numpy(), g["out0_class_sums"], rtol=1e-4, atol=0.5)
+    for i in range(1, 5):
+        np.testing.assert_allclose(out[i].numpy(), g[f"out{i}"], atol=2e-4, rtol=1e-4)
+    assert abs(float(loss) - float(g["loss"])) < 2e-5
+
+
 @pytest.mark.parametrize("variant", ["B", "A"])
 @pytest.mark.parametrize("tag", ["s0", "s2"])
 def test_mllablock_matches_reference(golden_dir, tag, variant):
