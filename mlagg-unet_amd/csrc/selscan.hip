@@ -185,8 +185,8 @@ __global__ void __launch_bounds__(128) selscan_fwd_kernel(const float *__restric
                                    const float *__restrict__ A, const float *__restrict__ Bm,
                                    const float *__restrict__ Cm, const float *__restrict__ Dv,
                                    const float *__restrict__ dbias, float *__restrict__ out,
-                                   float *__restrict__ cstate, float *__restrict__ cdsum, ScanGeom gm,
-                                   int softplus)
+                                   float *__restrict__ cstate, float *__restrict__ cdsum, float *__restrict__ csub,
+                                   ScanGeom gm, int softplus)
 {
     extern __shared__ float4 smem4[];
     float *su = reinterpret_cast<float *>(smem4);
@@ -245,6 +245,9 @@ __global__ void __launch_bounds__(128) selscan_fwd_kernel(const float *__restric
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
         const int t0 = tc0 + sub * ST;
+        if (FINAL && sub > 0 && id.act)       // state entering sub-tiles 1..3: saved so that backward does not re-sweep the chunk
+            *reinterpret_cast<float4 *>(csub + ((srow / gm.dim * (NSUB - 1) + (sub - 1)) * gm.dim + id.d) * NS + 4 * id.s) =
+                make_float4(h[0], h[1], h[2], h[3]);
         __syncthreads();
         if (id.act) {
             *reinterpret_cast<float4 *>(su + id.cl * UP + 4 * id.s) = pu[sub];
@@ -459,8 +462,8 @@ __device__ __forceinline__ void channel_reduce16(float (&v)[16])
 }
 
 // ------------------------------------------------------------------------------------------
-// backward pass 3: per chunk -- forward sweep to recover the states entering sub-tiles 1..3
-// (register checkpoints), then sub-tiles in reverse: per state, re-run 16 steps forward keeping
+// backward pass 3: per chunk, sub-tiles in reverse (their entry states were saved by the forward pass):
+// per state, re-run 16 steps forward keeping
 // h_{k-1} and a_k in registers, run the reverse recurrence and form every gradient.
 // dB/dC: butterfly over the wave's 16 channels, then ds_add_f32 into the workgroup's [t][n]
 // accumulators, stored once per sub-tile (plain stores when one workgroup covers the group).
@@ -471,7 +474,8 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
                    const float *__restrict__ A,
                    const float *__restrict__ Bm, const float *__restrict__ Cm, const float *__restrict__ Dv,
                    const float *__restrict__ dbias, const float *__restrict__ dout,
-                   const float *__restrict__ cstate, const float *__restrict__ cq, float *__restrict__ du,
+                   const float *__restrict__ cstate, const float *__restrict__ csub, const float *__restrict__ cq,
+                   float *__restrict__ du,
                    float *__restrict__ ddelta, float *__restrict__ dB, float *__restrict__ dC,
                    float *__restrict__ part, ScanGeom gm, int softplus, int atomic_bc)
 {
@@ -516,80 +520,13 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
     const size_t srow = ((size_t)id.b * gm.nchunks + id.chunk) * gm.dim + id.d;
     const int tc0 = id.chunk * TC;
 
-    float A2[4], Araw[4], h[4], ck[NSUB][4];
+    float A2[4], Araw[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         Araw[i] = id.act ? A[id.d * NS + 4 * id.s + i] : 0.f;
         A2[i] = Araw[i] * LOG2E;
-        h[i] = 0.f;
     }
-    if (id.act) {
-        const float4 h0 = *reinterpret_cast<const float4 *>(cstate + srow * NS + 4 * id.s);
-        h[0] = h0.x; h[1] = h0.y; h[2] = h0.z; h[3] = h0.w;
-    }
-
     if (tid < UP) sZ[tid] = 0.f;           // visible after the first barrier below
-    // ---- phase F: forward sweep over sub-tiles 0 .. NSUB-2, checkpointing entry states ----
-    float4 pu, pd, pbc;                    // pd: the lane's delta segment, or (LR) one rank-row segment
-    pu = pd = pbc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (LR) pd = load_rank_rows(drow, R, tid, tc0, L, vec);
-    if (id.act) {
-        pu = load4(urow, tc0 + 4 * id.s, L, vec);
-        if (!LR) pd = load4(drow, tc0 + 4 * id.s, L, vec);
-    }
-    if (tid < 64) pbc = load4(bcrow, tc0 + 4 * (tid & 3), L, vec);
-#pragma unroll
-    for (int sub = 0; sub < NSUB; ++sub) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ck[sub][i] = h[i];
-        if (sub == NSUB - 1) break;
-        const int t0 = tc0 + sub * ST;
-        __syncthreads();
-        if (LR) {                                   // rank rows first: the activation below reads them
-            stage_rank_rows(sR, R, tid, pd);
-            __syncthreads();
-        }
-        if (id.act) {
-            *reinterpret_cast<float4 *>(su + id.cl * UP + 4 * id.s) = pu;
-            float4 raw = pd;
-            if (LR) {
-                const float4 w4 = *reinterpret_cast<const float4 *>(sW + 8 * tid);
-                const float wv[RMAX] = {w4.x, w4.y, w4.z, w4.w};
-                raw = lowrank_delta(sR, R, id.s, wv);
-            }
-            *reinterpret_cast<float4 *>(sd + id.cl * UP + 4 * id.s) = activate_delta(raw, bias, softplus, t0 + 4 * id.s, L);
-        }
-        if (tid < 64) {
-            float *dst = sB + (4 * (tid & 3)) * BP + (tid >> 2);
-            dst[0] = pbc.x; dst[BP] = pbc.y; dst[2 * BP] = pbc.z; dst[3 * BP] = pbc.w;
-        }
-        __syncthreads();
-        if (sub + 2 < NSUB) {
-            const int t = t0 + ST;
-            if (LR) pd = load_rank_rows(drow, R, tid, t, L, vec);
-            if (id.act) {
-                pu = load4(urow, t + 4 * id.s, L, vec);
-                if (!LR) pd = load4(drow, t + 4 * id.s, L, vec);
-            }
-            if (tid < 64) pbc = load4(bcrow, t + 4 * (tid & 3), L, vec);
-        }
-        if (id.act) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 dv = *reinterpret_cast<const float4 *>(sd + id.cl * UP + 4 * q);
-                const float4 uv = *reinterpret_cast<const float4 *>(su + id.cl * UP + 4 * q);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float dl = f4get(dv, j), dlu = dl * f4get(uv, j);
-                    const float4 Bq = *reinterpret_cast<const float4 *>(sB + (4 * q + j) * BP + 4 * id.s);
-                    h[0] = fast_exp2(dl * A2[0]) * h[0] + dlu * Bq.x;
-                    h[1] = fast_exp2(dl * A2[1]) * h[1] + dlu * Bq.y;
-                    h[2] = fast_exp2(dl * A2[2]) * h[2] + dlu * Bq.z;
-                    h[3] = fast_exp2(dl * A2[3]) * h[3] + dlu * Bq.w;
-                }
-            }
-        }
-    }
 
     // ---- phase R: sub-tiles in reverse ----
     // Inactive lanes (padding of a partial wave) run the arithmetic on zeros so that the
@@ -607,6 +544,13 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
     for (int sub = NSUB - 1; sub >= 0; --sub) {
         const int t0 = tc0 + sub * ST;
         float4 ru = make_float4(0.f, 0.f, 0.f, 0.f), rd = ru, rg = ru, rbc = ru;
+        float hent[4] = {0.f, 0.f, 0.f, 0.f};      // the 4 states entering this sub-tile (saved by the forward pass)
+        if (id.act) {
+            const float *src = sub == 0 ? cstate + srow * NS
+                                        : csub + ((srow / gm.dim * (NSUB - 1) + (sub - 1)) * gm.dim + id.d) * NS;
+            const float4 h0 = *reinterpret_cast<const float4 *>(src + 4 * id.s);
+            hent[0] = h0.x; hent[1] = h0.y; hent[2] = h0.z; hent[3] = h0.w;
+        }
         if (LR) rd = load_rank_rows(drow, R, tid, t0, L, vec);
         if (id.act) {
             ru = load4(urow, t0 + 4 * id.s, L, vec);
@@ -651,7 +595,7 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
             // v[k] : a_k, later the dB term ;  v[ST + k], k = 0..16 : h_{k-1} (v[2 ST] = h_15); the dC term of step k
             // overwrites v[ST + 1 + k] (= h_k, not needed below step k)
             float v[2 * ST + 1];
-            float hh = sub == 3 ? ck[3][0] : (sub == 2 ? ck[2][0] : (sub == 1 ? ck[1][0] : ck[0][0]));
+            float hh = hent[0];
             const float *sBn = sB + (4 * id.s + i) * BP, *sCn = sC + (4 * id.s + i) * BP;   // this state's rows
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -709,8 +653,7 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
                 atomicAdd(acc0, v0);
                 atomicAdd(acc0 + NS, v1);                       // base is even: base + 1 stays in the same half
             }
-            rot4(A2); rot4(Araw); rot4(qc); rot4(dAacc);
-            rot4(ck[0]); rot4(ck[1]); rot4(ck[2]); rot4(ck[3]);
+            rot4(A2); rot4(Araw); rot4(qc); rot4(dAacc); rot4(hent);
         }
         // quad-reduce d(delta') and du, apply softplus', D skip; lane s keeps steps 4s..4s+3
         {
@@ -860,7 +803,7 @@ inline int block_threads(const ScanGeom &gm)
 extern "C" size_t mlagg_selscan_state_floats(int batch, int dim, int L, int N)
 {
     const size_t nchunks = (L + TC - 1) / TC;
-    return (size_t)batch * nchunks * dim * (N + 1);
+    return (size_t)batch * nchunks * dim * (N + 1 + (NSUB - 1) * N);     // chunk entry states, chunk delta sums, sub-tile entry states
 }
 
 extern "C" size_t mlagg_selscan_bwd_workspace_floats(int batch, int dim, int L, int N)
@@ -881,14 +824,15 @@ int scan_forward(const float *u, const float *delta, const float *Wdt, int R, co
     hipStream_t st = static_cast<hipStream_t>(stream);
     float *cstate = chunk_state;
     float *cdsum = chunk_state + (size_t)batch * gm.nchunks * dim * NS;
+    float *csub = cdsum + (size_t)batch * gm.nchunks * dim;
     const dim3 grid(gm.nchunks, G * gm.nblk, batch), block(block_threads(gm));
     const size_t lds = (size_t)(2 * gm.CB * UP + 2 * ST * BP + (LR ? 2 * RMAX * ST : 0)) * sizeof(float);
     { MLAGG_TIMED(K_SELSCAN_FWD_LOCAL, st); hipLaunchKernelGGL((selscan_fwd_kernel<false, LR>), grid, block, lds, st, u, delta, Wdt, R, A, B, C, D,
-                       delta_bias, out, cstate, cdsum, gm, delta_softplus); }
+                       delta_bias, out, cstate, cdsum, csub, gm, delta_softplus); }
     { MLAGG_TIMED(K_SELSCAN_PREFIX, st); hipLaunchKernelGGL(selscan_chunk_prefix, dim3((dim * NS + 255) / 256, batch), dim3(256), 0, st, A, cstate,
                        cdsum, gm, 0); }
     { MLAGG_TIMED(K_SELSCAN_FWD_FINAL, st); hipLaunchKernelGGL((selscan_fwd_kernel<true, LR>), grid, block, lds, st, u, delta, Wdt, R, A, B, C, D,
-                       delta_bias, out, cstate, cdsum, gm, delta_softplus); }
+                       delta_bias, out, cstate, cdsum, csub, gm, delta_softplus); }
     return (int)hipGetLastError();
 }
 
@@ -904,6 +848,7 @@ int scan_backward(const float *u, const float *delta, const float *Wdt, int R, c
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float *cstate = chunk_state;
     const float *cdsum = chunk_state + (size_t)batch * gm.nchunks * dim * NS;
+    const float *csub = cdsum + (size_t)batch * gm.nchunks * dim;
     float *cq = workspace;
     float *part = workspace + (size_t)batch * gm.nchunks * dim * NS;
     const dim3 grid(gm.nchunks, G * gm.nblk, batch), block(block_threads(gm));
@@ -927,7 +872,7 @@ int scan_backward(const float *u, const float *delta, const float *Wdt, int R, c
                        gm, 1); }
     const size_t lds3 = (size_t)(3 * gb.CB * UP + 2 * ST * BP + 2 * ST * NS + (LR ? 2 * RMAX * ST + 8 * 128 : 0) + UP + gb.CB * UP) * sizeof(float);
     { MLAGG_TIMED(K_SELSCAN_BWD, st); hipLaunchKernelGGL(selscan_bwd_kernel<LR>, gridb, blockb, lds3, st, u, delta, Wdt, R, A, B, C, D, delta_bias,
-                       dout, cstate, cq, du, ddelta, dB, dC, part, gb, delta_softplus, atomic_bc); }
+                       dout, cstate, csub, cq, du, ddelta, dB, dC, part, gb, delta_softplus, atomic_bc); }
     { MLAGG_TIMED(K_SELSCAN_REDUCE, st); hipLaunchKernelGGL(selscan_reduce_partials, dim3(dim), dim3(256), 0, st, part, dA, dD, ddelta_bias,
                        LR ? dWdt : nullptr, R, gm); }
     return (int)hipGetLastError();
