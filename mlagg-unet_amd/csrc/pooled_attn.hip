@@ -248,7 +248,7 @@ pooled_attn_bwd1_kernel(const float *__restrict__ q, const float *__restrict__ k
 // pooled_attn_bwd2_reduce_kernel sums the partial blocks.
 constexpr int B2_TILE = 32;                      // tokens per LDS tile of one wave
 constexpr int B2_TILE_FLOATS = B2_TILE * (HD2 + HD2 + 4);
-constexpr int B2_TPB = 512;                      // tokens per workgroup
+constexpr int B2_TPB = 128;                      // tokens per workgroup (512 left 1 workgroup per CU: every stage took ~85 us)
 constexpr int B2_RED_PITCH = 65;                 // [wave][channel][key] reduction image, conflict-free both ways
 
 __global__ void __launch_bounds__(256)
