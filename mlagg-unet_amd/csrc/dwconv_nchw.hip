@@ -73,6 +73,92 @@ dwconv_nchw_bwd_data_kernel(const float *__restrict__ dy, const float *__restric
     dx[((size_t)b * g.C + c) * g.H * g.W + idx] = acc;
 }
 
+// Stride-1 fast path (W % 4 == 0; every MedNeXtBlock.conv1 of the decoder): a thread owns 4 consecutive pixels of one row,
+// reads each of the 3 input rows as one aligned float4 plus its two neighbours (9 loads for 4 outputs instead of 36
+// guarded dword loads) and stores a float4.  FLIP = true applies the kernel rotated by 180 degrees: the data gradient.
+template <bool FLIP>
+__global__ void __launch_bounds__(256)
+dwconv_nchw_s1_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                      float *__restrict__ y, G g)
+{
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int W4 = g.W >> 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.H * W4) return;
+    const int oy = idx / W4, x0 = 4 * (idx - oy * W4);
+    const float *xp = x + ((size_t)b * g.C + c) * g.H * g.W;
+    float wk[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) wk[j] = w[c * 9 + (FLIP ? 8 - j : j)];
+    const float bv = (!FLIP && bias) ? bias[c] : 0.f;
+    float acc[4] = {bv, bv, bv, bv};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy + ky - 1;
+        if (iy < 0 || iy >= g.H) continue;
+        const float *row = xp + (size_t)iy * g.W + x0;
+        const float4 m = *reinterpret_cast<const float4 *>(row);
+        const float l = x0 > 0 ? row[-1] : 0.f;
+        const float r = x0 + 4 < g.W ? row[4] : 0.f;
+        const float v[6] = {l, m.x, m.y, m.z, m.w, r};
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            acc[o] += wk[3 * ky] * v[o] + wk[3 * ky + 1] * v[o + 1] + wk[3 * ky + 2] * v[o + 2];
+    }
+    *reinterpret_cast<float4 *>(y + ((size_t)b * g.C + c) * g.H * g.W + (size_t)oy * g.W + x0) =
+        make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+// Stride-1 weight gradient, same 4-pixel strips: dw[ky][kx] += dy[p] * x[p + (ky-1, kx-1)], dbias += dy[p]
+__global__ void __launch_bounds__(256)
+dwconv_nchw_s1_bwd_weight_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ part, G g)
+{
+    __shared__ float red[10][4];
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float *xp = x + ((size_t)b * g.C + c) * g.H * g.W;
+    const float *dp = dy + ((size_t)b * g.C + c) * g.H * g.W;
+    float gw[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float gb = 0.f;
+    const int W4 = g.W >> 2, n = g.H * W4;
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(lo + per, n);
+    for (int idx = lo + threadIdx.x; idx < hi; idx += blockDim.x) {
+        const int oy = idx / W4, x0 = 4 * (idx - oy * W4);
+        const float4 gv = *reinterpret_cast<const float4 *>(dp + (size_t)oy * g.W + x0);
+        const float gq[4] = {gv.x, gv.y, gv.z, gv.w};
+        gb += (gv.x + gv.y) + (gv.z + gv.w);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy + ky - 1;
+            if (iy < 0 || iy >= g.H) continue;
+            const float *row = xp + (size_t)iy * g.W + x0;
+            const float4 m = *reinterpret_cast<const float4 *>(row);
+            const float l = x0 > 0 ? row[-1] : 0.f;
+            const float r = x0 + 4 < g.W ? row[4] : 0.f;
+            const float v[6] = {l, m.x, m.y, m.z, m.w, r};
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                gw[3 * ky] += gq[o] * v[o];
+                gw[3 * ky + 1] += gq[o] * v[o + 1];
+                gw[3 * ky + 2] += gq[o] * v[o + 2];
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        float v = j < 9 ? gw[j] : gb;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[j][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        const float s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        part[(((size_t)b * gridDim.x + blockIdx.x) * g.C + c) * 10 + threadIdx.x] = s;
+    }
+}
+
 // one workgroup per (slice of a plane, channel, batch): part[(b * nslices + slice)][c][10]
 __global__ void __launch_bounds__(256)
 dwconv_nchw_bwd_weight_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ part, G g)
@@ -157,7 +243,10 @@ extern "C" int mlagg_dwconv3x3_nchw_fwd(const float *x, const float *w, const fl
     if (int rc = make_g(g, B, C, H, W, stride)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     MLAGG_TIMED(K_DWCONV_NCHW_FWD, st);
-    hipLaunchKernelGGL(dwconv_nchw_fwd_kernel, dim3((g.Ho * g.Wo + 255) / 256, C, B), dim3(256), 0, st, x, w, bias, y, g);
+    if (stride == 1 && (W & 3) == 0)
+        hipLaunchKernelGGL(dwconv_nchw_s1_kernel<false>, dim3((H * (W >> 2) + 255) / 256, C, B), dim3(256), 0, st, x, w, bias, y, g);
+    else
+        hipLaunchKernelGGL(dwconv_nchw_fwd_kernel, dim3((g.Ho * g.Wo + 255) / 256, C, B), dim3(256), 0, st, x, w, bias, y, g);
     return (int)hipGetLastError();
 }
 
@@ -178,9 +267,17 @@ extern "C" int mlagg_dwconv3x3_nchw_bwd(const float *x, const float *w, const fl
     hipStream_t st = static_cast<hipStream_t>(stream);
     {
         MLAGG_TIMED(K_DWCONV_NCHW_BWD, st);
-        hipLaunchKernelGGL(dwconv_nchw_bwd_data_kernel, dim3((H * W + 255) / 256, C, B), dim3(256), 0, st, dy, w, dx, g);
+        const bool strips = stride == 1 && (W & 3) == 0;
+        if (strips)
+            hipLaunchKernelGGL(dwconv_nchw_s1_kernel<true>, dim3((H * (W >> 2) + 255) / 256, C, B), dim3(256), 0, st, dy, w,
+                               nullptr, dx, g);
+        else
+            hipLaunchKernelGGL(dwconv_nchw_bwd_data_kernel, dim3((H * W + 255) / 256, C, B), dim3(256), 0, st, dy, w, dx, g);
         const int ns = wgrad_slices(g);
-        hipLaunchKernelGGL(dwconv_nchw_bwd_weight_kernel, dim3(ns, C, B), dim3(256), 0, st, x, dy, workspace, g);
+        if (strips)
+            hipLaunchKernelGGL(dwconv_nchw_s1_bwd_weight_kernel, dim3(ns, C, B), dim3(256), 0, st, x, dy, workspace, g);
+        else
+            hipLaunchKernelGGL(dwconv_nchw_bwd_weight_kernel, dim3(ns, C, B), dim3(256), 0, st, x, dy, workspace, g);
         hipLaunchKernelGGL(dwconv_nchw_wgrad_reduce_kernel, dim3((C * 10 + 255) / 256), dim3(256), 0, st, workspace,
                            B * ns, C, dw, dbias);
     }
