@@ -21,10 +21,12 @@ struct G {
     int B, C, H, W, Ho, Wo, stride;
 };
 
+template <int S>                      // S: compile-time stride (divisions and remainders fold), 0 = runtime g.stride
 __global__ void __launch_bounds__(256)
 dwconv_nchw_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                        float *__restrict__ y, G g)
 {
+    const int stride = S ? S : g.stride;
     const int c = blockIdx.y, b = blockIdx.z;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= g.Ho * g.Wo) return;
@@ -34,11 +36,11 @@ dwconv_nchw_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
     float acc = bias ? bias[c] : 0.f;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy * g.stride + ky - 1;
+        const int iy = oy * stride + ky - 1;
         if (iy < 0 || iy >= g.H) continue;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const int ix = ox * g.stride + kx - 1;
+            const int ix = ox * stride + kx - 1;
             if (ix >= 0 && ix < g.W) acc += wp[ky * 3 + kx] * xp[(size_t)iy * g.W + ix];
         }
     }
@@ -46,9 +48,11 @@ dwconv_nchw_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
 }
 
 // dx[iy][ix] = sum_{ky,kx} w[ky][kx] * dy[oy][ox] with oy*s + ky - 1 = iy, ox*s + kx - 1 = ix
+template <int S>
 __global__ void __launch_bounds__(256)
 dwconv_nchw_bwd_data_kernel(const float *__restrict__ dy, const float *__restrict__ w, float *__restrict__ dx, G g)
 {
+    const int stride = S ? S : g.stride;
     const int c = blockIdx.y, b = blockIdx.z;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= g.H * g.W) return;
@@ -59,14 +63,14 @@ dwconv_nchw_bwd_data_kernel(const float *__restrict__ dy, const float *__restric
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
         const int ty = iy + 1 - ky;
-        if (ty < 0 || ty % g.stride) continue;
-        const int oy = ty / g.stride;
+        if (ty < 0 || ty % stride) continue;
+        const int oy = ty / stride;
         if (oy >= g.Ho) continue;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int tx = ix + 1 - kx;
-            if (tx < 0 || tx % g.stride) continue;
-            const int ox = tx / g.stride;
+            if (tx < 0 || tx % stride) continue;
+            const int ox = tx / stride;
             if (ox < g.Wo) acc += wp[ky * 3 + kx] * dp[(size_t)oy * g.Wo + ox];
         }
     }
@@ -160,9 +164,11 @@ dwconv_nchw_s1_bwd_weight_kernel(const float *__restrict__ x, const float *__res
 }
 
 // one workgroup per (slice of a plane, channel, batch): part[(b * nslices + slice)][c][10]
+template <int S>
 __global__ void __launch_bounds__(256)
 dwconv_nchw_bwd_weight_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ part, G g)
 {
+    const int stride = S ? S : g.stride;
     __shared__ float red[10][4];
     const int c = blockIdx.y, b = blockIdx.z;
     const float *xp = x + ((size_t)b * g.C + c) * g.H * g.W;
@@ -178,11 +184,11 @@ dwconv_nchw_bwd_weight_kernel(const float *__restrict__ x, const float *__restri
         gb += gv;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy * g.stride + ky - 1;
+            const int iy = oy * stride + ky - 1;
             if (iy < 0 || iy >= g.H) continue;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int ix = ox * g.stride + kx - 1;
+                const int ix = ox * stride + kx - 1;
                 if (ix >= 0 && ix < g.W) gw[ky * 3 + kx] += gv * xp[(size_t)iy * g.W + ix];
             }
         }
@@ -245,8 +251,10 @@ extern "C" int mlagg_dwconv3x3_nchw_fwd(const float *x, const float *w, const fl
     MLAGG_TIMED(K_DWCONV_NCHW_FWD, st);
     if (stride == 1 && (W & 3) == 0)
         hipLaunchKernelGGL(dwconv_nchw_s1_kernel<false>, dim3((H * (W >> 2) + 255) / 256, C, B), dim3(256), 0, st, x, w, bias, y, g);
+    else if (stride == 2)
+        hipLaunchKernelGGL(dwconv_nchw_fwd_kernel<2>, dim3((g.Ho * g.Wo + 255) / 256, C, B), dim3(256), 0, st, x, w, bias, y, g);
     else
-        hipLaunchKernelGGL(dwconv_nchw_fwd_kernel, dim3((g.Ho * g.Wo + 255) / 256, C, B), dim3(256), 0, st, x, w, bias, y, g);
+        hipLaunchKernelGGL(dwconv_nchw_fwd_kernel<0>, dim3((g.Ho * g.Wo + 255) / 256, C, B), dim3(256), 0, st, x, w, bias, y, g);
     return (int)hipGetLastError();
 }
 
@@ -271,13 +279,17 @@ extern "C" int mlagg_dwconv3x3_nchw_bwd(const float *x, const float *w, const fl
         if (strips)
             hipLaunchKernelGGL(dwconv_nchw_s1_kernel<true>, dim3((H * (W >> 2) + 255) / 256, C, B), dim3(256), 0, st, dy, w,
                                nullptr, dx, g);
+        else if (stride == 2)
+            hipLaunchKernelGGL(dwconv_nchw_bwd_data_kernel<2>, dim3((H * W + 255) / 256, C, B), dim3(256), 0, st, dy, w, dx, g);
         else
-            hipLaunchKernelGGL(dwconv_nchw_bwd_data_kernel, dim3((H * W + 255) / 256, C, B), dim3(256), 0, st, dy, w, dx, g);
+            hipLaunchKernelGGL(dwconv_nchw_bwd_data_kernel<0>, dim3((H * W + 255) / 256, C, B), dim3(256), 0, st, dy, w, dx, g);
         const int ns = wgrad_slices(g);
         if (strips)
             hipLaunchKernelGGL(dwconv_nchw_s1_bwd_weight_kernel, dim3(ns, C, B), dim3(256), 0, st, x, dy, workspace, g);
+        else if (stride == 2)
+            hipLaunchKernelGGL(dwconv_nchw_bwd_weight_kernel<2>, dim3(ns, C, B), dim3(256), 0, st, x, dy, workspace, g);
         else
-            hipLaunchKernelGGL(dwconv_nchw_bwd_weight_kernel, dim3(ns, C, B), dim3(256), 0, st, x, dy, workspace, g);
+            hipLaunchKernelGGL(dwconv_nchw_bwd_weight_kernel<0>, dim3(ns, C, B), dim3(256), 0, st, x, dy, workspace, g);
         hipLaunchKernelGGL(dwconv_nchw_wgrad_reduce_kernel, dim3((C * 10 + 255) / 256), dim3(256), 0, st, workspace,
                            B * ns, C, dw, dbias);
     }

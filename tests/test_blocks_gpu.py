@@ -223,7 +223,7 @@ def test_layernorm_matches_torch(rows, C, strided):
 
 
 @gpu
-@pytest.mark.parametrize("C,H,W,stride", [(96, 16, 12, 1), (48, 9, 7, 2), (8, 128, 128, 2), (5, 1, 1, 1), (7, 2, 3, 2)])
+@pytest.mark.parametrize("C,H,W,stride", [(96, 16, 12, 1), (48, 9, 7, 2), (8, 128, 128, 2), (5, 1, 1, 1), (7, 2, 3, 2), (4, 7, 8, 1), (3, 33, 36, 1)])
 def test_dwconv3x3_nchw_matches_conv2d(C, H, W, stride):
     from mlagg_unet_amd import ops
     g = torch.Generator().manual_seed(C * H + stride)
