@@ -193,10 +193,7 @@ extern "C" int mlagg_layernorm_bwd(const float *x, int x_stride, const float *dy
         }
     }
     // partial rows are [d(gamma) | d(beta)]: column sums of an (nb x 2C) matrix
-    hipLaunchKernelGGL(mlagg_internal::column_sum_kernel<false>, dim3((C + 63) / 64), dim3(1024), 0, st, workspace, nb,
-                       2 * C, C, dgamma);
-    if (dbeta)
-        hipLaunchKernelGGL(mlagg_internal::column_sum_kernel<false>, dim3((C + 63) / 64), dim3(1024), 0, st,
-                           workspace + C, nb, 2 * C, C, dbeta);
+    hipLaunchKernelGGL(mlagg_internal::column_sum_split_kernel<0>, dim3((2 * C + 63) / 64), dim3(1024), 0, st, workspace, nb,
+                       2 * C, dbeta ? 2 * C : C, C, dgamma, dbeta);
     return (int)hipGetLastError();
 }
