@@ -60,6 +60,8 @@ cross_scan_kernel(const float *__restrict__ tok_c, float *__restrict__ tok_m, co
     const int c0 = blockIdx.y * CH, b = blockIdx.z;
     const int nc = min(CH, g.CB - c0);
     const int tid = threadIdx.x;
+    // 16-byte sequence accesses need H, W, the scale offset and L_cat to be multiples of 4 (all true for power-of-two maps)
+    const bool vec4 = ((H | W | off | g.Lc) & 3) == 0;
     const size_t tokbase = (size_t)b * g.Lc + off;
 
     auto tok_ptr = [&](int ly, int lx, int blk, int c) -> size_t {
@@ -79,6 +81,23 @@ cross_scan_kernel(const float *__restrict__ tok_c, float *__restrict__ tok_m, co
                 }
                 __syncthreads();
             }
+            if (vec4) {
+                // 4 consecutive sequence positions per thread: one 16-byte store instead of four 4-byte ones
+                for (int e = tid; e < TS * (TS / 4) * CH; e += 256) {
+                    const int q = e & 63, c = e >> 6;
+                    const int a = q >> 2, f4 = (q & 3) * 4;      // f4..f4+3 along the direction's own axis
+                    const int ly0 = (k & 1) ? f4 : a, lx0 = (k & 1) ? a : f4;
+                    if (c < nc && y0 + ly0 < H && x0 + lx0 < W) {
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = tile[lds_idx((k & 1) ? ly0 + j : ly0, (k & 1) ? lx0 : lx0 + j, c)];
+                        const int pf = (k & 1) ? (x0 + lx0) * H + y0 + ly0 : (y0 + ly0) * W + x0 + lx0;   // forward position
+                        float *dst = seq_m + ((size_t)b * 4 * g.CB + (size_t)k * g.CB + c0 + c) * g.Lc + off;
+                        if (k & 2) *reinterpret_cast<float4 *>(dst + (H * W - 4 - pf)) = make_float4(v[3], v[2], v[1], v[0]);
+                        else *reinterpret_cast<float4 *>(dst + pf) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+            } else
             for (int e = tid; e < TS * TS * CH; e += 256) {
                 const int q = e & 255, c = e >> 8;
                 const int a = q >> 4, f = q & 15;            // f runs fastest along the direction's own axis
@@ -93,6 +112,30 @@ cross_scan_kernel(const float *__restrict__ tok_c, float *__restrict__ tok_m, co
         for (int k = 0; k < 4; ++k) {
             const bool fresh = (k == 0 || g.nblk > 1);
             __syncthreads();
+            if (vec4) {
+                for (int e = tid; e < TS * (TS / 4) * CH; e += 256) {
+                    const int q = e & 63, c = e >> 6;
+                    const int a = q >> 2, f4 = (q & 3) * 4;
+                    const int ly0 = (k & 1) ? f4 : a, lx0 = (k & 1) ? a : f4;
+                    float v[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (c < nc && y0 + ly0 < H && x0 + lx0 < W) {
+                        const int pf = (k & 1) ? (x0 + lx0) * H + y0 + ly0 : (y0 + ly0) * W + x0 + lx0;
+                        const float *src = seq_c + ((size_t)b * 4 * g.CB + (size_t)k * g.CB + c0 + c) * g.Lc + off;
+                        if (k & 2) {
+                            const float4 r = *reinterpret_cast<const float4 *>(src + (H * W - 4 - pf));
+                            v[0] = r.w; v[1] = r.z; v[2] = r.y; v[3] = r.x;
+                        } else {
+                            const float4 r = *reinterpret_cast<const float4 *>(src + pf);
+                            v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int li = lds_idx((k & 1) ? ly0 + j : ly0, (k & 1) ? lx0 : lx0 + j, c);
+                        if (fresh) tile[li] = v[j]; else tile[li] += v[j];
+                    }
+                }
+            } else
             for (int e = tid; e < TS * TS * CH; e += 256) {
                 const int q = e & 255, c = e >> 8;
                 const int a = q >> 4, f = q & 15;
