@@ -308,14 +308,31 @@ __global__ void selscan_chunk_prefix(const float *__restrict__ A, float *__restr
     const float A2 = A[d * NS + n] * LOG2E;
     float H = 0.f;
     const size_t base = (size_t)b * gm.nchunks * gm.dim + d;
-#pragma unroll 4
-    for (int i = 0; i < gm.nchunks; ++i) {
-        const int c = reverse ? gm.nchunks - 1 - i : i;
-        const size_t row = base + (size_t)c * gm.dim;
-        const float S = cstate[row * NS + n];
-        const float P = fast_exp2(A2 * cdsum[row]);
-        cstate[row * NS + n] = H;
-        H = P * H + S;
+    // groups of 8 chunks: all 16 loads of a group are issued before its 8 dependent updates (the loop is a latency
+    // chain of nchunks steps on ~1 wave per SIMD; with the in-place store between them the loads did not overlap)
+    constexpr int GR = 8;
+    for (int i0 = 0; i0 < gm.nchunks; i0 += GR) {
+        float S[GR], P[GR];
+#pragma unroll
+        for (int j = 0; j < GR; ++j) {
+            const int i = i0 + j;
+            if (i < gm.nchunks) {
+                const size_t row = base + (size_t)(reverse ? gm.nchunks - 1 - i : i) * gm.dim;
+                S[j] = cstate[row * NS + n];
+                P[j] = cdsum[row];
+            } else {
+                S[j] = 0.f; P[j] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < GR; ++j) {
+            const int i = i0 + j;
+            if (i < gm.nchunks) {
+                const size_t row = base + (size_t)(reverse ? gm.nchunks - 1 - i : i) * gm.dim;
+                cstate[row * NS + n] = H;
+                H = fast_exp2(A2 * P[j]) * H + S[j];
+            }
+        }
     }
 }
 
