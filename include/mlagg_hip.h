@@ -48,7 +48,8 @@ int mlagg_profile_collect(double *ms, int *counts);
  *   D, delta_bias      (dim) or NULL
  *   chunk_state        workspace AND saved-for-backward tensor, mlagg_selscan_state_floats() floats:
  *                      [batch][nchunks][dim][N] states entering each 64-step chunk, followed by
- *                      [batch][nchunks][dim] per-chunk sums of softplus'd delta.
+ *                      [batch][nchunks][dim] per-chunk sums of softplus'd delta and
+ *                      [batch][nchunks][3][dim][N] states entering the 2nd..4th 16-step sub-tile of each chunk.
  * ------------------------------------------------------------------------------------------ */
 size_t mlagg_selscan_state_floats(int batch, int dim, int L, int N);
 int mlagg_selscan_fwd(const float *u, const float *delta, const float *A, const float *B, const float *C,
@@ -225,6 +226,10 @@ int mlagg_diff_lambda_bwd(const float *dlam, const float *q1, const float *k1, c
                           const float *saved_exp, int n, float *dq1, float *dk1, float *dq2, float *dk2, void *stream);
 int mlagg_scaled_residual(const float *skip, const float *branch, const float *scale, float *out, int batch,
                           long per_sample, void *stream);
+/* transpose_2d: dst[b][c][r] = src[b][r][c], (batch, R, C) -> contiguous (batch, C, R); src matrices contiguous, src_batch_stride
+ * elements apart (0 = R * C; a channel slice of an NCHW map has a larger one): the NCHW <-> token-major flips
+ * (`x.flatten(2).transpose(1, 2)` / its inverse at nnUNetTrainer_MLAgg_2D_dt_MS.py:878-880, 910; MambaSkip.py:727-733, 747-751). */
+int mlagg_transpose_2d(const float *src, long src_batch_stride, float *dst, int batch, int R, int C, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K9: Dice + cross-entropy statistics and gradient of one deep-supervision level.  Replaces softmax, one-hot scatter,

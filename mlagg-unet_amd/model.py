@@ -232,6 +232,13 @@ class MLLABlock(nn.Module):
         return _TokensToMap.apply(self.forward_tokens(_MapToTokens.apply(x)), h, w)
 
 
+def _flip(t3):
+    """(B, R, C) -> contiguous (B, C, R): the library's tiled transpose on the device, a plain copy elsewhere."""
+    if t3.is_cuda:
+        return ops.transpose_2d(t3)
+    return t3.transpose(1, 2).contiguous()
+
+
 class _MapToTokens(torch.autograd.Function):
     """(B, C, H, W) -> contiguous token-major (B, H*W, C); the gradient comes back as a contiguous NCHW map.
     Both directions are REAL transposes: permute + reshape alone is a strided view, and every residual add,
@@ -242,24 +249,24 @@ class _MapToTokens(torch.autograd.Function):
     def forward(ctx, x):
         B, C, h, w = x.shape
         ctx.hw = (h, w)
-        return x.permute(0, 2, 3, 1).contiguous().view(B, h * w, C)
+        return _flip(x.reshape(B, C, h * w))
 
     @staticmethod
     def backward(ctx, g):
         B, N, C = g.shape
-        return g.transpose(1, 2).contiguous().view(B, C, *ctx.hw)
+        return _flip(g).view(B, C, *ctx.hw)
 
 
 class _TokensToMap(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, h, w):
         B, N, C = t.shape
-        return t.view(B, h, w, C).permute(0, 3, 1, 2).contiguous()
+        return _flip(t).view(B, C, h, w)
 
     @staticmethod
     def backward(ctx, g):
         B, C, h, w = g.shape
-        return g.permute(0, 2, 3, 1).contiguous().view(B, h * w, C), None, None
+        return _flip(g.reshape(B, C, h * w)), None, None
 
 
 class BasicLayer(nn.Module):
@@ -292,7 +299,7 @@ class Project(nn.Module):  # reference T:972-1001
 
     @staticmethod
     def _ln(norm, x):
-        return norm(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2).contiguous()
+        return _TokensToMap.apply(norm(_MapToTokens.apply(x)), x.shape[2], x.shape[3])
 
     def forward(self, x):
         x = self.conv2(self._ln(self.norm1, F.gelu(self.conv1(x))))

@@ -706,3 +706,16 @@ class DiceCEStatsFn(torch.autograd.Function):
 
 def dice_ce_stats(logits, targets):
     return DiceCEStatsFn.apply(len(logits), *logits, *targets)
+
+
+def transpose_2d(src):
+    """(B, R, C) -> (B, C, R) contiguous on the tiled transpose kernel (K8).  The source matrices must be contiguous;
+    their batch stride may be larger than R * C (a channel slice of an NCHW map), anything else is copied first."""
+    _require(src, "src")
+    B, R, C = src.shape
+    if not (src.stride(2) == 1 and src.stride(1) == C and src.stride(0) >= R * C and src.data_ptr() % 16 == 0
+            and (C % 4 or src.stride(0) % 4 == 0)):
+        src = src.contiguous()
+    dst = torch.empty(B, C, R, device=src.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mlagg_transpose_2d(_ptr(src), src.stride(0), _ptr(dst), B, R, C, _stream()), "mlagg_transpose_2d")
+    return dst

@@ -332,3 +332,15 @@ def test_fused_loss_extreme_logits_stay_finite():
     assert torch.isfinite(loss) and abs(float(loss) - float(want)) < 1e-3
     loss.backward()
     assert torch.isfinite(zz.grad).all()
+
+
+@gpu
+@pytest.mark.parametrize("B,R,C", [(2, 64, 64), (3, 130, 48), (1, 7, 5), (2, 33, 96), (1, 4096, 192)])
+def test_transpose_2d_bit_exact(B, R, C):
+    from mlagg_unet_amd import ops
+    x = torch.randn(B, R, C, generator=torch.Generator().manual_seed(R)).to(DEV)
+    assert torch.equal(ops.transpose_2d(x), x.transpose(1, 2).contiguous())
+    if R % 4 == 0:                                   # a channel slice of a wider NCHW map: larger batch stride, no copy
+        wide = torch.randn(B, 2 * R, C, generator=torch.Generator().manual_seed(C)).to(DEV)
+        sl = wide[:, :R]
+        assert torch.equal(ops.transpose_2d(sl), sl.transpose(1, 2).contiguous())
