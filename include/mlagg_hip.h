@@ -230,6 +230,13 @@ int mlagg_scaled_residual(const float *skip, const float *branch, const float *s
  * elements apart (0 = R * C; a channel slice of an NCHW map has a larger one): the NCHW <-> token-major flips
  * (`x.flatten(2).transpose(1, 2)` / its inverse at nnUNetTrainer_MLAgg_2D_dt_MS.py:878-880, 910; MambaSkip.py:727-733, 747-751). */
 int mlagg_transpose_2d(const float *src, long src_batch_stride, float *dst, int batch, int R, int C, void *stream);
+/* Bias gradients.  channel_sum: out[c] = sum over batch and pixels of an NCHW gradient map g (B, C, HW) -- the bias gradient of
+ * the convolutions around the path (torch computes it with a generic reduction inside convolution_backward); workspace:
+ * mlagg_channel_sum_workspace_floats(B, C) floats.  column_sum: out[c] = sum_r x[r][c], x (rows, cols) at row stride x_stride --
+ * the bias gradient of the Linear layers whose GEMMs go to the library (few tokens). */
+size_t mlagg_channel_sum_workspace_floats(int B, int C);
+int mlagg_channel_sum(const float *g, float *out, float *workspace, int B, int C, long HW, void *stream);
+int mlagg_column_sum(const float *x, int x_stride, float *out, int rows, int cols, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K9: Dice + cross-entropy statistics and gradient of one deep-supervision level.  Replaces softmax, one-hot scatter,

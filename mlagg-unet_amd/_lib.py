@@ -59,6 +59,9 @@ SIGNATURES = {
     "mlagg_dice_ce_max_classes": (_I, []),
     "mlagg_dice_ce_stats": (_I, [_F, _F, _F, _F, _F, _I, _I, ctypes.c_long, _S]),
     "mlagg_dice_ce_grad": (_I, [_F, _F, _F, _F, _F, _I, _I, ctypes.c_long, _S]),
+    "mlagg_channel_sum_workspace_floats": (_SZ, [_I, _I]),
+    "mlagg_channel_sum": (_I, [_F, _F, _F, _I, _I, ctypes.c_long, _S]),
+    "mlagg_column_sum": (_I, [_F, _I, _F, _I, _I, _S]),
     "mlagg_transpose_2d": (_I, [_F, ctypes.c_long, _F, _I, _I, _I, _S]),
     "mlagg_gate_fwd": (_I, [_F, _F, _F, _I, _F, ctypes.c_long, _I, _S]),
     "mlagg_gate_bwd": (_I, [_F, _I, _F, _F, _F, _I, _F, _F, _F, ctypes.c_long, _I, _S]),

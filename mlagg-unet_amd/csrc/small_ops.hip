@@ -194,3 +194,63 @@ extern "C" int mlagg_transpose_2d(const float *src, long src_batch_stride, float
                        src_batch_stride);
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Bias gradients.  channel_sum: out[c] = sum_{b, p} g[b][c][p] of an NCHW map (what convolution backward needs for its bias;
+// ATen's generic reduction runs these at 1.3-2 TB/s: 49 us for 63 MB).  column_sum: out[c] = sum_r x[r][c] of a row-major
+// matrix (the bias gradient of the small-M Linear layers that go to the library GEMM).
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void __launch_bounds__(256)
+plane_sum_kernel(const float *__restrict__ g, float *__restrict__ part, int C, long HW)
+{
+    __shared__ float red[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float *p = g + ((size_t)b * C + c) * HW;
+    float s0 = 0.f, s1 = 0.f;
+    const long n4 = ((HW & 3) == 0 && (((uintptr_t)p) & 15) == 0) ? HW >> 2 : 0;
+    for (long i = threadIdx.x; i < n4; i += 512) {
+        const float4 a = reinterpret_cast<const float4 *>(p)[i];
+        s0 += (a.x + a.y) + (a.z + a.w);
+        if (i + 256 < n4) {
+            const float4 b4 = reinterpret_cast<const float4 *>(p)[i + 256];
+            s1 += (b4.x + b4.y) + (b4.z + b4.w);
+        }
+    }
+    for (long i = 4 * n4 + threadIdx.x; i < HW; i += 256) s0 += p[i];
+    float s = s0 + s1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(size_t)b * C + c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+}  // namespace
+
+#include "internal.h"
+
+extern "C" size_t mlagg_channel_sum_workspace_floats(int B, int C) { return (size_t)(B > 0 ? B : 0) * (C > 0 ? C : 0); }
+
+extern "C" int mlagg_channel_sum(const float *g, float *out, float *workspace, int B, int C, long HW, void *stream)
+{
+    if (!g || !out || !workspace) return MLAGG_E_NULLPTR;
+    if (B <= 0 || C <= 0 || HW <= 0 || B > 65535) return MLAGG_E_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MLAGG_TIMED(K_BIAS_GRAD, st);
+    hipLaunchKernelGGL(plane_sum_kernel, dim3(C, B), dim3(256), 0, st, g, workspace, C, HW);
+    hipLaunchKernelGGL(mlagg_internal::column_sum_kernel<false>, dim3((C + 63) / 64), dim3(1024), 0, st, workspace, B, C, C, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mlagg_column_sum(const float *x, int x_stride, float *out, int rows, int cols, void *stream)
+{
+    if (!x || !out) return MLAGG_E_NULLPTR;
+    if (rows <= 0 || cols <= 0 || x_stride < cols) return MLAGG_E_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MLAGG_TIMED(K_BIAS_GRAD, st);
+    hipLaunchKernelGGL(mlagg_internal::column_sum_kernel<false>, dim3((cols + 63) / 64), dim3(1024), 0, st, x, rows, x_stride, cols,
+                       out);
+    return (int)hipGetLastError();
+}

@@ -95,6 +95,26 @@ class DropPath(nn.Module):
         return torch.addcmul(skip, branch, m.view((-1,) + (1,) * (branch.dim() - 1)))
 
 
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d (same parameter names): MIOpen convolution without its bias, then K8's in-place channel bias whose
+    gradient is one plane-sum launch (inside convolution_backward it is a generic ATen reduction at 1.3-2 TB/s)."""
+
+    def forward(self, x):
+        if self.bias is None or not x.is_cuda or self.padding_mode != "zeros":
+            return super().forward(x)
+        y = F.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation, self.groups)
+        return ops.channel_bias(y, self.bias)
+
+
+class ConvTranspose2d(nn.ConvTranspose2d):
+    def forward(self, x, output_size=None):
+        if self.bias is None or not x.is_cuda or output_size is not None:
+            return super().forward(x, output_size)
+        y = F.conv_transpose2d(x, self.weight, None, self.stride, self.padding, self.output_padding, self.groups,
+                               self.dilation)
+        return ops.channel_bias(y, self.bias)
+
+
 class Linear(nn.Linear):
     """nn.Linear (same parameter names) whose weight/bias gradients run on K5w for large token counts."""
 
@@ -145,11 +165,11 @@ class AggregatedAttention(nn.Module):
         if not local:
             self.sr_ratio = sr_ratio
             self.pool_H, self.pool_W = self.H // sr_ratio, self.W // sr_ratio
-            self.sr = nn.Conv2d(dim, dim, 1)
+            self.sr = Conv2d(dim, dim, 1)
             self.norm = LayerNorm(dim)
         self.q = Linear(dim, dim)
         self.kv = Linear(dim, 2 * dim)
-        self.lepe = nn.Conv2d(dim, dim, 3, padding=1, groups=dim)
+        self.lepe = Conv2d(dim, dim, 3, padding=1, groups=dim)
 
     def lambda_full(self):
         return ops.diff_lambda(self.lambda_q1, self.lambda_k1, self.lambda_q2, self.lambda_k2, LAMBDA_INIT)
@@ -194,7 +214,7 @@ class MLLABlock(nn.Module):
         self.norm1 = LayerNorm(dim)
         self.in_proj = Linear(dim, dim)
         self.act_proj = Linear(dim, dim)
-        self.dwc = nn.Conv2d(dim, dim, 3, padding=1, groups=dim)
+        self.dwc = Conv2d(dim, dim, 3, padding=1, groups=dim)
         self.attn = nn.ModuleList([
             AggregatedAttention(dim // 2, input_resolution, num_heads // 2, True, sr_ratio, variant),
             AggregatedAttention(dim // 2, input_resolution, num_heads // 2, False, sr_ratio, variant)])
@@ -290,8 +310,8 @@ class BasicLayer(nn.Module):
 class Project(nn.Module):  # reference T:972-1001
     def __init__(self, cin, cout, stride, last):
         super().__init__()
-        self.conv1 = nn.Conv2d(cin, cout, 3, stride=stride, padding=1)
-        self.conv2 = nn.Conv2d(cout, cout, 3, stride=1, padding=1)
+        self.conv1 = Conv2d(cin, cout, 3, stride=stride, padding=1)
+        self.conv2 = Conv2d(cout, cout, 3, stride=1, padding=1)
         self.norm1 = LayerNorm(cout)
         self.last = last
         if not last:
@@ -320,10 +340,10 @@ class MedNeXtBlock(nn.Module):  # reference T:230-324
     def __init__(self, cin, cout, exp_r, k=3, do_res=True, stride=1):
         super().__init__()
         self.do_res = do_res
-        self.conv1 = nn.Conv2d(cin, cin, k, stride=stride, padding=k // 2, groups=cin)
+        self.conv1 = Conv2d(cin, cin, k, stride=stride, padding=k // 2, groups=cin)
         self.norm = nn.GroupNorm(cin, cin)
-        self.conv2 = nn.Conv2d(cin, exp_r * cin, 1)
-        self.conv3 = nn.Conv2d(exp_r * cin, cout, 1)
+        self.conv2 = Conv2d(cin, exp_r * cin, 1)
+        self.conv3 = Conv2d(exp_r * cin, cout, 1)
 
     def body(self, x):
         # conv1 is depthwise 3x3 (stride 1, or 2 in the down block): K2n instead of MIOpen's naive fallback
@@ -338,7 +358,7 @@ class MedNeXtBlock(nn.Module):  # reference T:230-324
 class MedNeXtDownBlock(MedNeXtBlock):  # reference T:327-366
     def __init__(self, cin, cout, exp_r, k=3):
         super().__init__(cin, cout, exp_r, k, do_res=False, stride=2)
-        self.res_conv = nn.Conv2d(cin, cout, 1, stride=2)
+        self.res_conv = Conv2d(cin, cout, 1, stride=2)
 
     def forward(self, x):
         return self.body(x) + self.res_conv(x)
@@ -347,8 +367,8 @@ class MedNeXtDownBlock(MedNeXtBlock):  # reference T:327-366
 class PatchExpand(nn.Module):  # reference T:479-546
     def __init__(self, cin, cout, k=3):
         super().__init__()
-        self.res_conv = nn.ConvTranspose2d(cin, cout, 1, stride=2)
-        self.conv1 = nn.ConvTranspose2d(cin, cout, k, stride=2, padding=k // 2)
+        self.res_conv = ConvTranspose2d(cin, cout, 1, stride=2)
+        self.conv1 = ConvTranspose2d(cin, cout, k, stride=2, padding=k // 2)
         self.norm = nn.GroupNorm(cin, cin)
 
     def forward(self, x):
@@ -358,7 +378,7 @@ class PatchExpand(nn.Module):  # reference T:479-546
 class OutBlock(nn.Module):  # reference T:549-561
     def __init__(self, cin, n_classes):
         super().__init__()
-        self.conv_out = nn.ConvTranspose2d(cin, n_classes, 1)
+        self.conv_out = ConvTranspose2d(cin, n_classes, 1)
 
     def forward(self, x):
         return self.conv_out(x)
@@ -368,9 +388,9 @@ class _ConvOnly(nn.Module):
     def __init__(self, cin, cout, k, stride=1, transposed=False):
         super().__init__()
         if transposed:
-            self.conv = nn.ConvTranspose2d(cin, cout, k, stride=stride, bias=False)
+            self.conv = ConvTranspose2d(cin, cout, k, stride=stride, bias=False)
         else:
-            self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False)
+            self.conv = Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False)
 
     def forward(self, x):
         return self.conv(x)
@@ -463,7 +483,7 @@ class SS2D_skip(nn.Module):
         self.dt_rank = math.ceil(d_model / 16)
         self.in_proj = Linear(d_model, self.d_inner, bias=False)
         self.conv2d = nn.ModuleList([
-            nn.Conv2d(self.d_inner, self.d_inner, 3, padding=1, groups=self.d_inner) for _ in range(stage_num)])
+            Conv2d(self.d_inner, self.d_inner, 3, padding=1, groups=self.d_inner) for _ in range(stage_num)])
         xp = [nn.Linear(self.d_inner, self.dt_rank + 2 * d_state, bias=False) for _ in range(4)]
         self.x_proj_weight = nn.Parameter(torch.stack([t.weight for t in xp], 0))
         dts = [_dt_init(self.dt_rank, self.d_inner) for _ in range(4)]
@@ -505,7 +525,7 @@ class SS2D_skip(nn.Module):
 class _DWConv(nn.Module):
     def __init__(self, dim):
         super().__init__()
-        self.dwconv = nn.Conv2d(dim, dim, 3, padding=1, groups=dim)
+        self.dwconv = Conv2d(dim, dim, 3, padding=1, groups=dim)
 
 
 class ConvolutionalGLU(nn.Module):  # reference M:559-577
@@ -534,7 +554,7 @@ class VSS_Conv_Block(nn.Module):  # reference M:669-753
         self.norm2 = LayerNorm(hidden_dim)
         self.mlps = nn.ModuleList([ConvolutionalGLU(hidden_dim, hidden_dim * 4) for _ in feature_dims])
         self.conv_branches = nn.ModuleList([
-            nn.Sequential(nn.Conv2d(c, c, 3, padding=1), nn.InstanceNorm2d(c, affine=True), nn.SiLU())
+            nn.Sequential(Conv2d(c, c, 3, padding=1), nn.InstanceNorm2d(c, affine=True), nn.SiLU())
             for c in self.conv_dims])
 
     def forward(self, inputs):

@@ -344,3 +344,35 @@ def test_transpose_2d_bit_exact(B, R, C):
         wide = torch.randn(B, 2 * R, C, generator=torch.Generator().manual_seed(C)).to(DEV)
         sl = wide[:, :R]
         assert torch.equal(ops.transpose_2d(sl), sl.transpose(1, 2).contiguous())
+
+
+@gpu
+@pytest.mark.parametrize("shape", [(3, 7, 12, 20), (2, 5, 9, 7), (1, 96, 64, 64)])
+def test_channel_bias_and_column_sum(shape):
+    """Conv2d / ConvTranspose2d of the product model add their bias through K8 (gradient = plane sums)."""
+    from mlagg_unet_amd import model as PM, ops
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(B, C, H, W, generator=g).to(DEV)
+    conv = PM.Conv2d(C, C + 1, 3, padding=1).to(DEV)
+    ref = torch.nn.Conv2d(C, C + 1, 3, padding=1).to(DEV)
+    ref.load_state_dict(conv.state_dict())
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = conv(xa), ref(xb)
+    assert float((ya - yb).abs().max()) < 1e-5
+    gy = torch.randn(ya.shape, generator=g).to(DEV)
+    ya.backward(gy)
+    yb.backward(gy)
+    assert float((conv.bias.grad - ref.bias.grad).abs().max()) < 1e-4 * max(1.0, float(ref.bias.grad.abs().max()))
+    assert float((conv.weight.grad - ref.weight.grad).abs().max()) < 1e-3 and float((xa.grad - xb.grad).abs().max()) < 1e-4
+    ct, rt = PM.ConvTranspose2d(C, 4, 3, stride=2, padding=1).to(DEV), torch.nn.ConvTranspose2d(C, 4, 3, stride=2, padding=1).to(DEV)
+    rt.load_state_dict(ct.state_dict())
+    za, zb = ct(x), rt(x)
+    assert float((za - zb).abs().max()) < 1e-5
+    za.sum().backward()
+    zb.sum().backward()
+    assert float((ct.bias.grad - rt.bias.grad).abs().max()) < 1e-3 * float(rt.bias.grad.abs().max())
+    m = torch.randn(257, C, generator=g).to(DEV)
+    assert float((ops.column_sum(m) - m.sum(0)).abs().max()) < 1e-4
+    wide = torch.randn(100, 3 * C, generator=g).to(DEV)
+    assert float((ops.column_sum(wide[:, C:2 * C]) - wide[:, C:2 * C].sum(0)).abs().max()) < 1e-4
