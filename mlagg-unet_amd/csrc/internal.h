@@ -63,6 +63,29 @@ column_sum_split_kernel(const float *__restrict__ part, int rows, int pitch, int
     }
 }
 
+// Column sums of a (rows x cols) matrix whose columns alternate between two outputs: even columns -> out0[col / 2], odd -> out1.
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(1024)
+column_sum_interleaved_kernel(const float *__restrict__ part, int rows, int cols, float *__restrict__ out0,
+                              float *__restrict__ out1)
+{
+    __shared__ float red[16][65];
+    const int cx = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    float s = 0.f;
+    if (c < cols)
+        for (int r = rg; r < rows; r += 16) s += part[(size_t)r * cols + c];
+    red[rg][cx] = s;
+    __syncthreads();
+    if (rg == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][cx];
+        float *o = (c & 1) ? out1 : out0;
+        if (o) o[c >> 1] = t;
+    }
+}
+
 size_t dwconv_wgrad_workspace_floats(int batch, int H, int W, int C);
 // dw (C, 9) and dbias (C, may be NULL) are ACCUMULATED into; part = workspace of the size above
 void dwconv_wgrad_launch(const float *x, int x_stride, const float *dy, int dy_stride, const float *pre, float *dw,

@@ -1,0 +1,182 @@
+// K10 -- per-plane normalisation of NCHW maps with the activation that follows it, forward and backward:
+//   y = act( (x - mean_bc) * rstd_bc * gamma_c + beta_c ),   mean / var over the H*W pixels of one (batch, channel) plane.
+// This one kernel pair is
+//   * nn.GroupNorm(C, C)                      of MedNeXtBlock / MedNeXtDownBlock / PatchExpand (reference
+//                                             nnUNetTrainer_MLAgg_2D_dt_MS.py:268-270, 357, 500-502), act = none;
+//   * nn.InstanceNorm2d + LeakyReLU(0.01)     of the MONAI UnetResBlock in encoder0 / decoder0 (structure vendored at
+//                                             MambaSkip.py:581-667; T:1339-1357), gamma = beta = NULL;
+//   * nn.InstanceNorm2d(affine) + SiLU        of the MSMM convolution branch (MambaSkip.py:700-706).
+// ATen runs them as native_group_norm / native_batch_norm (+ a separate activation kernel each way): 2.2 ms per step at
+// config 2.  A workgroup owns one plane: pass 1 sums it from HBM, passes 2 (variance about the mean) and 3 (write) re-read
+// it from L2 (a plane is at most 256 KB); backward the same with two reductions.  d(gamma), d(beta) leave as per-plane
+// partials and are summed over the batch by the shared column-sum kernel.
+// HBM-bound: 8 bytes per element forward, 12 backward.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mlagg_hip.h"
+#include "prof.h"
+#include "internal.h"
+
+namespace {
+
+enum Act { ACT_NONE = 0, ACT_LEAKY = 1, ACT_SILU = 2 };
+
+__device__ __forceinline__ float block_sum(float v, float *red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();                                   // red may still be read from the previous reduction
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__device__ __forceinline__ float act_fwd(float v, int act, float slope)
+{
+    if (act == ACT_LEAKY) return v > 0.f ? v : v * slope;
+    if (act == ACT_SILU) return v / (1.f + __expf(-v));
+    return v;
+}
+
+__device__ __forceinline__ float act_bwd(float v, int act, float slope)      // d act / d v at pre-activation v
+{
+    if (act == ACT_LEAKY) return v > 0.f ? 1.f : slope;
+    if (act == ACT_SILU) {
+        const float s = 1.f / (1.f + __expf(-v));
+        return s * (1.f + v * (1.f - s));
+    }
+    return 1.f;
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+plane_norm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+                      float *__restrict__ y, float *__restrict__ stats, int C, long HW, float eps, int act, float slope)
+{
+    __shared__ float red[4];
+    const long plane = blockIdx.x;
+    const int c = (int)(plane % C);
+    const float *xp = x + plane * HW;
+    float *yp = y + plane * HW;
+    const long n4 = VEC ? HW >> 2 : 0;
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n4; i += 256) {
+        const float4 a = reinterpret_cast<const float4 *>(xp)[i];
+        s += (a.x + a.y) + (a.z + a.w);
+    }
+    for (long i = 4 * n4 + threadIdx.x; i < HW; i += 256) s += xp[i];
+    const float mean = block_sum(s, red) / (float)HW;
+    float q = 0.f;
+    for (long i = threadIdx.x; i < n4; i += 256) {
+        const float4 a = reinterpret_cast<const float4 *>(xp)[i];
+        const float d0 = a.x - mean, d1 = a.y - mean, d2 = a.z - mean, d3 = a.w - mean;
+        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    for (long i = 4 * n4 + threadIdx.x; i < HW; i += 256) { const float d = xp[i] - mean; q += d * d; }
+    const float rstd = rsqrtf(block_sum(q, red) / (float)HW + eps);
+    const float ga = (gamma ? gamma[c] : 1.f) * rstd, be = (beta ? beta[c] : 0.f) - mean * ga;
+    for (long i = threadIdx.x; i < n4; i += 256) {
+        const float4 a = reinterpret_cast<const float4 *>(xp)[i];
+        reinterpret_cast<float4 *>(yp)[i] = make_float4(act_fwd(a.x * ga + be, act, slope), act_fwd(a.y * ga + be, act, slope),
+                                                         act_fwd(a.z * ga + be, act, slope), act_fwd(a.w * ga + be, act, slope));
+    }
+    for (long i = 4 * n4 + threadIdx.x; i < HW; i += 256) yp[i] = act_fwd(xp[i] * ga + be, act, slope);
+    if (threadIdx.x == 0) { stats[2 * plane] = mean; stats[2 * plane + 1] = rstd; }
+}
+
+// g = dy * act'(pre);  dx = rstd * gamma * (g - mean(g) - xhat * mean(g * xhat));  partials: sum g * xhat, sum g
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+plane_norm_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ gamma,
+                      const float *__restrict__ beta, const float *__restrict__ stats, float *__restrict__ dx,
+                      float *__restrict__ part, int C, long HW, int act, float slope)
+{
+    __shared__ float red[4];
+    const long plane = blockIdx.x;
+    const int c = (int)(plane % C);
+    const float *xp = x + plane * HW, *gp = dy + plane * HW;
+    float *dp = dx + plane * HW;
+    const float mean = stats[2 * plane], rstd = stats[2 * plane + 1];
+    const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    const long n4 = VEC ? HW >> 2 : 0;
+    float s1 = 0.f, s2 = 0.f;
+    auto term = [&](float xv, float gv, float &xh) {
+        xh = (xv - mean) * rstd;
+        return act == ACT_NONE ? gv : gv * act_bwd(xh * ga + be, act, slope);
+    };
+    for (long i = threadIdx.x; i < n4; i += 256) {
+        const float4 a = reinterpret_cast<const float4 *>(xp)[i], g4 = reinterpret_cast<const float4 *>(gp)[i];
+        float xh;
+        float t = term(a.x, g4.x, xh); s1 += t; s2 += t * xh;
+        t = term(a.y, g4.y, xh); s1 += t; s2 += t * xh;
+        t = term(a.z, g4.z, xh); s1 += t; s2 += t * xh;
+        t = term(a.w, g4.w, xh); s1 += t; s2 += t * xh;
+    }
+    for (long i = 4 * n4 + threadIdx.x; i < HW; i += 256) {
+        float xh;
+        const float t = term(xp[i], gp[i], xh);
+        s1 += t; s2 += t * xh;
+    }
+    const float S1 = block_sum(s1, red), S2 = block_sum(s2, red);
+    const float m1 = S1 / (float)HW, m2 = S2 / (float)HW, k = rstd * ga;
+    for (long i = threadIdx.x; i < n4; i += 256) {
+        const float4 a = reinterpret_cast<const float4 *>(xp)[i], g4 = reinterpret_cast<const float4 *>(gp)[i];
+        float xh;
+        float4 o;
+        float t = term(a.x, g4.x, xh); o.x = k * (t - m1 - xh * m2);
+        t = term(a.y, g4.y, xh); o.y = k * (t - m1 - xh * m2);
+        t = term(a.z, g4.z, xh); o.z = k * (t - m1 - xh * m2);
+        t = term(a.w, g4.w, xh); o.w = k * (t - m1 - xh * m2);
+        reinterpret_cast<float4 *>(dp)[i] = o;
+    }
+    for (long i = 4 * n4 + threadIdx.x; i < HW; i += 256) {
+        float xh;
+        const float t = term(xp[i], gp[i], xh);
+        dp[i] = k * (t - m1 - xh * m2);
+    }
+    if (threadIdx.x == 0 && part) { part[2 * plane] = S2; part[2 * plane + 1] = S1; }     // d(gamma), d(beta) of this plane
+}
+
+int check(int B, int C, long HW, int act)
+{
+    if (B <= 0 || C <= 0 || HW <= 0 || (long)B * C > 2147483647L || act < 0 || act > 2) return MLAGG_E_UNSUPPORTED;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t mlagg_plane_norm_bwd_workspace_floats(int B, int C) { return (size_t)(B > 0 ? B : 0) * (C > 0 ? C : 0) * 2; }
+
+extern "C" int mlagg_plane_norm_fwd(const float *x, const float *gamma, const float *beta, float *y, float *stats, int B, int C,
+                                    long HW, float eps, int act, float slope, void *stream)
+{
+    if (!x || !y || !stats) return MLAGG_E_NULLPTR;
+    if (int rc = check(B, C, HW, act)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool vec = (HW & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
+    MLAGG_TIMED(K_PLANE_NORM_FWD, st);
+    if (vec) hipLaunchKernelGGL(plane_norm_fwd_kernel<true>, dim3(B * C), dim3(256), 0, st, x, gamma, beta, y, stats, C, HW, eps, act, slope);
+    else hipLaunchKernelGGL(plane_norm_fwd_kernel<false>, dim3(B * C), dim3(256), 0, st, x, gamma, beta, y, stats, C, HW, eps, act, slope);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mlagg_plane_norm_bwd(const float *x, const float *dy, const float *gamma, const float *beta, const float *stats,
+                                    float *dx, float *dgamma, float *dbeta, float *workspace, int B, int C, long HW, int act,
+                                    float slope, void *stream)
+{
+    if (!x || !dy || !stats || !dx || ((dgamma || dbeta) && !workspace)) return MLAGG_E_NULLPTR;
+    if (int rc = check(B, C, HW, act)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool vec = (HW & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0;
+    float *part = (dgamma || dbeta) ? workspace : nullptr;
+    {
+        MLAGG_TIMED(K_PLANE_NORM_BWD, st);
+        if (vec) hipLaunchKernelGGL(plane_norm_bwd_kernel<true>, dim3(B * C), dim3(256), 0, st, x, dy, gamma, beta, stats, dx, part, C, HW, act, slope);
+        else hipLaunchKernelGGL(plane_norm_bwd_kernel<false>, dim3(B * C), dim3(256), 0, st, x, dy, gamma, beta, stats, dx, part, C, HW, act, slope);
+    }
+    if (part)           // partials are a (B) x (2C) matrix [c][dgamma | dbeta] interleaved: columns 2c, 2c+1
+        hipLaunchKernelGGL(mlagg_internal::column_sum_interleaved_kernel<0>, dim3((2 * C + 63) / 64), dim3(1024), 0, st, part, B,
+                           2 * C, dgamma, dbeta);
+    return (int)hipGetLastError();
+}

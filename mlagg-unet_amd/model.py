@@ -115,6 +115,23 @@ class ConvTranspose2d(nn.ConvTranspose2d):
         return ops.channel_bias(y, self.bias)
 
 
+class GroupNorm(nn.GroupNorm):
+    """nn.GroupNorm (same parameter names); with one channel per group -- every use on the path -- K10."""
+
+    def forward(self, x):
+        if self.num_groups == self.num_channels and x.is_cuda and x.dim() == 4:
+            return ops.plane_norm(x, self.weight, self.bias, self.eps)
+        return super().forward(x)
+
+
+def _instance_norm_act(norm, x, act=ops.ACT_NONE, slope=0.0):
+    """nn.InstanceNorm2d `norm` followed by the activation, fused on K10 (plain modules off the device)."""
+    if x.is_cuda and not norm.track_running_stats:
+        return ops.plane_norm(x, norm.weight, norm.bias, norm.eps, act, slope)
+    y = norm(x)
+    return F.leaky_relu(y, slope) if act == ops.ACT_LEAKY else (F.silu(y) if act == ops.ACT_SILU else y)
+
+
 class Linear(nn.Linear):
     """nn.Linear (same parameter names) whose weight/bias gradients run on K5w for large token counts."""
 
@@ -341,7 +358,7 @@ class MedNeXtBlock(nn.Module):  # reference T:230-324
         super().__init__()
         self.do_res = do_res
         self.conv1 = Conv2d(cin, cin, k, stride=stride, padding=k // 2, groups=cin)
-        self.norm = nn.GroupNorm(cin, cin)
+        self.norm = GroupNorm(cin, cin)
         self.conv2 = Conv2d(cin, exp_r * cin, 1)
         self.conv3 = Conv2d(exp_r * cin, cout, 1)
 
@@ -369,7 +386,7 @@ class PatchExpand(nn.Module):  # reference T:479-546
         super().__init__()
         self.res_conv = ConvTranspose2d(cin, cout, 1, stride=2)
         self.conv1 = ConvTranspose2d(cin, cout, k, stride=2, padding=k // 2)
-        self.norm = nn.GroupNorm(cin, cin)
+        self.norm = GroupNorm(cin, cin)
 
     def forward(self, x):
         return F.pad(self.conv1(self.norm(x)) , (1, 0, 1, 0)) + F.pad(self.res_conv(x), (1, 0, 1, 0))
@@ -410,9 +427,9 @@ class UnetResBlock(nn.Module):
             self.norm3 = nn.InstanceNorm2d(cout)
 
     def forward(self, x):
-        out = F.leaky_relu(self.norm1(self.conv1(x)), 0.01)
-        out = self.norm2(self.conv2(out))
-        res = self.norm3(self.conv3(x)) if hasattr(self, "conv3") else x
+        out = _instance_norm_act(self.norm1, self.conv1(x), ops.ACT_LEAKY, 0.01)
+        out = _instance_norm_act(self.norm2, self.conv2(out))
+        res = _instance_norm_act(self.norm3, self.conv3(x)) if hasattr(self, "conv3") else x
         return F.leaky_relu(out + res, 0.01)
 
 
@@ -571,7 +588,8 @@ class VSS_Conv_Block(nn.Module):  # reference M:669-753
         for i, (mi, (H, W)) in enumerate(zip(m.split(Ls, dim=1), HW)):
             mi = self.drop_path.residual(mi, self.mlps[i](mi, H, W))
             mi = _TokensToMap.apply(mi.contiguous(), H, W)      # real transpose: keeps the gradient token-major
-            outs.append(torch.cat([mi, self.conv_branches[i](halves[i][1])], dim=1))
+            conv, norm = self.conv_branches[i][0], self.conv_branches[i][1]          # [2] is the SiLU fused into K10
+            outs.append(torch.cat([mi, _instance_norm_act(norm, conv(halves[i][1]), ops.ACT_SILU)], dim=1))
         return outs
 
 

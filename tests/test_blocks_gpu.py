@@ -376,3 +376,38 @@ def test_channel_bias_and_column_sum(shape):
     assert float((ops.column_sum(m) - m.sum(0)).abs().max()) < 1e-4
     wide = torch.randn(100, 3 * C, generator=g).to(DEV)
     assert float((ops.column_sum(wide[:, C:2 * C]) - wide[:, C:2 * C].sum(0)).abs().max()) < 1e-4
+
+
+@gpu
+@pytest.mark.parametrize("B,C,H,W", [(3, 6, 16, 12), (2, 5, 7, 9), (1, 48, 64, 64)])
+@pytest.mark.parametrize("kind", ["group", "instance_leaky", "instance_affine_silu"])
+def test_plane_norm_matches_torch(B, C, H, W, kind):
+    """K10 against nn.GroupNorm(C, C) / nn.InstanceNorm2d (+ LeakyReLU 0.01 / SiLU), forward and all gradients."""
+    from mlagg_unet_amd import ops
+    g = torch.Generator().manual_seed(H)
+    x = (torch.randn(B, C, H, W, generator=g) * 2 + 0.5).to(DEV)
+    gamma = (torch.randn(C, generator=g) * 0.5 + 1).to(DEV)
+    beta = torch.randn(C, generator=g).to(DEV)
+    gy = torch.randn(B, C, H, W, generator=g).to(DEV)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    if kind == "group":
+        ga, ba = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        gb, bb = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        ya = ops.plane_norm(xa, ga, ba, 1e-5)
+        yb = F.group_norm(xb, C, gb, bb, 1e-5)
+    elif kind == "instance_leaky":
+        ga = ba = gb = bb = None
+        ya = ops.plane_norm(xa, None, None, 1e-5, ops.ACT_LEAKY, 0.01)
+        yb = F.leaky_relu(F.instance_norm(xb, eps=1e-5), 0.01)
+    else:
+        ga, ba = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        gb, bb = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        ya = ops.plane_norm(xa, ga, ba, 1e-5, ops.ACT_SILU)
+        yb = F.silu(F.instance_norm(xb, weight=gb, bias=bb, eps=1e-5))
+    assert float((ya - yb).abs().max()) < 2e-5
+    ya.backward(gy)
+    yb.backward(gy)
+    assert float((xa.grad - xb.grad).abs().max()) < 5e-5 * max(1.0, float(xb.grad.abs().max()))
+    if ga is not None:
+        assert float((ga.grad - gb.grad).abs().max()) < 1e-4 * max(1.0, float(gb.grad.abs().max()))
+        assert float((ba.grad - bb.grad).abs().max()) < 1e-4 * max(1.0, float(bb.grad.abs().max()))
