@@ -17,9 +17,14 @@ import re
 def family(n):
     if n.startswith("Cijk_"):
         return "GEMM (rocBLAS/hipBLASLt)"
-    for key, lab in (("selscan", "HIP K1 selective scan"), ("dwconv", "HIP K2 depthwise conv"),
+    for key, lab in (("selscan", "HIP K1 selective scan"), ("cross_scan_kernel", "HIP K1' cross-scan / merge"),
+                     ("dwconv", "HIP K2 depthwise conv"),
                      ("local_attn", "HIP K3 local diff-attention"), ("pooled_attn", "HIP K4 pooled diff-attention"),
-                     ("linear_wgrad", "HIP K5w linear weight-grad")):
+                     ("linear_wgrad", "HIP K5w linear weight-grad"), ("linear_mfma", "HIP K5 projections (fwd, dx)"),
+                     ("layernorm_", "HIP K6 LayerNorm"), ("column_sum", "HIP K6/K8 column sums"), ("gate_", "HIP K7 gate"),
+                     ("row_scale", "HIP K8 small ops"), ("diff_lambda", "HIP K8 small ops"),
+                     ("transpose_tile", "HIP K8 small ops"), ("plane_sum", "HIP K8 small ops"),
+                     ("dice_ce", "HIP K9 fused loss"), ("plane_norm", "HIP K10 plane norm + activation")):
         if key in n:
             return lab
     if re.search(r"miopen|igemm|naive_conv|Im2d2Col|Col2Im|batched_transpose|gridwise|conv|Conv|SubTensor|transpose_", n):
