@@ -257,18 +257,20 @@ int mlagg_dice_ce_grad(const float *logits, const float *target, const float *g_
 /* ------------------------------------------------------------------------------------------
  * K10: per-plane normalisation of an NCHW map fused with the activation that follows it:
  *   y = act((x - mean_bc) * rstd_bc * gamma_c + beta_c),  statistics over the HW pixels of each (batch, channel) plane.
- * gamma / beta (C) may be NULL (1 / 0).  act: 0 none, 1 LeakyReLU(slope), 2 SiLU.  Replaces nn.GroupNorm(C, C)
+ * gamma / beta (C) may be NULL (1 / 0).  act: 0 none, 1 LeakyReLU(slope), 2 SiLU.  res (B, C, HW) or NULL is added before the
+ * activation (the residual sum of the UnetResBlock, MambaSkip.py:662-666): y = act(norm(x) + res); backward then also writes
+ * dres (may be NULL).  Replaces nn.GroupNorm(C, C)
  * (nnUNetTrainer_MLAgg_2D_dt_MS.py:268-270, 357, 500-502), nn.InstanceNorm2d + LeakyReLU(0.01) of the MONAI UnetResBlock
  * (T:1339-1357; structure at MambaSkip.py:581-667) and nn.InstanceNorm2d(affine) + SiLU (MambaSkip.py:700-706).
  * stats (B*C, 2) receives mean and rstd for the backward, which overwrites dx and, when non-NULL, dgamma / dbeta (C);
  * workspace: mlagg_plane_norm_bwd_workspace_floats(B, C) floats (needed only with dgamma / dbeta).
  * ------------------------------------------------------------------------------------------ */
-int mlagg_plane_norm_fwd(const float *x, const float *gamma, const float *beta, float *y, float *stats, int B, int C, long HW,
-                         float eps, int act, float slope, void *stream);
+int mlagg_plane_norm_fwd(const float *x, const float *gamma, const float *beta, const float *res, float *y, float *stats, int B,
+                         int C, long HW, float eps, int act, float slope, void *stream);
 size_t mlagg_plane_norm_bwd_workspace_floats(int B, int C);
-int mlagg_plane_norm_bwd(const float *x, const float *dy, const float *gamma, const float *beta, const float *stats, float *dx,
-                         float *dgamma, float *dbeta, float *workspace, int B, int C, long HW, int act, float slope,
-                         void *stream);
+int mlagg_plane_norm_bwd(const float *x, const float *dy, const float *gamma, const float *beta, const float *res,
+                         const float *stats, float *dx, float *dres, float *dgamma, float *dbeta, float *workspace, int B, int C,
+                         long HW, int act, float slope, void *stream);
 
 #ifdef __cplusplus
 }

@@ -52,13 +52,15 @@ __device__ __forceinline__ float act_bwd(float v, int act, float slope)      // 
 template <bool VEC>
 __global__ void __launch_bounds__(256)
 plane_norm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
-                      float *__restrict__ y, float *__restrict__ stats, int C, long HW, float eps, int act, float slope)
+                      const float *__restrict__ res, float *__restrict__ y, float *__restrict__ stats, int C, long HW,
+                      float eps, int act, float slope)
 {
     __shared__ float red[4];
     const long plane = blockIdx.x;
     const int c = (int)(plane % C);
     const float *xp = x + plane * HW;
     float *yp = y + plane * HW;
+    const float *rp = res ? res + plane * HW : nullptr;
     const long n4 = VEC ? HW >> 2 : 0;
     float s = 0.f;
     for (long i = threadIdx.x; i < n4; i += 256) {
@@ -78,10 +80,11 @@ plane_norm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gam
     const float ga = (gamma ? gamma[c] : 1.f) * rstd, be = (beta ? beta[c] : 0.f) - mean * ga;
     for (long i = threadIdx.x; i < n4; i += 256) {
         const float4 a = reinterpret_cast<const float4 *>(xp)[i];
-        reinterpret_cast<float4 *>(yp)[i] = make_float4(act_fwd(a.x * ga + be, act, slope), act_fwd(a.y * ga + be, act, slope),
-                                                         act_fwd(a.z * ga + be, act, slope), act_fwd(a.w * ga + be, act, slope));
+        const float4 r = rp ? reinterpret_cast<const float4 *>(rp)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4 *>(yp)[i] = make_float4(act_fwd(a.x * ga + be + r.x, act, slope), act_fwd(a.y * ga + be + r.y, act, slope),
+                                                         act_fwd(a.z * ga + be + r.z, act, slope), act_fwd(a.w * ga + be + r.w, act, slope));
     }
-    for (long i = 4 * n4 + threadIdx.x; i < HW; i += 256) yp[i] = act_fwd(xp[i] * ga + be, act, slope);
+    for (long i = 4 * n4 + threadIdx.x; i < HW; i += 256) yp[i] = act_fwd(xp[i] * ga + be + (rp ? rp[i] : 0.f), act, slope);
     if (threadIdx.x == 0) { stats[2 * plane] = mean; stats[2 * plane + 1] = rstd; }
 }
 
@@ -89,51 +92,59 @@ plane_norm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gam
 template <bool VEC>
 __global__ void __launch_bounds__(256)
 plane_norm_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ gamma,
-                      const float *__restrict__ beta, const float *__restrict__ stats, float *__restrict__ dx,
-                      float *__restrict__ part, int C, long HW, int act, float slope)
+                      const float *__restrict__ beta, const float *__restrict__ res, const float *__restrict__ stats,
+                      float *__restrict__ dx, float *__restrict__ dres, float *__restrict__ part, int C, long HW, int act,
+                      float slope)
 {
     __shared__ float red[4];
     const long plane = blockIdx.x;
     const int c = (int)(plane % C);
     const float *xp = x + plane * HW, *gp = dy + plane * HW;
     float *dp = dx + plane * HW;
+    const float *rp = res ? res + plane * HW : nullptr;
+    float *drp = dres ? dres + plane * HW : nullptr;
     const float mean = stats[2 * plane], rstd = stats[2 * plane + 1];
     const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
     const long n4 = VEC ? HW >> 2 : 0;
     float s1 = 0.f, s2 = 0.f;
-    auto term = [&](float xv, float gv, float &xh) {
+    auto term = [&](float xv, float gv, float rv, float &xh) {
         xh = (xv - mean) * rstd;
-        return act == ACT_NONE ? gv : gv * act_bwd(xh * ga + be, act, slope);
+        return act == ACT_NONE ? gv : gv * act_bwd(xh * ga + be + rv, act, slope);
     };
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (long i = threadIdx.x; i < n4; i += 256) {
         const float4 a = reinterpret_cast<const float4 *>(xp)[i], g4 = reinterpret_cast<const float4 *>(gp)[i];
+        const float4 r = rp ? reinterpret_cast<const float4 *>(rp)[i] : z4;
         float xh;
-        float t = term(a.x, g4.x, xh); s1 += t; s2 += t * xh;
-        t = term(a.y, g4.y, xh); s1 += t; s2 += t * xh;
-        t = term(a.z, g4.z, xh); s1 += t; s2 += t * xh;
-        t = term(a.w, g4.w, xh); s1 += t; s2 += t * xh;
+        float t = term(a.x, g4.x, r.x, xh); s1 += t; s2 += t * xh;
+        t = term(a.y, g4.y, r.y, xh); s1 += t; s2 += t * xh;
+        t = term(a.z, g4.z, r.z, xh); s1 += t; s2 += t * xh;
+        t = term(a.w, g4.w, r.w, xh); s1 += t; s2 += t * xh;
     }
     for (long i = 4 * n4 + threadIdx.x; i < HW; i += 256) {
         float xh;
-        const float t = term(xp[i], gp[i], xh);
+        const float t = term(xp[i], gp[i], rp ? rp[i] : 0.f, xh);
         s1 += t; s2 += t * xh;
     }
     const float S1 = block_sum(s1, red), S2 = block_sum(s2, red);
     const float m1 = S1 / (float)HW, m2 = S2 / (float)HW, k = rstd * ga;
     for (long i = threadIdx.x; i < n4; i += 256) {
         const float4 a = reinterpret_cast<const float4 *>(xp)[i], g4 = reinterpret_cast<const float4 *>(gp)[i];
+        const float4 r = rp ? reinterpret_cast<const float4 *>(rp)[i] : z4;
         float xh;
-        float4 o;
-        float t = term(a.x, g4.x, xh); o.x = k * (t - m1 - xh * m2);
-        t = term(a.y, g4.y, xh); o.y = k * (t - m1 - xh * m2);
-        t = term(a.z, g4.z, xh); o.z = k * (t - m1 - xh * m2);
-        t = term(a.w, g4.w, xh); o.w = k * (t - m1 - xh * m2);
+        float4 o, tr;
+        float t = term(a.x, g4.x, r.x, xh); o.x = k * (t - m1 - xh * m2); tr.x = t;
+        t = term(a.y, g4.y, r.y, xh); o.y = k * (t - m1 - xh * m2); tr.y = t;
+        t = term(a.z, g4.z, r.z, xh); o.z = k * (t - m1 - xh * m2); tr.z = t;
+        t = term(a.w, g4.w, r.w, xh); o.w = k * (t - m1 - xh * m2); tr.w = t;
         reinterpret_cast<float4 *>(dp)[i] = o;
+        if (drp) reinterpret_cast<float4 *>(drp)[i] = tr;          // gradient of the residual input
     }
     for (long i = 4 * n4 + threadIdx.x; i < HW; i += 256) {
         float xh;
-        const float t = term(xp[i], gp[i], xh);
+        const float t = term(xp[i], gp[i], rp ? rp[i] : 0.f, xh);
         dp[i] = k * (t - m1 - xh * m2);
+        if (drp) drp[i] = t;
     }
     if (threadIdx.x == 0 && part) { part[2 * plane] = S2; part[2 * plane + 1] = S1; }     // d(gamma), d(beta) of this plane
 }
@@ -161,13 +172,15 @@ constexpr int NV = 16;
 template <int NT>
 __global__ void __launch_bounds__(NT)
 plane_norm_fwd_reg_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
-                          float *__restrict__ y, float *__restrict__ stats, int C, long HW, float eps, int act, float slope)
+                          const float *__restrict__ res, float *__restrict__ y, float *__restrict__ stats, int C, long HW,
+                          float eps, int act, float slope)
 {
     __shared__ float red[NT / 64];
     const long plane = blockIdx.x;
     const int c = (int)(plane % C);
     const float4 *xp = reinterpret_cast<const float4 *>(x + plane * HW);
     float4 *yp = reinterpret_cast<float4 *>(y + plane * HW);
+    const float4 *rp = res ? reinterpret_cast<const float4 *>(res + plane * HW) : nullptr;
     const int n4 = (int)(HW >> 2);
     float4 v[NV];
     float s = 0.f;
@@ -191,9 +204,11 @@ plane_norm_fwd_reg_kernel(const float *__restrict__ x, const float *__restrict__
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = threadIdx.x + i * NT;
-        if (idx < n4)
-            yp[idx] = make_float4(act_fwd(v[i].x * ga + be, act, slope), act_fwd(v[i].y * ga + be, act, slope),
-                                  act_fwd(v[i].z * ga + be, act, slope), act_fwd(v[i].w * ga + be, act, slope));
+        if (idx < n4) {
+            const float4 r = rp ? rp[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+            yp[idx] = make_float4(act_fwd(v[i].x * ga + be + r.x, act, slope), act_fwd(v[i].y * ga + be + r.y, act, slope),
+                                  act_fwd(v[i].z * ga + be + r.z, act, slope), act_fwd(v[i].w * ga + be + r.w, act, slope));
+        }
     }
     if (threadIdx.x == 0) { stats[2 * plane] = mean; stats[2 * plane + 1] = rstd; }
 }
@@ -208,34 +223,34 @@ int check(int B, int C, long HW, int act)
 
 extern "C" size_t mlagg_plane_norm_bwd_workspace_floats(int B, int C) { return (size_t)(B > 0 ? B : 0) * (C > 0 ? C : 0) * 2; }
 
-extern "C" int mlagg_plane_norm_fwd(const float *x, const float *gamma, const float *beta, float *y, float *stats, int B, int C,
-                                    long HW, float eps, int act, float slope, void *stream)
+extern "C" int mlagg_plane_norm_fwd(const float *x, const float *gamma, const float *beta, const float *res, float *y, float *stats,
+                                    int B, int C, long HW, float eps, int act, float slope, void *stream)
 {
     if (!x || !y || !stats) return MLAGG_E_NULLPTR;
     if (int rc = check(B, C, HW, act)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool vec = (HW & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
+    const bool vec = (HW & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)res)) & 15) == 0;
     MLAGG_TIMED(K_PLANE_NORM_FWD, st);
-    if (vec && HW <= 256 * 4 * NV) hipLaunchKernelGGL(plane_norm_fwd_reg_kernel<256>, dim3(B * C), dim3(256), 0, st, x, gamma, beta, y, stats, C, HW, eps, act, slope);
-    else if (vec && HW <= 1024 * 4 * NV) hipLaunchKernelGGL(plane_norm_fwd_reg_kernel<1024>, dim3(B * C), dim3(1024), 0, st, x, gamma, beta, y, stats, C, HW, eps, act, slope);
-    else if (vec) hipLaunchKernelGGL(plane_norm_fwd_kernel<true>, dim3(B * C), dim3(256), 0, st, x, gamma, beta, y, stats, C, HW, eps, act, slope);
-    else hipLaunchKernelGGL(plane_norm_fwd_kernel<false>, dim3(B * C), dim3(256), 0, st, x, gamma, beta, y, stats, C, HW, eps, act, slope);
+    if (vec && HW <= 256 * 4 * NV) hipLaunchKernelGGL(plane_norm_fwd_reg_kernel<256>, dim3(B * C), dim3(256), 0, st, x, gamma, beta, res, y, stats, C, HW, eps, act, slope);
+    else if (vec && HW <= 1024 * 4 * NV) hipLaunchKernelGGL(plane_norm_fwd_reg_kernel<1024>, dim3(B * C), dim3(1024), 0, st, x, gamma, beta, res, y, stats, C, HW, eps, act, slope);
+    else if (vec) hipLaunchKernelGGL(plane_norm_fwd_kernel<true>, dim3(B * C), dim3(256), 0, st, x, gamma, beta, res, y, stats, C, HW, eps, act, slope);
+    else hipLaunchKernelGGL(plane_norm_fwd_kernel<false>, dim3(B * C), dim3(256), 0, st, x, gamma, beta, res, y, stats, C, HW, eps, act, slope);
     return (int)hipGetLastError();
 }
 
-extern "C" int mlagg_plane_norm_bwd(const float *x, const float *dy, const float *gamma, const float *beta, const float *stats,
-                                    float *dx, float *dgamma, float *dbeta, float *workspace, int B, int C, long HW, int act,
-                                    float slope, void *stream)
+extern "C" int mlagg_plane_norm_bwd(const float *x, const float *dy, const float *gamma, const float *beta, const float *res,
+                                    const float *stats, float *dx, float *dres, float *dgamma, float *dbeta, float *workspace,
+                                    int B, int C, long HW, int act, float slope, void *stream)
 {
     if (!x || !dy || !stats || !dx || ((dgamma || dbeta) && !workspace)) return MLAGG_E_NULLPTR;
     if (int rc = check(B, C, HW, act)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool vec = (HW & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0;
+    const bool vec = (HW & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)res) | ((uintptr_t)dres)) & 15) == 0;
     float *part = (dgamma || dbeta) ? workspace : nullptr;
     {
         MLAGG_TIMED(K_PLANE_NORM_BWD, st);
-        if (vec) hipLaunchKernelGGL(plane_norm_bwd_kernel<true>, dim3(B * C), dim3(256), 0, st, x, dy, gamma, beta, stats, dx, part, C, HW, act, slope);
-        else hipLaunchKernelGGL(plane_norm_bwd_kernel<false>, dim3(B * C), dim3(256), 0, st, x, dy, gamma, beta, stats, dx, part, C, HW, act, slope);
+        if (vec) hipLaunchKernelGGL(plane_norm_bwd_kernel<true>, dim3(B * C), dim3(256), 0, st, x, dy, gamma, beta, res, stats, dx, dres, part, C, HW, act, slope);
+        else hipLaunchKernelGGL(plane_norm_bwd_kernel<false>, dim3(B * C), dim3(256), 0, st, x, dy, gamma, beta, res, stats, dx, dres, part, C, HW, act, slope);
     }
     if (part)           // partials are a (B) x (2C) matrix [c][dgamma | dbeta] interleaved: columns 2c, 2c+1
         hipLaunchKernelGGL(mlagg_internal::column_sum_interleaved_kernel<0>, dim3((2 * C + 63) / 64), dim3(1024), 0, st, part, B,

@@ -124,11 +124,11 @@ class GroupNorm(nn.GroupNorm):
         return super().forward(x)
 
 
-def _instance_norm_act(norm, x, act=ops.ACT_NONE, slope=0.0):
-    """nn.InstanceNorm2d `norm` followed by the activation, fused on K10 (plain modules off the device)."""
+def _instance_norm_act(norm, x, act=ops.ACT_NONE, slope=0.0, res=None):
+    """act(nn.InstanceNorm2d `norm`(x) + res), fused on K10 (plain modules off the device)."""
     if x.is_cuda and not norm.track_running_stats:
-        return ops.plane_norm(x, norm.weight, norm.bias, norm.eps, act, slope)
-    y = norm(x)
+        return ops.plane_norm(x, norm.weight, norm.bias, norm.eps, act, slope, res)
+    y = norm(x) if res is None else norm(x) + res
     return F.leaky_relu(y, slope) if act == ops.ACT_LEAKY else (F.silu(y) if act == ops.ACT_SILU else y)
 
 
@@ -428,9 +428,8 @@ class UnetResBlock(nn.Module):
 
     def forward(self, x):
         out = _instance_norm_act(self.norm1, self.conv1(x), ops.ACT_LEAKY, 0.01)
-        out = _instance_norm_act(self.norm2, self.conv2(out))
         res = _instance_norm_act(self.norm3, self.conv3(x)) if hasattr(self, "conv3") else x
-        return F.leaky_relu(out + res, 0.01)
+        return _instance_norm_act(self.norm2, self.conv2(out), ops.ACT_LEAKY, 0.01, res)       # act(norm2(.) + res)
 
 
 class UnetrBasicBlock(nn.Module):

@@ -759,39 +759,41 @@ ACT_NONE, ACT_LEAKY, ACT_SILU = 0, 1, 2
 
 
 class PlaneNormFn(torch.autograd.Function):
-    """K10: per-(batch, channel)-plane normalisation of an NCHW map fused with the activation that follows it
-    (GroupNorm(C, C); InstanceNorm2d + LeakyReLU; InstanceNorm2d(affine) + SiLU)."""
+    """K10: per-(batch, channel)-plane normalisation of an NCHW map fused with what follows it: y = act(norm(x) + res)
+    (GroupNorm(C, C); InstanceNorm2d + LeakyReLU; InstanceNorm2d(affine) + SiLU; the residual sum of the UnetResBlock)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, act, slope):
+    def forward(ctx, x, gamma, beta, res, eps, act, slope):
         x = _require(x.contiguous(), "x")
+        res = None if res is None else _require(res.contiguous(), "res", x.shape)
         B, C = x.shape[:2]
         hw = x.numel() // (B * C)
         y = torch.empty_like(x)
         stats = torch.empty(B * C, 2, device=x.device, dtype=torch.float32)
-        _lib.check(_lib.lib().mlagg_plane_norm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), B, C, hw, float(eps),
-                                                   int(act), float(slope), _stream()), "mlagg_plane_norm_fwd")
-        ctx.save_for_backward(x, gamma, beta, stats)
+        _lib.check(_lib.lib().mlagg_plane_norm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(res), _ptr(y), _ptr(stats), B, C, hw,
+                                                   float(eps), int(act), float(slope), _stream()), "mlagg_plane_norm_fwd")
+        ctx.save_for_backward(x, gamma, beta, res, stats)
         ctx.meta = (int(act), float(slope))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, beta, stats = ctx.saved_tensors
+        x, gamma, beta, res, stats = ctx.saved_tensors
         act, slope = ctx.meta
         dy = _require(dy.contiguous(), "dy")
         B, C = x.shape[:2]
         hw = x.numel() // (B * C)
         lib = _lib.lib()
         dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (res is not None and ctx.needs_input_grad[3]) else None
         dg = torch.empty_like(gamma) if gamma is not None else None
         db = torch.empty_like(beta) if beta is not None else None
         ws = torch.empty(lib.mlagg_plane_norm_bwd_workspace_floats(B, C), device=x.device, dtype=torch.float32) \
             if (dg is not None or db is not None) else None
-        _lib.check(lib.mlagg_plane_norm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(stats), _ptr(dx), _ptr(dg), _ptr(db),
-                                            _ptr(ws), B, C, hw, act, slope, _stream()), "mlagg_plane_norm_bwd")
-        return dx, dg, db, None, None, None
+        _lib.check(lib.mlagg_plane_norm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(res), _ptr(stats), _ptr(dx), _ptr(dres),
+                                            _ptr(dg), _ptr(db), _ptr(ws), B, C, hw, act, slope, _stream()), "mlagg_plane_norm_bwd")
+        return dx, dg, db, dres, None, None, None
 
 
-def plane_norm(x, gamma, beta, eps=1e-5, act=ACT_NONE, slope=0.0):
-    return PlaneNormFn.apply(x, gamma, beta, eps, act, slope)
+def plane_norm(x, gamma, beta, eps=1e-5, act=ACT_NONE, slope=0.0, res=None):
+    return PlaneNormFn.apply(x, gamma, beta, res, eps, act, slope)

@@ -411,3 +411,21 @@ def test_plane_norm_matches_torch(B, C, H, W, kind):
     if ga is not None:
         assert float((ga.grad - gb.grad).abs().max()) < 1e-4 * max(1.0, float(gb.grad.abs().max()))
         assert float((ba.grad - bb.grad).abs().max()) < 1e-4 * max(1.0, float(bb.grad.abs().max()))
+
+
+@gpu
+def test_plane_norm_residual_before_activation():
+    """y = leaky(IN(x) + res): the tail of the MONAI UnetResBlock, forward and both gradients."""
+    from mlagg_unet_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 6, 20, 12, generator=g).to(DEV)
+    r = torch.randn(2, 6, 20, 12, generator=g).to(DEV)
+    gy = torch.randn(2, 6, 20, 12, generator=g).to(DEV)
+    xa, ra = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    xb, rb = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    ya = ops.plane_norm(xa, None, None, 1e-5, ops.ACT_LEAKY, 0.01, ra)
+    yb = F.leaky_relu(F.instance_norm(xb, eps=1e-5) + rb, 0.01)
+    assert float((ya - yb).abs().max()) < 2e-5
+    ya.backward(gy)
+    yb.backward(gy)
+    assert float((xa.grad - xb.grad).abs().max()) < 5e-5 and float((ra.grad - rb.grad).abs().max()) < 1e-6
