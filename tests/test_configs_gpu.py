@@ -97,3 +97,31 @@ def test_headline_size_matches_reference_golden():
     norms = {n: float(p.grad.double().norm()) for n, p in m.named_parameters() if p.grad is not None}
     for n, ref in zip(g["grad_names"], g["grad_norms"]):
         assert abs(norms[str(n)] - ref) <= 5e-3 * max(ref, 1e-3), (n, norms[str(n)], ref)
+
+
+@gpu
+def test_five_optimizer_steps_track_the_oracle():
+    """Whole train steps (forward, fused loss, backward, clip 12, AdamW) repeated on one batch: the product's loss
+    trajectory and final weights against the CPU oracle's (B:833-863, T:137-147), DropPath off (eval) on both sides."""
+    from mlagg_unet_amd import model as PM, trainer as TR
+    img = (64, 64)
+    net = PM.build_network_architecture(img, 1, 14, True, "B")
+    O.deterministic_fill_(net.state_dict())
+    ref = O.build_reference_config_model(img, 1, 14, True, "B")
+    ref.load_state_dict(net.state_dict())
+    net = net.to(DEV).eval()
+    ref.eval()
+    opt, _ = TR.configure_optimizers(net)
+    ropt = O.make_optimizer(ref)
+    data, target = O.synthetic_batch(2, 1, *img, 14, seed=99)
+    dd, td = data.to(DEV), [t.to(DEV) for t in target]
+    got, want = [], []
+    for _ in range(5):
+        got.append(float(TR.train_step(net, opt, dd, td)))
+        want.append(float(O.train_step(ref, ropt, data, target)))
+    assert want[-1] < want[0]                                   # the batch is being fitted
+    for a, b in zip(got, want):
+        assert abs(a - b) < 2e-3 * abs(b), (got, want)
+    rp = dict(ref.named_parameters())
+    worst = max(float((p.detach().cpu() - rp[n].detach()).abs().max()) for n, p in net.named_parameters())
+    assert worst < 5e-3, worst                                  # AdamW's sign-like early updates amplify rounding: 5e-4 lr x 5 steps
