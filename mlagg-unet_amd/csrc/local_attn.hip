@@ -307,10 +307,21 @@ local_attn_bwd_a_kernel(const float *__restrict__ q, const float *__restrict__ k
         }
         store12(wrow + 28 + PER * u.r, dO);
     }
-    // block reduction of the parameter gradients
+    // block reduction of the parameter gradients: first over the 16 units of a wave (lanes with equal r: xor 4, 8, 16, 32),
+    // then one LDS add per (wave, r, e) -- 64 lanes adding to one LDS word serialise
 #pragma unroll
-    for (int e = 0; e < PER; ++e) atomicAdd(&red[threadIdx.x & 3][e], dw[e]);
-    if (dl_acc != 0.f) atomicAdd(&red[0][PER], dl_acc);
+    for (int e = 0; e < PER; ++e) {
+        float v = dw[e];
+#pragma unroll
+        for (int off = 4; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) < 4) atomicAdd(&red[threadIdx.x & 3][e], v);
+    }
+    {
+        float v = dl_acc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&red[0][PER], v);
+    }
     __syncthreads();
     if (threadIdx.x < 4 * PER) atomicAdd(dsubln_w + threadIdx.x, red[threadIdx.x / PER][threadIdx.x % PER]);
     if (threadIdx.x == 63) atomicAdd(dlam, red[0][PER]);
