@@ -16,7 +16,31 @@ import torch  # noqa: E402
 import mlagg_unet_amd  # noqa: E402,F401
 from mlagg_unet_amd import dataloading as DL  # noqa: E402
 from mlagg_unet_amd import miopen_tuning, model, trainer  # noqa: E402
-from oracle import dataloading_oracle as DO  # noqa: E402  (dataset writer only)
+
+
+def write_synthetic_dataset(folder, n_cases, labels, seed=3):
+    """nnUNet_preprocessed-style 2-D case folder with AbdomenMR-like slice sizes: <case>.npz, unpacked .npy / _seg.npy, and
+    <case>.pkl with `class_locations` (up to 10 000 sampled voxels per class, as the reference preprocessor stores them)."""
+    import pickle
+    os.makedirs(folder, exist_ok=True)
+    rng = np.random.RandomState(seed)
+    for i in range(n_cases):
+        D, H, W = 5 + i, 300 + 8 * i, 280 + 12 * i
+        data = rng.standard_normal((1, D, H, W)).astype(np.float32)
+        seg = np.zeros((1, D, H, W), dtype=np.int16)
+        for lab in labels:
+            d, y, x = rng.randint(0, D), rng.randint(2, H - 40), rng.randint(2, W - 40)
+            seg[0, d:d + 2, y:y + 30, x:x + 30] = lab
+        name = f"case_{i:03d}"
+        np.savez_compressed(os.path.join(folder, name + ".npz"), data=data, seg=seg)
+        np.save(os.path.join(folder, name + ".npy"), data)
+        np.save(os.path.join(folder, name + "_seg.npy"), seg)
+        locs = {}
+        for lab in labels:
+            a = np.argwhere(seg == lab)
+            locs[lab] = a[rng.choice(len(a), min(10000, len(a)), replace=False)] if len(a) else []
+        with open(os.path.join(folder, name + ".pkl"), "wb") as fh:
+            pickle.dump({"class_locations": locs}, fh)
 
 
 def main():
@@ -27,7 +51,7 @@ def main():
     ap.add_argument("--workers", type=int, default=6)
     a = ap.parse_args()
     if not os.path.isdir(a.dir) or not os.listdir(a.dir):
-        DO.write_synthetic_dataset(a.dir, n_cases=a.cases, unpack=True, small=False, labels=tuple(range(1, 14)))
+        write_synthetic_dataset(a.dir, a.cases, tuple(range(1, 14)))
     ds = DL.Dataset(a.dir)
     B, patch = 10, (256, 256)
     labels = list(range(14))
