@@ -272,6 +272,19 @@ int mlagg_plane_norm_bwd(const float *x, const float *dy, const float *gamma, co
                          const float *stats, float *dx, float *dres, float *dgamma, float *dbeta, float *workspace, int B, int C,
                          long HW, int act, float slope, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K11: clip_grad_norm_ + AdamW.step() of the train step (nnUNetTrainer.py:855-857; optimizer of
+ * nnUNetTrainer_MLAgg_2D_dt_MS.py:137-147) for every parameter in two launches.
+ * tensor_table: device array of rows {param*, grad*, exp_avg*, exp_avg_sq*, int64 numel} (5 x 8 bytes each);
+ * work_list: device array of int32 pairs (tensor index, chunk index), one per mlagg_adamw_chunk_elements() elements;
+ * sumsq: one device double (scratch).  max_norm > 0: gradients are scaled by min(1, max_norm / (||g||_2 + 1e-6)) as they are
+ * read (the global norm is formed on the device; no host synchronisation; gradients in memory stay unscaled); <= 0: no clipping.
+ * step: 1-based step count for the bias corrections.  Arithmetic of torch.optim.AdamW (decoupled decay, amsgrad off).
+ * ------------------------------------------------------------------------------------------ */
+int mlagg_adamw_chunk_elements(void);
+int mlagg_adamw_clip_step(const void *tensor_table, const void *work_list, int n_work, double *sumsq, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, float max_norm, int step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

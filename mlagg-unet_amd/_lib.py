@@ -65,6 +65,8 @@ SIGNATURES = {
     "mlagg_plane_norm_fwd": (_I, [_F, _F, _F, _F, _F, _F, _I, _I, ctypes.c_long, ctypes.c_float, _I, ctypes.c_float, _S]),
     "mlagg_plane_norm_bwd_workspace_floats": (_SZ, [_I, _I]),
     "mlagg_plane_norm_bwd": (_I, [_F] * 11 + [_I, _I, ctypes.c_long, _I, ctypes.c_float, _S]),
+    "mlagg_adamw_chunk_elements": (_I, []),
+    "mlagg_adamw_clip_step": (_I, [_F, _F, _I, _F] + [ctypes.c_float] * 6 + [_I, _S]),
     "mlagg_transpose_2d": (_I, [_F, ctypes.c_long, _F, _I, _I, _I, _S]),
     "mlagg_gate_fwd": (_I, [_F, _F, _F, _I, _F, ctypes.c_long, _I, _S]),
     "mlagg_gate_bwd": (_I, [_F, _I, _F, _F, _F, _I, _F, _F, _F, ctypes.c_long, _I, _S]),

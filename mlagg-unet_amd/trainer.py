@@ -118,12 +118,87 @@ def deep_supervision_loss(outputs, targets, batch_dice=True, ddp=False, smooth=1
 # ------------------------------------------------------------------------------------------------
 # optimiser / schedule
 # ------------------------------------------------------------------------------------------------
+class ClipAdamW(torch.optim.Optimizer):
+    """clip_grad_norm_(max_norm) + AdamW in two launches for all parameters (K11).  Same hyper-parameters, arithmetic and
+    ``state_dict`` layout (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``) as ``torch.optim.AdamW``; the clip
+    coefficient is computed on the device (no host synchronisation) and the gradients in memory stay unscaled."""
+
+    def __init__(self, params, lr=5e-4, betas=(0.9, 0.999), eps=1e-4, weight_decay=3e-5):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._steps = 0
+        self._work = {}
+        self._sumsq = None
+
+    def _state_of(self, p):
+        st = self.state[p]
+        if not st:
+            st["step"] = torch.tensor(0.0)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    def state_dict(self):
+        for st in self.state.values():
+            if st:
+                st["step"] = torch.tensor(float(self._steps))
+        return super().state_dict()
+
+    def load_state_dict(self, sd):
+        super().load_state_dict(sd)
+        steps = [int(st["step"]) for st in self.state.values() if st and "step" in st]
+        self._steps = max(steps) if steps else 0
+
+    @torch.no_grad()
+    def step(self, closure=None, max_norm=0.0):
+        from . import _lib
+        lib = _lib.lib()
+        chunk = lib.mlagg_adamw_chunk_elements()
+        self._steps += 1
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            dev = ps[0].device
+            rows = []
+            for p in ps:
+                st = self._state_of(p)
+                g = p.grad
+                if not (p.is_cuda and g.is_contiguous() and p.is_contiguous() and p.dtype == torch.float32
+                        and g.dtype == torch.float32):
+                    raise RuntimeError("ClipAdamW: fp32 contiguous parameters and gradients on the MI355X expected")
+                rows.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()))
+            key = tuple(r[4] for r in rows)
+            if key not in self._work:
+                wl = [(i, c) for i, n in enumerate(key) for c in range((n + chunk - 1) // chunk)]
+                self._work[key] = torch.tensor(wl, dtype=torch.int32).to(dev)
+            work = self._work[key]
+            table = torch.tensor(rows, dtype=torch.int64).to(dev)
+            if self._sumsq is None or self._sumsq.device != dev:
+                self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+            b1, b2 = group["betas"]
+            lr = float(group["lr"])
+            _lib.check(lib.mlagg_adamw_clip_step(table.data_ptr(), work.data_ptr(), work.shape[0], self._sumsq.data_ptr(), lr,
+                                                 float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                                 float(max_norm), self._steps, torch.cuda.current_stream().cuda_stream),
+                       "mlagg_adamw_clip_step")
+            self._keepalive = (table, ps)             # the table must outlive the asynchronous launches
+        return None
+
+    def grad_norm(self):
+        """||g||_2 of the last step (device tensor; reading it synchronises)."""
+        return self._sumsq.sqrt().float()
+
+
 def configure_optimizers(model, initial_lr=5e-4, weight_decay=3e-5, fused=None, capturable=False):
     """AdamW + cosine schedule of reference T:137-147.  ``capturable=True`` keeps the step counter and the
     learning rate on the device so that the whole step can live inside one hipGraph (GraphedTrainStep)."""
     params = [p for p in model.parameters() if p.requires_grad]
     if fused is None:
         fused = all(p.is_cuda for p in params)
+    if not capturable and fused and all(p.is_cuda for p in params):
+        # eager steps on the device: clip + AdamW of all parameters in two launches (K11)
+        opt = ClipAdamW(params, initial_lr, weight_decay=weight_decay, eps=1e-4)
+        return opt, CosineLRSchedule(opt, t_initial=500, lr_min=1e-6, warmup_t=10, warmup_lr_init=1e-4)
     lr = torch.tensor(initial_lr, device=params[0].device, dtype=torch.float32) if capturable else initial_lr
     opt = torch.optim.AdamW(params, lr, weight_decay=weight_decay, eps=1e-4, fused=fused, capturable=capturable)
     return opt, CosineLRSchedule(opt, t_initial=500, lr_min=1e-6, warmup_t=10, warmup_lr_init=1e-4)
@@ -192,8 +267,11 @@ def train_step(network, optimizer, data, target: List[torch.Tensor], batch_dice=
     output = network(data)
     loss = deep_supervision_loss(output, target, batch_dice, ddp)
     loss.backward()
-    torch.nn.utils.clip_grad_norm_([p for p in network.parameters() if p.grad is not None], clip)
-    optimizer.step()
+    if isinstance(optimizer, ClipAdamW):
+        optimizer.step(max_norm=clip)                      # norm, clip coefficient and AdamW on the device, two launches
+    else:
+        torch.nn.utils.clip_grad_norm_([p for p in network.parameters() if p.grad is not None], clip)
+        optimizer.step()
     return loss.detach()
 
 

@@ -429,3 +429,37 @@ def test_plane_norm_residual_before_activation():
     ya.backward(gy)
     yb.backward(gy)
     assert float((xa.grad - xb.grad).abs().max()) < 5e-5 and float((ra.grad - rb.grad).abs().max()) < 1e-6
+
+
+@gpu
+@pytest.mark.parametrize("max_norm", [12.0, 0.05, 0.0])
+def test_clip_adamw_matches_torch(max_norm):
+    """K11 against torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW over several steps (clip active, inactive, off)."""
+    from mlagg_unet_amd import trainer as TR
+    g = torch.Generator().manual_seed(9)
+    shapes = [(7,), (33, 5), (1,), (300, 257), (96, 1, 3, 3), (70001,)]
+    pa = [torch.nn.Parameter(torch.randn(s, generator=g).to(DEV)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    unused = torch.nn.Parameter(torch.ones(1, device=DEV))                      # like dummy_tensor: never gets a gradient
+    oa = TR.ClipAdamW(pa + [unused], 5e-4, eps=1e-4, weight_decay=3e-5)
+    ob = torch.optim.AdamW(pb, 5e-4, eps=1e-4, weight_decay=3e-5)
+    for it in range(4):
+        grads = [torch.randn(s, generator=g).to(DEV) * (0.1 + it) for s in shapes]
+        for p, q, gr in zip(pa, pb, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        oa.step(max_norm=max_norm)
+        if max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(pb, max_norm)
+        ob.step()
+        for p, gr in zip(pa, grads):
+            assert torch.equal(p.grad, gr)                                       # gradients stay unscaled in memory
+        if max_norm > 0:
+            want = torch.sqrt(sum((gr.double() ** 2).sum() for gr in grads))
+            assert abs(float(oa.grad_norm()) - float(want)) < 1e-5 * float(want)
+    for p, q in zip(pa, pb):
+        assert float((p - q).abs().max()) < 2e-6, float((p - q).abs().max())
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert float(sa["state"][3]["step"]) == 4.0 == float(sb["state"][3]["step"])
+    v_ref = sb["state"][3]["exp_avg_sq"]
+    assert float((sa["state"][3]["exp_avg_sq"] - v_ref).abs().max()) < 1e-4 * float(v_ref.abs().max())   # (g * coef)^2 rounding
+    assert float(unused) == 1.0 and 6 not in sa["state"]
