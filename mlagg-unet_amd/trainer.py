@@ -145,6 +145,7 @@ class ClipAdamW(torch.optim.Optimizer):
 
     def load_state_dict(self, sd):
         super().load_state_dict(sd)
+        self._work.clear()                            # the moment tensors were replaced: cached addresses are stale
         steps = [int(st["step"]) for st in self.state.values() if st and "step" in st]
         self._steps = max(steps) if steps else 0
 
@@ -159,20 +160,27 @@ class ClipAdamW(torch.optim.Optimizer):
             if not ps:
                 continue
             dev = ps[0].device
-            rows = []
-            for p in ps:
-                st = self._state_of(p)
-                g = p.grad
-                if not (p.is_cuda and g.is_contiguous() and p.is_contiguous() and p.dtype == torch.float32
-                        and g.dtype == torch.float32):
-                    raise RuntimeError("ClipAdamW: fp32 contiguous parameters and gradients on the MI355X expected")
-                rows.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()))
-            key = tuple(r[4] for r in rows)
+            key = tuple(id(p) for p in ps)
             if key not in self._work:
-                wl = [(i, c) for i, n in enumerate(key) for c in range((n + chunk - 1) // chunk)]
-                self._work[key] = torch.tensor(wl, dtype=torch.int32).to(dev)
-            work = self._work[key]
-            table = torch.tensor(rows, dtype=torch.int64).to(dev)
+                # per parameter set: the work list and the static columns of the pointer table (uploaded once)
+                for p in ps:
+                    self._state_of(p)
+                    if not (p.is_cuda and p.is_contiguous() and p.dtype == torch.float32):
+                        raise RuntimeError("ClipAdamW: fp32 contiguous parameters on the MI355X expected")
+                numels = [p.numel() for p in ps]
+                wl = [(i, c) for i, n in enumerate(numels) for c in range((n + chunk - 1) // chunk)]
+                base = torch.tensor([(p.data_ptr(), 0, self.state[p]["exp_avg"].data_ptr(),
+                                      self.state[p]["exp_avg_sq"].data_ptr(), p.numel()) for p in ps], dtype=torch.int64)
+                self._work[key] = (torch.tensor(wl, dtype=torch.int32).to(dev), base)
+            work, base = self._work[key]
+            # only the gradient addresses change from step to step (zero_grad(set_to_none=True)); the table goes up through
+            # pinned memory without blocking the host (a pageable copy would make the CPU wait for the GPU every step)
+            host = base.clone()
+            host[:, 1] = torch.tensor([p.grad.data_ptr() for p in ps], dtype=torch.int64)
+            for p in ps:
+                if not (p.grad.is_contiguous() and p.grad.dtype == torch.float32):
+                    raise RuntimeError("ClipAdamW: fp32 contiguous gradients expected")
+            table = host.pin_memory().to(dev, non_blocking=True)
             if self._sumsq is None or self._sumsq.device != dev:
                 self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
             b1, b2 = group["betas"]
@@ -181,7 +189,7 @@ class ClipAdamW(torch.optim.Optimizer):
                                                  float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
                                                  float(max_norm), self._steps, torch.cuda.current_stream().cuda_stream),
                        "mlagg_adamw_clip_step")
-            self._keepalive = (table, ps)             # the table must outlive the asynchronous launches
+            self._keepalive = table                   # the table must outlive the asynchronous launches
         return None
 
     def grad_norm(self):

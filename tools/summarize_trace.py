@@ -24,7 +24,8 @@ def family(n):
                      ("layernorm_", "HIP K6 LayerNorm"), ("column_sum", "HIP K6/K8 column sums"), ("gate_", "HIP K7 gate"),
                      ("row_scale", "HIP K8 small ops"), ("diff_lambda", "HIP K8 small ops"),
                      ("transpose_tile", "HIP K8 small ops"), ("plane_sum", "HIP K8 small ops"),
-                     ("dice_ce", "HIP K9 fused loss"), ("plane_norm", "HIP K10 plane norm + activation")):
+                     ("dice_ce", "HIP K9 fused loss"), ("plane_norm", "HIP K10 plane norm + activation"),
+                     ("adamw_", "HIP K11 clip + AdamW")):
         if key in n:
             return lab
     if re.search(r"miopen|igemm|naive_conv|Im2d2Col|Col2Im|batched_transpose|gridwise|conv|Conv|SubTensor|transpose_", n):
