@@ -16,7 +16,7 @@ stage (the reference flips NCHW <-> NLC per block and again around every depthwi
 produced once per stage for the MIOpen convolutions that consume the stage output.
 """
 import math
-from typing import List, Sequence
+from typing import Sequence
 
 import torch
 import torch.nn as nn

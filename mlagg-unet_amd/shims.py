@@ -13,7 +13,6 @@ files run unmodified on MI355X:
 import sys
 import types
 
-import torch
 import torch.nn.functional as F
 
 from . import ops
