@@ -622,8 +622,10 @@ class MLLA_Uper(nn.Module):  # reference T:1183-1407
         self.encoder0 = UnetrBasicBlock(in_channels, E // 2)
         self.decoder0 = UnetrUpBlock(E, E // 2)
         self.out_0 = OutBlock(E // 2, out_channels)
-        # unused in forward (reference T:1362); excluded from DDP reduction, see trainer.wrap_ddp
-        self.dummy_tensor = nn.Parameter(torch.tensor([1.0]))
+        # unused in forward (reference T:1362): kept as a Parameter for the state_dict key and its slot in the optimizer's
+        # parameter list, but frozen -- DistributedDataParallel only registers parameters that require a gradient, so
+        # the reference's "finished reduction" hazard (SURVEY finding 7a) cannot arise and no DDP-private API is needed
+        self.dummy_tensor = nn.Parameter(torch.tensor([1.0]), requires_grad=False)
         self._dp_pool = _DropPathPool()
         if deep_supervision:
             self.out_1 = OutBlock(E, out_channels)
@@ -632,13 +634,17 @@ class MLLA_Uper(nn.Module):  # reference T:1183-1407
             self.out_4 = OutBlock(8 * E, out_channels)
 
     def forward(self, x_in):
-        if not self.training:
-            return self._forward(x_in)
-        self._dp_pool.begin(x_in.shape[0], x_in.device)
-        try:
-            return self._forward(x_in)
-        finally:
-            self._dp_pool.end()
+        # The network computes in ITS precision whatever the caller's autocast state: the reference loop runs it under
+        # autocast('cuda') (B:848), where the first MIOpen convolution would hand fp16 maps to fp32 HIP kernels.
+        with torch.autocast(x_in.device.type, enabled=False):
+            x_in = x_in.float()
+            if not self.training:
+                return self._forward(x_in)
+            self._dp_pool.begin(x_in.shape[0], x_in.device)
+            try:
+                return self._forward(x_in)
+            finally:
+                self._dp_pool.end()
 
     def _forward(self, x_in):
         hs = self.mlla(x_in)

@@ -2,17 +2,33 @@
 (reference utilities/find_class_by_name.py:7-24 walks nnunetv2/training/nnUNetTrainer/**).
 
 Drop this file's class into that tree and ``nnUNetv2_train ... -tr
-nnUNetTrainer_MLAgg_2D_dt_MS`` trains the MI355X network with unchanged plans, loop, checkpoints.
+nnUNetTrainer_MLAgg_2D_dt_MS`` trains the MI355X network with unchanged plans, epoch loop and checkpoints.
 nnunetv2 is not importable in the build container (its dependencies are absent offline), so the class
 is produced by a factory that receives the base class.
+
+What the class overrides, and why the inherited method cannot stay (B = nnUNetTrainer.py, T = the reference trainer):
+  * ``train_step``  B:833-863 runs the network under ``autocast('cuda')`` with a ``GradScaler``.  The MI355X path of
+                    this class computes in the precision it was built with (``precision`` below), so the step is
+                    ``trainer.train_step`` (zero_grad, forward, loss, backward, clip 12, AdamW) and ``grad_scaler`` is
+                    None; the returned dictionary and the per-step host copy of the loss are the reference's (B:863).
+  * ``initialize``  B:193-215 wraps with a plain ``DDP(...)``; here ``trainer.wrap_ddp`` (bucket views, no buffer
+                    broadcast) and the loss is rebuilt so that it knows about DDP.
+  * ``_build_loss`` T:106-129: the fused Dice + CE deep-supervision loss (K9) with the batch-dice exchange as one
+                    all-reduce; region / ignore-label datasets keep the reference's own loss classes.
 """
+import torch
+
 from . import evaluation, miopen_tuning, model, trainer
 
+PRECISIONS = ("fp32",)
 
-def make_trainer_class(nnUNetTrainer, variant="B"):
+
+def make_trainer_class(nnUNetTrainer, variant="B", precision="fp32"):
+    if precision not in PRECISIONS:
+        raise RuntimeError(f"precision {precision!r}: this build of the MI355X path offers {PRECISIONS}")
+
     class nnUNetTrainer_MLAgg_2D_dt_MS(nnUNetTrainer):
         def __init__(self, plans, configuration, fold, dataset_json, unpack_dataset=True, device=None):
-            import torch
             super().__init__(plans, configuration, fold, dataset_json, unpack_dataset,
                              device if device is not None else torch.device("cuda"))
             # reference T:52-59
@@ -22,6 +38,11 @@ def make_trainer_class(nnUNetTrainer, variant="B"):
             self.num_iterations_per_epoch = 250
             self.num_val_iterations_per_epoch = 50
             self.num_epochs = 500
+            self.current_epoch = 0
+            # B:152 creates a GradScaler for the fp16 autocast of B:848; this path does not scale the loss.  Checkpoints
+            # then carry ``grad_scaler_state: None`` exactly as the reference's CPU runs do (B:1018, 1047-1049).
+            self.grad_scaler = None
+            self.mlagg_precision = precision
             # run_training.py:123-125 sets cudnn.benchmark (MIOpen's exhaustive find); here: the committed find-db
             miopen_tuning.use_tuned_convolutions()
 
@@ -33,20 +54,58 @@ def make_trainer_class(nnUNetTrainer, variant="B"):
                                                     label_manager.num_segmentation_heads, enable_deep_supervision,
                                                     variant)
 
+        def initialize(self):                                                       # reference B:193-215
+            ddp = self.is_ddp
+            self.is_ddp = False           # keeps the inherited body from wrapping with the plain DDP(...) of B:205-207
+            try:
+                super().initialize()
+            finally:
+                self.is_ddp = ddp
+            if ddp:
+                self.network = trainer.wrap_ddp(self.network, self.device.index if self.device.type == "cuda" else None)
+                self.loss = self._build_loss()
+
         def set_deep_supervision_enabled(self, enabled):
             trainer.set_deep_supervision_enabled(self.network, enabled)             # fixes SURVEY finding 7b
 
         def _get_deep_supervision_scales(self):                                    # reference T:101-104
             return [[1.0 / 2 ** i] * 2 for i in range(5)]
 
+        def _build_loss(self):                                                      # reference T:106-129
+            lm = self.label_manager
+            if getattr(lm, "has_regions", False) or getattr(lm, "ignore_label", None) is not None:
+                # DC_and_BCE_loss / ignore-label masking (T:107-116): not on the MLAgg-UNet benchmark path; the
+                # reference's own torch loss classes run unchanged on the device logits
+                return super()._build_loss()
+            batch_dice, ddp = bool(self.configuration_manager.batch_dice), bool(self.is_ddp)
+
+            def loss(output, target):
+                if not isinstance(output, (list, tuple)):                           # deep supervision off (validation of
+                    output, target = [output], [target if torch.is_tensor(target) else target[0]]   # a no-DS network)
+                return trainer.deep_supervision_loss(list(output), list(target[:len(output)]), batch_dice, ddp)
+
+            return loss
+
         def configure_optimizers(self):                                             # reference T:137-147
             return trainer.configure_optimizers(self.network, self.initial_lr, self.weight_decay)
 
-        def validation_step(self, batch):                                           # reference B:880-942
+        def _to_device(self, batch):                                                # reference B:834-841
             data = batch["data"].to(self.device, non_blocking=True)
             target = batch["target"]
             target = [t.to(self.device, non_blocking=True) for t in target] if isinstance(target, list) else \
                 target.to(self.device, non_blocking=True)
+            return data, target
+
+        def train_step(self, batch):                                                # reference B:833-863
+            data, target = self._to_device(batch)
+            if not isinstance(target, list):
+                target = [target]
+            loss = trainer.train_step(self.network, self.optimizer, data.float(), [t.float() for t in target],
+                                      clip=12.0, loss_fn=self.loss)
+            return {"loss": loss.cpu().numpy()}                                     # the reference's per-step host copy
+
+        def validation_step(self, batch):                                           # reference B:880-942
+            data, target = self._to_device(batch)
             return evaluation.validation_step(self.network, data, target, self.configuration_manager.batch_dice,
                                               self.is_ddp)
 

@@ -200,7 +200,9 @@ class ClipAdamW(torch.optim.Optimizer):
 def configure_optimizers(model, initial_lr=5e-4, weight_decay=3e-5, fused=None, capturable=False):
     """AdamW + cosine schedule of reference T:137-147.  ``capturable=True`` keeps the step counter and the
     learning rate on the device so that the whole step can live inside one hipGraph (GraphedTrainStep)."""
-    params = [p for p in model.parameters() if p.requires_grad]
+    # every parameter, in module order, as the reference's ``AdamW(self.network.parameters(), ...)`` (T:138): the
+    # frozen ``dummy_tensor`` keeps its slot, so parameter indices in optimizer checkpoints equal the reference's
+    params = list(model.parameters())
     if fused is None:
         fused = all(p.is_cuda for p in params)
     if not capturable and fused and all(p.is_cuda for p in params):
@@ -250,11 +252,12 @@ def split_batch_size(global_batch, world_size):
 
 def wrap_ddp(model, device_index=None, bucket_cap_mb=25):
     """DistributedDataParallel over RCCL with gradient buckets overlapped with backward.  The
-    never-used ``dummy_tensor`` (reference T:1362) is excluded from reduction so that
-    ``find_unused_parameters`` can stay False (SURVEY finding 7a)."""
+    never-used ``dummy_tensor`` (reference T:1362) is frozen (``requires_grad`` False: DDP registers only
+    parameters that require a gradient), so ``find_unused_parameters`` can stay False (SURVEY finding 7a)."""
     from torch.nn.parallel import DistributedDataParallel as DDP
-    # torch builds the name as f"{module_name}.{param_name}", which is ".dummy_tensor" for the root module
-    DDP._set_params_and_buffers_to_ignore_for_model(model, ["dummy_tensor", ".dummy_tensor"])
+    dummy = getattr(model, "dummy_tensor", None)
+    if isinstance(dummy, torch.nn.Parameter):
+        dummy.requires_grad_(False)
     ids = None if device_index is None else [device_index]
     return DDP(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True,
                broadcast_buffers=False)
@@ -268,12 +271,14 @@ def set_deep_supervision_enabled(network, enabled):
 # ------------------------------------------------------------------------------------------------
 # step
 # ------------------------------------------------------------------------------------------------
-def train_step(network, optimizer, data, target: List[torch.Tensor], batch_dice=True, ddp=False, clip=12.0):
+def train_step(network, optimizer, data, target: List[torch.Tensor], batch_dice=True, ddp=False, clip=12.0,
+               loss_fn=None):
     """One optimisation step on device-resident tensors; returns the detached loss tensor (the caller
-    decides when to synchronise -- the reference's ``.cpu()`` per step, B:863, is a host sync)."""
+    decides when to synchronise -- the reference's ``.cpu()`` per step, B:863, is a host sync).
+    ``loss_fn(output, target)`` replaces the Dice + CE deep-supervision loss (the trainer plugin passes ``self.loss``)."""
     optimizer.zero_grad(set_to_none=True)
     output = network(data)
-    loss = deep_supervision_loss(output, target, batch_dice, ddp)
+    loss = deep_supervision_loss(output, target, batch_dice, ddp) if loss_fn is None else loss_fn(output, target)
     loss.backward()
     if isinstance(optimizer, ClipAdamW):
         optimizer.step(max_norm=clip)                      # norm, clip coefficient and AdamW on the device, two launches

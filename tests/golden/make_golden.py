@@ -102,8 +102,8 @@ def import_reference():
     return T, M
 
 
-def ref_model(T, img, n_cls=14):
-    m = T.MLLA_Uper(img_size=list(img), patch_size=2, in_channels=1, out_channels=n_cls, embed_dim=96,
+def ref_model(T, img, n_cls=14, in_ch=1):
+    m = T.MLLA_Uper(img_size=list(img), patch_size=2, in_channels=in_ch, out_channels=n_cls, embed_dim=96,
                     depths=[2, 2, 2, 2], num_heads=[2, 4, 8, 16], mlp_ratio=2, qkv_bias=True, drop_rate=0.,
                     dropout_path_rate=0.1, sr_ratio=[16, 8, 4, 2], norm_layer=nn.LayerNorm, ape=False,
                     use_checkpoint=False, deep_supervision=True)
@@ -175,6 +175,66 @@ def golden_full_model_256(T):
         out0_abs_max=float(out[0].detach().abs().max()),
         **{f"out{i}": o.detach().numpy() for i, o in enumerate(out) if i > 0})
     print("full model 256", float(loss), [tuple(o.shape) for o in out])
+
+
+CONFIG_GOLDENS = {
+    # tag: (img, in_ch, n_cls, batch, variant, data_seed, autocast dtype or None)
+    # BASELINE configs[2] shape (ACDC-like: 224 x 224, 4 classes), fp32 and under the reference's autocast (B:848) in bf16
+    "224_variantB": ((224, 224), 1, 4, 1, "B", 2240, None),
+    "224_variantB_bf16": ((224, 224), 1, 4, 1, "B", 2240, torch.bfloat16),
+    # the headline size with TWO samples: batch-dice across samples and every kernel's batch indexing at 256 x 256
+    "256_b2_variantB": ((256, 256), 1, 14, 2, "B", 2562, None),
+    # BASELINE configs[4] shape (Endovis17-like: 512 x 640 RGB, 8 classes), shipped flash scaling (variant A)
+    "512x640_variantA": ((512, 640), 3, 8, 1, "A", 5126, None),
+    "512x640_variantA_fp16": ((512, 640), 3, 8, 1, "A", 5126, torch.float16),
+}
+
+
+def _sub_stride(h, w, budget=8192):
+    s = 1
+    while ((h + s - 1) // s) * ((w + s - 1) // s) > budget:
+        s += 1
+    return s
+
+
+def golden_full_model_config(T, tag):
+    """The reference network + DeepSupervisionWrapper(DC_and_CE_loss) at one BASELINE shape: sub-sampled logits of the
+    five heads (stride chosen so a map keeps <= 8192 pixels), per-(sample, class) sums and |max| of the FULL maps, the loss
+    and every parameter-gradient norm.  With ``autocast`` the forward and the loss run under torch.autocast("cpu", dtype),
+    as nnUNetTrainer.train_step does on the device (B:848-851); there is no GradScaler on this side (its scale cancels)."""
+    img, in_ch, n_cls, batch, variant, seed, amp = CONFIG_GOLDENS[tag]
+    FLASH_SCALE["value"] = None if variant == "A" else 1.0
+    m = ref_model(T, img, n_cls, in_ch).eval()
+    data, target = O.synthetic_batch(batch, in_ch, *img, n_cls, seed=seed)
+    from nnunetv2.training.loss.compound_losses import DC_and_CE_loss
+    from nnunetv2.training.loss.deep_supervision import DeepSupervisionWrapper
+    from nnunetv2.training.loss.dice import MemoryEfficientSoftDiceLoss
+    base = DC_and_CE_loss({'batch_dice': True, 'smooth': 1e-5, 'do_bg': False, 'ddp': False}, {}, weight_ce=1,
+                          weight_dice=1, ignore_label=None, dice_class=MemoryEfficientSoftDiceLoss)
+    w = np.array([1 / (2 ** i) for i in range(5)])
+    import contextlib
+    import time
+    t0 = time.time()
+    ctx = torch.autocast("cpu", dtype=amp) if amp is not None else contextlib.nullcontext()
+    with ctx:
+        out = m(data)
+        loss = DeepSupervisionWrapper(base, w / w.sum())(out, target)
+    loss.backward()
+    names, norms = grad_summary(m)
+    store = {}
+    for i, o in enumerate(out):
+        o = o.detach().float()
+        s = _sub_stride(o.shape[2], o.shape[3])
+        store[f"out{i}_sub"] = o.numpy()[:, :, ::s, ::s]
+        store[f"out{i}_stride"] = s
+        store[f"out{i}_sums"] = o.double().sum((2, 3)).numpy()
+        store[f"out{i}_abs_max"] = float(o.abs().max())
+    np.savez_compressed(
+        os.path.join(HERE, f"full_model_{tag}.npz"), img=np.asarray(img), in_ch=in_ch, n_cls=n_cls, batch=batch,
+        variant=variant, data_seed=seed, autocast="" if amp is None else str(amp).replace("torch.", ""),
+        out_dtype=str(out[0].dtype).replace("torch.", ""), loss=float(loss),
+        grad_names=np.asarray(names), grad_norms=norms, **store)
+    print("full model", tag, float(loss), [tuple(o.shape) for o in out], out[0].dtype, f"{time.time() - t0:.0f}s", flush=True)
 
 
 def golden_mllablock(T, variant):
@@ -349,6 +409,10 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     T, M = import_reference()
+    if "--config" in sys.argv:
+        for tag in sys.argv[sys.argv.index("--config") + 1:]:
+            golden_full_model_config(T, tag)
+        sys.exit(0)
     if "--only-256" in sys.argv:
         golden_full_model_256(T)
         sys.exit(0)
@@ -366,3 +430,5 @@ if __name__ == "__main__":
         golden_mllablock(T, v)
         golden_full_model(T, v)
     golden_full_model_256(T)
+    for tag in CONFIG_GOLDENS:
+        golden_full_model_config(T, tag)

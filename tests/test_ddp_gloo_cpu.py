@@ -66,6 +66,7 @@ class _Tiny(torch.nn.Module):
         super().__init__()
         self.lin = torch.nn.Linear(4, 3)
         self.dummy_tensor = torch.nn.Parameter(torch.tensor([1.0]))    # never used in forward (reference T:1362)
+        # as the reference declares it (trainable): wrap_ddp must freeze it, or iteration 2 raises (SURVEY finding 7a)
 
     def forward(self, x):
         return self.lin(x)
@@ -87,7 +88,8 @@ def _ddp_case(rank, world):
         ddp(x).square().mean().backward()
         opt.step()
     trainer.set_deep_supervision_enabled(ddp, False)
-    return [net.lin.weight.detach().clone(), net.dummy_tensor.grad is None, getattr(net, "deep_supervision", None)]
+    return [net.lin.weight.detach().clone(), net.dummy_tensor.grad is None and not net.dummy_tensor.requires_grad,
+            getattr(net, "deep_supervision", None)]
 
 
 def test_ddp_runs_with_unused_dummy_tensor_and_stays_in_sync():
@@ -95,6 +97,63 @@ def test_ddp_runs_with_unused_dummy_tensor_and_stays_in_sync():
     assert torch.equal(res[0][0], res[1][0])           # replicas identical after 3 steps
     assert res[0][1] and res[1][1]                     # dummy_tensor never received a gradient
     assert res[0][2] is False                          # attribute set on the module, not on the wrapper
+
+
+def _plugin_case(rank, world):
+    """The trainer plugin under DDP, driven like run_training drives it: construct (is_ddp is read from the process
+    group, B:81), initialize, train_step.  Each rank trains on its own half of a global batch of 4."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    sys.path.insert(0, here)
+    os.environ["MLAGG_MIOPEN_TUNED"] = "0"
+    import fake_nnunet as FK
+    import test_plugin_cpu as TP
+    import mlagg_unet_amd  # noqa: F401
+    from mlagg_unet_amd import model, nnunet_plugin, trainer
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    def build(patch_size, in_ch, n_cls, ds=True, variant="B"):
+        torch.manual_seed(0)
+        return TP.StubNet(in_ch, n_cls, ds)
+
+    model.build_network_architecture = build
+    cls = nnunet_plugin.make_trainer_class(FK.nnUNetTrainer)
+    tr = cls(FK.make_plans((32, 32), 4), "2d_bs10", 0, FK.make_dataset_json(5), device=torch.device("cpu"))
+    tr.initialize()
+    losses = []
+    for it in range(3):
+        b = TP._batch(50 + it, n=4)
+        mine = {"data": b["data"][2 * rank:2 * rank + 2], "target": [t[2 * rank:2 * rank + 2] for t in b["target"]]}
+        losses.append(float(tr.train_step(mine)["loss"]))
+    # the same three steps on the whole batch in one process (batch dice over all 4 samples, mean CE over all pixels)
+    torch.manual_seed(0)
+    ref = TP.StubNet(1, 5, True)
+    opt = torch.optim.AdamW(ref.parameters(), 5e-4, weight_decay=3e-5, eps=1e-4)
+    ref_losses = []
+    for it in range(3):
+        b = TP._batch(50 + it, n=4)
+        opt.zero_grad()
+        loss = trainer.deep_supervision_loss_eager(ref(b["data"]), b["target"], True, False)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 12)
+        opt.step()
+        ref_losses.append(float(loss.detach()))
+    err = max(float((a - b).abs().max()) for a, b in zip(tr.network.module.state_dict().values(), ref.state_dict().values()))
+    return [isinstance(tr.network, DDP), tr.base_calls["plain_ddp_wrap"], tr.base_calls["train_step"], losses, ref_losses,
+            err, tr.network.module.body.weight.detach().clone()]
+
+
+def test_trainer_plugin_under_ddp_equals_one_process_on_the_global_batch():
+    res = _run(_plugin_case)
+    for is_ddp, plain, base_steps, losses, ref_losses, err, _ in res:
+        assert is_ddp and plain == 0 and base_steps == 0        # wrapped by trainer.wrap_ddp, stepped by the plugin
+        # the dice term is the GLOBAL batch dice on every rank, the CE term the rank's own mean: their average over ranks
+        # is the single-process loss; parameters follow the single-process trajectory (DDP averages the gradients)
+        assert err < 2e-6
+    assert torch.equal(res[0][6], res[1][6])
+    mean_losses = [(a + b) / 2 for a, b in zip(res[0][3], res[1][3])]
+    assert max(abs(a - b) for a, b in zip(mean_losses, res[0][4])) < 1e-5
 
 
 def _val_case(rank, world):

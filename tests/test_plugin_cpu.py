@@ -1,0 +1,111 @@
+"""CPU: plugin boundary #1 behind the reference's trainer loop.  The class made by ``nnunet_plugin.make_trainer_class`` is
+built on ``tests/fake_nnunet.nnUNetTrainer`` (a restatement of the reference base class's ``__init__`` / ``initialize`` /
+AMP ``train_step``, nnUNetTrainer.py:64-215, 833-863) and driven the way ``run_training`` drives it (B:1202-1223):
+construct, ``initialize``, ``train_step(batch)``.  The product network cannot run on the host (its ops refuse CPU
+tensors), so ``model.build_network_architecture`` is replaced by a small five-head network here; the GPU twin of this
+test (test_plugin_gpu.py) runs the real one."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import fake_nnunet as FK
+
+
+class StubNet(nn.Module):
+    def __init__(self, in_ch, n_cls, ds=True):
+        super().__init__()
+        self.deep_supervision = ds
+        self.body = nn.Conv2d(in_ch, 8, 3, padding=1)
+        self.heads = nn.ModuleList([nn.Conv2d(8, n_cls, 1) for _ in range(5)])
+        self.dummy_tensor = nn.Parameter(torch.tensor([1.0]), requires_grad=False)
+
+    def forward(self, x):
+        f = F.relu(self.body(x))
+        outs = [h(F.avg_pool2d(f, 2 ** s) if s else f) for s, h in enumerate(self.heads)]
+        return outs if self.deep_supervision else outs[0]
+
+
+@pytest.fixture
+def plugin(monkeypatch):
+    import mlagg_unet_amd  # noqa: F401
+    from mlagg_unet_amd import model, nnunet_plugin
+    seen = {}
+
+    def build(patch_size, in_ch, n_cls, ds=True, variant="B"):
+        seen["args"] = (tuple(patch_size), in_ch, n_cls, ds, variant)
+        torch.manual_seed(0)
+        return StubNet(in_ch, n_cls, ds)
+
+    monkeypatch.setattr(model, "build_network_architecture", build)
+    monkeypatch.setenv("MLAGG_MIOPEN_TUNED", "0")
+    return nnunet_plugin.make_trainer_class(FK.nnUNetTrainer, variant="B"), seen
+
+
+def _batch(seed, n=3, n_cls=5, size=32):
+    g = torch.Generator().manual_seed(seed)
+    return {"data": torch.rand(n, 1, size, size, generator=g),
+            "target": [torch.round(torch.rand(n, 1, size >> s, size >> s, generator=g) * (n_cls - 1)) for s in range(5)]}
+
+
+def test_plugin_runs_its_own_step_behind_the_reference_loop(plugin):
+    cls, seen = plugin
+    from mlagg_unet_amd import trainer
+    assert cls.__name__ == "nnUNetTrainer_MLAgg_2D_dt_MS" and issubclass(cls, FK.nnUNetTrainer)
+    for name in ("train_step", "initialize", "_build_loss", "configure_optimizers", "build_network_architecture",
+                 "set_deep_supervision_enabled", "_get_deep_supervision_scales", "validation_step"):
+        assert getattr(cls, name) is not getattr(FK.nnUNetTrainer, name, None), f"{name} is inherited"
+    tr = cls(FK.make_plans((32, 32), 3), "2d_bs10", 0, FK.make_dataset_json(5), device=torch.device("cpu"))
+    assert (tr.initial_lr, tr.weight_decay, tr.num_epochs, tr.num_iterations_per_epoch) == (5e-4, 3e-5, 500, 250)
+    assert tr.grad_scaler is None
+    tr.initialize()
+    assert seen["args"] == ((32, 32), 1, 5, True, "B")
+    assert tr.base_calls["initialize"] == 1 and tr.base_calls["_build_loss"] == 0 and tr.base_calls["plain_ddp_wrap"] == 0
+    assert callable(tr.loss) and tr._get_deep_supervision_scales() == [[1 / 2 ** i] * 2 for i in range(5)]
+    # the reference step, written out with torch pieces on a copy of the network (B:843-861, fp32 branch)
+    ref_net = copy.deepcopy(tr.network)
+    ref_opt = torch.optim.AdamW(ref_net.parameters(), 5e-4, weight_decay=3e-5, eps=1e-4)
+    for it in range(2):
+        b = _batch(10 + it)
+        out = tr.train_step(b)
+        assert set(out) == {"loss"} and isinstance(out["loss"], np.ndarray)
+        ref_opt.zero_grad()
+        loss = trainer.deep_supervision_loss_eager(ref_net(b["data"]), b["target"], True, False)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(ref_net.parameters(), 12)
+        ref_opt.step()
+        assert abs(float(out["loss"]) - float(loss)) < 1e-6
+    assert tr.base_calls["train_step"] == 0                      # the AMP body of B:833-863 never ran
+    for (k, a), b in zip(tr.network.state_dict().items(), ref_net.state_dict().values()):
+        assert torch.allclose(a, b, atol=1e-7), k
+    # optimizer checkpoints keep the reference's parameter indexing: every parameter incl. the frozen dummy_tensor
+    assert len(tr.optimizer.param_groups[0]["params"]) == len(list(tr.network.parameters()))
+    tr.set_deep_supervision_enabled(False)
+    assert tr.network.deep_supervision is False
+
+
+def test_plugin_drops_the_grad_scaler_of_a_gpu_trainer(plugin):
+    """On a GPU device the reference constructor makes a GradScaler (B:152) and its train_step autocasts (B:848); the
+    plugin must leave neither in place (constructing needs no GPU)."""
+    cls, _ = plugin
+    tr = cls(FK.make_plans((32, 32), 3), "2d_bs10", 0, FK.make_dataset_json(5), device=torch.device("cuda"))
+    assert tr.device == torch.device("cuda", 0) and tr.grad_scaler is None
+
+
+def test_region_or_ignore_label_datasets_keep_the_reference_loss(plugin):
+    cls, _ = plugin
+    dj = FK.make_dataset_json(5)
+    dj["ignore_label"] = 5
+    tr = cls(FK.make_plans((32, 32), 3), "2d_bs10", 0, dj, device=torch.device("cpu"))
+    tr.initialize()
+    assert tr.base_calls["_build_loss"] == 1 and tr.loss == "reference-loss-classes"
+
+
+def test_unknown_precision_is_refused():
+    import mlagg_unet_amd  # noqa: F401
+    from mlagg_unet_amd import nnunet_plugin
+    with pytest.raises(RuntimeError):
+        nnunet_plugin.make_trainer_class(FK.nnUNetTrainer, precision="int8")

@@ -1,0 +1,71 @@
+"""GPU: plugin boundary #1 with the REAL product network behind the reference's trainer loop (fake base class:
+tests/fake_nnunet.py restates nnUNetTrainer.py:64-215, 833-863)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import fake_nnunet as FK
+
+pytestmark = pytest.mark.gpu
+IMG, NCLS, BATCH = (64, 64), 14, 2
+
+
+def _trainer(variant="B"):
+    import mlagg_unet_amd  # noqa: F401
+    from mlagg_unet_amd import nnunet_plugin
+    from oracle import mlagg_oracle as O
+    cls = nnunet_plugin.make_trainer_class(FK.nnUNetTrainer, variant=variant)
+    tr = cls(FK.make_plans(IMG, BATCH), "2d_bs10", 0, FK.make_dataset_json(NCLS), device=torch.device("cuda"))
+    tr.initialize()
+    O.deterministic_fill_(tr.network.state_dict())
+    return tr
+
+
+def _batches(n):
+    from mlagg_unet_amd import trainer
+    out = []
+    for it in range(n):
+        data, target = trainer.synthetic_batch(BATCH, 1, *IMG, NCLS, seed=700 + it)
+        out.append({"data": data, "target": target})
+    return out
+
+
+def test_plugin_train_step_equals_trainer_train_step_bit_for_bit():
+    from mlagg_unet_amd import model, trainer
+    tr = _trainer()
+    assert isinstance(tr.network, model.MLLA_Uper) and tr.grad_scaler is None
+    assert isinstance(tr.optimizer, trainer.ClipAdamW)
+    twin = copy.deepcopy(tr.network)
+    twin_opt, _ = trainer.configure_optimizers(twin, tr.initial_lr, tr.weight_decay)
+    for b in _batches(2):
+        torch.manual_seed(5)                                   # DropPath masks
+        got = tr.train_step(b)
+        torch.manual_seed(5)
+        want = trainer.train_step(twin, twin_opt, b["data"].cuda(), [t.cuda() for t in b["target"]], batch_dice=True)
+        assert isinstance(got["loss"], np.ndarray) and float(got["loss"]) == float(want)
+    assert tr.base_calls["train_step"] == 0 and tr.base_calls["_build_loss"] == 0
+    for (k, a), b in zip(tr.network.state_dict().items(), twin.state_dict().values()):
+        assert torch.equal(a, b), k
+
+
+def test_reference_amp_step_also_runs_on_the_product_network():
+    """The inherited body of B:833-863 (autocast('cuda') + GradScaler) is not what the plugin runs, but a maintainer who
+    keeps it must not crash: the network leaves autocast for its own precision, gradients come back fp32, and the scaled
+    step lands on the same parameters (the GradScaler's power-of-two scale cancels)."""
+    from mlagg_unet_amd import trainer
+    tr = _trainer()
+    twin = copy.deepcopy(tr.network)
+    twin_opt = torch.optim.AdamW(twin.parameters(), tr.initial_lr, weight_decay=tr.weight_decay, eps=1e-4)
+    tr.optimizer = torch.optim.AdamW(tr.network.parameters(), tr.initial_lr, weight_decay=tr.weight_decay, eps=1e-4)
+    tr.grad_scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    for b in _batches(2):
+        torch.manual_seed(9)
+        got = FK.nnUNetTrainer.train_step(tr, b)               # the reference's AMP step, verbatim logic
+        torch.manual_seed(9)
+        want = trainer.train_step(twin, twin_opt, b["data"].cuda(), [t.cuda() for t in b["target"]], batch_dice=True)
+        assert np.isfinite(got["loss"]) and abs(float(got["loss"]) - float(want)) < 1e-5
+    assert tr.base_calls["train_step"] == 2
+    for (k, a), b in zip(tr.network.state_dict().items(), twin.state_dict().values()):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), k
