@@ -175,24 +175,39 @@ class PrefetchLoader:
 
     def _work(self, loader):
         while not self.stop.is_set():
-            b = loader.generate_train_batch()
-            if self.copy_stream is not None:
-                data, targets = to_device(b, self.device, self.n_levels, self.copy_stream)
-                ev = torch.cuda.Event()
-                ev.record(self.copy_stream)
-            else:
-                data, targets = to_device(b, self.device, self.n_levels)
-                ev = None
-            item = (data, targets, ev, b)                     # keep the pinned host batch alive until consumed
-            while not self.stop.is_set():
+            try:
+                b = loader.generate_train_batch()
+                if self.copy_stream is not None:
+                    data, targets = to_device(b, self.device, self.n_levels, self.copy_stream)
+                    ev = torch.cuda.Event()
+                    ev.record(self.copy_stream)
+                else:
+                    data, targets = to_device(b, self.device, self.n_levels)
+                    ev = None
+                item = (data, targets, ev, b)                 # keep the pinned host batch alive until consumed
+            except BaseException as e:                        # missing .pkl, bad .npz, out of memory on the copy stream ...
+                item = e                                      # handed to the consumer: next() re-raises it
+                self.stop.set()
+            while True:
                 try:
                     self.q.put(item, timeout=0.2)
                     break
                 except queue.Full:
-                    continue
+                    if self.stop.is_set() and not isinstance(item, BaseException):
+                        break
 
     def next(self):
-        data, targets, ev, _ = self.q.get()
+        while True:
+            try:
+                item = self.q.get(timeout=1.0)
+                break
+            except queue.Empty:
+                if not any(t.is_alive() for t in self.workers):
+                    raise RuntimeError("PrefetchLoader: every worker thread has exited and no batch is queued")
+        if isinstance(item, BaseException):
+            self.q.put(item)                                  # the next caller sees it too
+            raise RuntimeError(f"PrefetchLoader worker failed: {type(item).__name__}: {item}") from item
+        data, targets, ev, _ = item
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)
             for t in [data] + targets:

@@ -47,7 +47,10 @@ def algorithmic_bytes(kernel, batch, img):
     }
     if kernel in scan:
         return scan[kernel] * batch
-    dn = 48 * n0                                   # (C/2) * N, identical at all four stages
+    # (C/2) * N_tokens per attention module HALVES from stage to stage (C doubles, the token count quarters):
+    # 48 n0, 24 n0, 12 n0, 6 n0.  These kernels run once per block at each of the 4 stages and their timers average over
+    # all launches, so the figure priced against that average is the mean over the four stage shapes.
+    dn = sum(48 * n0 / 2 ** i for i in range(4)) / 4
     per_module = {
         "local_attn_fwd_kernel": 16 * dn,          # q, k, v in; out
         "local_attn_bwd_a_kernel": 20 * dn,        # q, k, v, dout in; dq out
@@ -58,4 +61,4 @@ def algorithmic_bytes(kernel, batch, img):
     }
     # K2 / K2n / K5w / K6 / K1' are launched with several shapes per step (different callers): they have no
     # single bytes-per-launch figure and are reported by time only
-    return per_module.get(kernel, 0) * batch
+    return int(per_module.get(kernel, 0) * batch)

@@ -142,3 +142,27 @@ class DataLoader2D:
             data_all[j] = np.pad(data, ((0, 0), *pad), "constant", constant_values=0)
             seg_all[j] = np.pad(seg, ((0, 0), *pad), "constant", constant_values=-1)
         return {"data": data_all, "seg": seg_all, "keys": keys}
+
+
+def downsample_seg_for_ds(seg, ds_scales):
+    """DownsampleSegForDSTransform2 (training/data_augmentation/custom_transforms/deep_supervision_donwsampling.py:7-55,
+    order 0) after RemoveLabelTransform(-1, 0) (nnUNetTrainer.py:713): the list of targets train_step consumes (B:838-839).
+    batchgenerators' resize_segmentation (third-party, absent offline -- unpinned) is, for order 0, skimage's
+    resize(order=0, mode="edge", anti_aliasing=False), which is scipy.ndimage.zoom(order=0, mode="nearest",
+    grid_mode=True); restated with scipy here."""
+    import numpy as np
+    from scipy import ndimage
+    seg = np.where(seg < 0, 0, seg).astype(np.float32)
+    out = []
+    for s in ds_scales:
+        if all(v == 1 for v in s):
+            out.append(seg)
+            continue
+        new_shape = np.round(np.array(seg.shape[2:], dtype=float) * np.array(s)).astype(int)
+        level = np.zeros(seg.shape[:2] + tuple(new_shape), dtype=seg.dtype)
+        for b in range(seg.shape[0]):
+            for c in range(seg.shape[1]):
+                zoom = [n / o for n, o in zip(new_shape, seg.shape[2:])]
+                level[b, c] = ndimage.zoom(seg[b, c], zoom, order=0, mode="nearest", grid_mode=True)
+        out.append(level)
+    return out

@@ -57,6 +57,33 @@ def test_device_targets_pyramid(tmp_path):
     assert torch.equal(targets[2], seg[:, :, 2::4, 2::4])
 
 
+def test_target_pyramid_equals_the_reference_transform_chain(tmp_path):
+    """to_device's label clean-up + nearest down-sampling vs the oracle's restatement of RemoveLabelTransform(-1, 0) +
+    DownsampleSegForDSTransform2(order 0) (nnUNetTrainer.py:713, 746-748) on a non-square patch."""
+    DO.write_synthetic_dataset(str(tmp_path), unpack=True, small=False)
+    dl = DL.DataLoader2D(DL.Dataset(str(tmp_path)), 3, (96, 160), (96, 160), [0, 1, 2, 3], 0.5,
+                         rng=np.random.RandomState(4), pin_memory=False)
+    b = dl.generate_train_batch()
+    _, targets = DL.to_device(b, "cpu")
+    want = DO.downsample_seg_for_ds(b["seg"].numpy(), [[1.0 / 2 ** i] * 2 for i in range(5)])
+    for got, w in zip(targets, want):
+        assert np.array_equal(got.numpy(), w)
+
+
+def test_prefetch_loader_raises_when_its_workers_fail(tmp_path):
+    DO.write_synthetic_dataset(str(tmp_path), unpack=True)
+    dl = DL.DataLoader2D(DL.Dataset(str(tmp_path)), 2, (32, 32), (32, 32), [0, 1, 2, 3], 0.33, pin_memory=False)
+    for f in os.listdir(str(tmp_path)):
+        if f.endswith(".pkl"):
+            os.remove(os.path.join(str(tmp_path), f))
+    pf = DL.PrefetchLoader(dl, "cpu", num_workers=2, depth=2)
+    try:
+        with pytest.raises(RuntimeError, match="worker failed"):
+            pf.next()
+    finally:
+        pf.close()
+
+
 def test_prefetch_loader_on_cpu(tmp_path):
     DO.write_synthetic_dataset(str(tmp_path), unpack=True)
     dl = DL.DataLoader2D(DL.Dataset(str(tmp_path)), 3, (32, 32), (32, 32), [0, 1, 2, 3], 0.33, pin_memory=False)
