@@ -24,6 +24,7 @@
 // 4*(5*dim + 4*G*N) backward.  This 3-pass form reads u/delta twice.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "mlagg_hip.h"
 #include "prof.h"
@@ -71,6 +72,10 @@ __device__ __forceinline__ float dpp_quad_xor1(float v)
 __device__ __forceinline__ float dpp_quad_xor2(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_quad_0011(float v)      // quad lane s reads quad lane s >> 1
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x50, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float quad_sum(float v)
 {
@@ -771,6 +776,492 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// backward pass 3, group-per-wave form (round 2): ONE wave owns (batch b, group g, chunk) and ALL channels of the
+// group.  lane = 4 * cl + s: channel lane cl (16) x state quad s (states 4s .. 4s+3); the lane walks J = ceil(Hc / 16)
+// channels cl + 16 j one after the other, so the sums over channels that dB / dC / d(dtr) need are first taken IN the
+// lane (the dB / dC products are the accumulating operand of an FMA: free) and cross lanes once per 8-step tile for all
+// J channels -- 0.7 instead of 4 cross-lane instructions per (step, state) pair.  Nothing is shared with another wave:
+// no barrier, no LDS / global atomics, no memset of dB / dC, one staging of the B / C tile per chunk and group.
+//   * time tile: 8 steps (accumulators: 4 states x 8 steps x {dB, dC} = 64 VGPRs).  The forward pass saves entry
+//     states every 16 steps; the odd 8-step tile re-runs the 8 steps in front of it from the saved state.
+//   * the channel loop is ROLLED (unrolled, the compiler keeps ~150 VGPRs of every channel body alive: 700 spills at
+//     J = 6); what a channel carries from tile to tile sits in LDS: reverse carry q[4] and dA[4] per lane, dD / d(bias) /
+//     dWdt[R] per channel (quad-reduced).
+//   * per (tile, channel): lane (cl, s) loads / activates delta for its steps, parks delta', delta' u, u, dy rows in LDS
+//     (quad-private rows, b128 broadcast reads), runs its 4 states (forward 8 steps keeping a_k, h_{k-1}; reverse 8 steps),
+//     quad-reduces the per-step sums and finishes du / d(delta) for steps 2s, 2s + 1.
+// ~22 KB of LDS per wave: 7 waves per CU.
+// ------------------------------------------------------------------------------------------
+constexpr int T8 = 8;            // steps per tile of the group kernel
+constexpr int SP16 = 20;         // pitch of the 16-step staging rows
+constexpr int SP8 = 12;          // pitch of the 8-step dy rows
+constexpr int JMAX = 6;          // channel slots per lane: groups of up to 96 channels
+
+__device__ __forceinline__ float2 load2(const float *__restrict__ row, int t, int L, bool vec2)
+{
+    float2 v = make_float2(0.f, 0.f);
+    if (vec2) {
+        if (t < L) v = *reinterpret_cast<const float2 *>(row + t);
+    } else {
+        if (t < L) v.x = row[t];
+        if (t + 1 < L) v.y = row[t + 1];
+    }
+    return v;
+}
+__device__ __forceinline__ void store2(float *__restrict__ row, int t, int L, bool vec2, float2 v)
+{
+    if (vec2) {
+        if (t < L) *reinterpret_cast<float2 *>(row + t) = v;
+    } else {
+        if (t < L) row[t] = v.x;
+        if (t + 1 < L) row[t + 1] = v.y;
+    }
+}
+__device__ __forceinline__ float act_delta(float raw, float bias, int softplus, bool inr)
+{
+    float x = raw + bias;
+    if (softplus) x = softplus_f(x);
+    return inr ? x : 0.f;
+}
+
+// Loads / stores of the group kernel.  VEC (L % 4 == 0: every MLAgg-UNet shape): branch-free -- the address is clamped
+// and the value selected, so that no conditional block (and no s_waitcnt at its end) sits between a prefetch and its use.
+template <bool VEC>
+__device__ __forceinline__ float4 gload4(const float *__restrict__ base, unsigned t, unsigned end)   // elements [t, t+4) of base, zero at / beyond `end`
+{
+    if (VEC) {
+        const bool ok = t < end;
+        const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)(ok ? t : 0u));
+        return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < end) v.x = base[t];
+    if (t + 1 < end) v.y = base[t + 1];
+    if (t + 2 < end) v.z = base[t + 2];
+    if (t + 3 < end) v.w = base[t + 3];
+    return v;
+}
+template <bool VEC>
+__device__ __forceinline__ float2 gload2(const float *__restrict__ base, unsigned t, unsigned end)
+{
+    if (VEC) {
+        const bool ok = t < end;
+        const float2 v = *reinterpret_cast<const float2 *>(base + (size_t)(ok ? t : 0u));
+        return make_float2(ok ? v.x : 0.f, ok ? v.y : 0.f);
+    }
+    float2 v = make_float2(0.f, 0.f);
+    if (t < end) v.x = base[t];
+    if (t + 1 < end) v.y = base[t + 1];
+    return v;
+}
+template <bool VEC>
+__device__ __forceinline__ void gstore4(float *__restrict__ base, unsigned t, unsigned end, float4 v)
+{
+    if (VEC) {
+        if (t < end) *reinterpret_cast<float4 *>(base + (size_t)t) = v;
+    } else {
+        if (t < end) base[t] = v.x;
+        if (t + 1 < end) base[t + 1] = v.y;
+        if (t + 2 < end) base[t + 2] = v.z;
+        if (t + 3 < end) base[t + 3] = v.w;
+    }
+}
+template <bool VEC>
+__device__ __forceinline__ void gstore2(float *__restrict__ base, unsigned t, unsigned end, float2 v)
+{
+    if (VEC) {
+        if (t < end) *reinterpret_cast<float2 *>(base + (size_t)t) = v;
+    } else {
+        if (t < end) base[t] = v.x;
+        if (t + 1 < end) base[t + 1] = v.y;
+    }
+}
+// One wave per workgroup: LDS instructions of a wave execute in order, so all the kernel needs between a producer and a
+// consumer of an LDS row is that the COMPILER keeps the order.  (__syncthreads() would also drain vmcnt and with it the
+// prefetched streams.)
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("" ::: "memory"); }
+// component-wise: a select between float4 AGGREGATES is lowered through a scratch (stack) slot
+__device__ __forceinline__ float4 keep4(bool c, const float4 &v)
+{
+    return make_float4(c ? v.x : 0.f, c ? v.y : 0.f, c ? v.z : 0.f, c ? v.w : 0.f);
+}
+
+// FULL: the group is a whole number of 16-channel slots (Hc % 16 == 0, every MLAgg-UNet shape): no padding lanes, so the
+// ~30 selects per (tile, channel) that zero them disappear.
+template <bool LR, bool VEC, bool FULL>
+__global__ void __launch_bounds__(64, 2)
+selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ delta, const float *__restrict__ Wdt, int R,
+                         const float *__restrict__ A, const float *__restrict__ Bm, const float *__restrict__ Cm,
+                         const float *__restrict__ Dv, const float *__restrict__ dbias, const float *__restrict__ dout,
+                         const float *__restrict__ cstate, const float *__restrict__ csub, const float *__restrict__ cq,
+                         float *__restrict__ du, float *__restrict__ ddelta, float *__restrict__ dB, float *__restrict__ dC,
+                         float *__restrict__ part, ScanGeom gm, int softplus)
+{
+    __shared__ float sB[NS * BP], sC[NS * BP];          // [n][16 steps] of the current 16-step tile
+    __shared__ float sR[RMAX * ST];                     // LR: rank rows [r][16 steps]
+    __shared__ float sD[16 * SP16], sX[16 * SP16], sU[16 * SP16];   // per channel lane: delta', delta' u, u
+    __shared__ float sY[16 * SP8];                      // dy of the current 8 steps
+    __shared__ float4 sQ[JMAX * 64], sA[JMAX * 64];     // per (channel slot, lane): reverse carry q[4], dA[4]
+    __shared__ float4 sE[JMAX * 16 * 2];                // per channel: {dD, d(bias), dW0, dW1}, {dW2, dW3, -, -}
+
+    const int chunk = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+    const int L = gm.L, Hc = gm.Hc, dim = gm.dim;
+    const int J = (Hc + 15) >> 4;
+    const int tc0 = chunk * TC;
+    const size_t crow = (size_t)b * gm.nchunks + chunk;            // row of the per-chunk tensors
+    const size_t bg = (size_t)b * gm.G + g;
+
+    {
+        const int lane = threadIdx.x, cl = lane >> 2, s = lane & 3;
+        for (int j = 0; j < J; ++j) {
+            const bool act = cl + 16 * j < Hc;
+            float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (act) q0 = *reinterpret_cast<const float4 *>(cq + (crow * dim + g * Hc + cl + 16 * j) * NS + 4 * s);
+            sQ[j * 64 + lane] = q0;
+            sA[j * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int i = lane; i < J * 32; i += 64) sE[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+
+    // Tiles run in reverse, channels inside a tile forward: ONE flat loop over (tile, channel) so that the HBM streams of
+    // the NEXT (tile, channel) -- u, dy, the saved entry state -- are in flight while this one computes (with ~2 waves
+    // per SIMD and no prefetch, half of all wave cycles were s_waitcnt: PMC SQ_WAIT_ANY, profiles/round2_a).
+    const int m_first = min(TC / T8 - 1, (L - 1 - tc0) / T8);     // last tile that starts inside the sequence
+    const int n_it = (m_first + 1) * J;
+
+    const size_t grow = ((size_t)b * dim + g * Hc) * L;            // first row of the group in the (B, D, L) tensors
+    const float *ubase = u + grow, *gbase = dout + grow, *dbase = LR ? u : delta + grow;
+    float *dubase = du + grow, *ddbase = LR ? du : ddelta + grow;
+    struct Stream { float4 uv; float2 gy; float4 hv; float4 dv; };   // dv: raw delta of the plain (not low-rank) form
+    // branch-free: a load inside a conditional block makes the compiler's vmcnt bookkeeping fall back to vmcnt(0) at the
+    // next use of ANY loaded value, which would drain the prefetch at once.  Out-of-range iterations / padding lanes read
+    // a valid address and the value is dropped.
+    auto fetch = [&](int it, int ln) -> Stream {
+        Stream f;
+        const bool live = it < n_it;
+        it = min(it, n_it - 1);
+        const int cl = ln >> 2, s = ln & 3;
+        const int m = m_first - it / J, j = it % J;
+        const bool act = live && (FULL || cl + 16 * j < Hc);
+        const int sub = m >> 1, odd = m & 1;
+        const int t16 = tc0 + sub * ST, tm = t16 + odd * T8;
+        // uniform 64-bit bases + 32-bit lane offsets: the loads take the SGPR-base form (no 64-bit VALU address arithmetic)
+        const unsigned c = act ? cl + 16 * j : 0;
+        const unsigned roff = c * (unsigned)L;
+        const float *sbase = sub == 0 ? cstate + (crow * dim + g * Hc) * NS : csub + ((crow * (NSUB - 1) + (sub - 1)) * dim + g * Hc) * NS;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 hv = *reinterpret_cast<const float4 *>(sbase + (size_t)(c * NS + 4 * s));
+        const float2 gy = gload2<VEC>(gbase, roff + tm + 2 * s, roff + L);
+        // both visits of a 16-step tile fetch all 16 steps of u, 4 per lane (one code path: no branch between a prefetch
+        // and its use)
+        const float4 uv = gload4<VEC>(ubase, roff + t16 + 4 * s, roff + L);
+        f.dv = z4;
+        if (!LR) f.dv = gload4<VEC>(dbase, roff + t16 + 4 * s, roff + L);
+        f.hv = hv; f.uv = uv; f.gy = gy;        // raw: the consumer zeroes padding lanes (a select here would wait for the load)
+        return f;
+    };
+
+    float accB[4][T8], accC[4][T8], accR[RMAX][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < T8; ++k) { accB[i][k] = 0.f; accC[i][k] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) { accR[r][0] = 0.f; accR[r][1] = 0.f; }
+
+    Stream nx = fetch(0, threadIdx.x);
+#pragma unroll 1
+    for (int it = 0; it < n_it; ++it) {
+        // The lane index is made opaque once per iteration: every LDS / global address below is then a value of THIS
+        // iteration.  Left to itself the optimiser hoists the ~100 loop-invariant address variants (per state row, ...)
+        // out of the loop and the register allocator spills them again.
+        int ln = threadIdx.x;
+        asm volatile("" : "+v"(ln));
+        const int lane = ln, cl = ln >> 2, s = ln & 3;
+        const int m = m_first - it / J, j = it % J;
+        const int sub = m >> 1, odd = m & 1, ho = odd * T8;
+        const int t16 = tc0 + sub * ST;                            // first step of the 16-step tile
+        const int tm = t16 + ho;                                   // first step of this 8-step tile
+        const bool need_lo = odd != 0;                             // odd tile: steps 0..7 of the 16-tile are re-run forward
+        if (j == 0 && (odd || m == m_first)) {
+            // first visit of the 16-step tile (tiles run in reverse): stage B / C rows and the rank rows of all 16 steps
+            const unsigned no = (unsigned)(lane >> 2) * (unsigned)L;
+            const float4 rb = gload4<VEC>(Bm + bg * NS * L, no + t16 + 4 * (lane & 3), no + L);
+            const float4 rc = gload4<VEC>(Cm + bg * NS * L, no + t16 + 4 * (lane & 3), no + L);
+            float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (LR && lane < 4 * R) rr = gload4<VEC>(delta + bg * R * L, no + t16 + 4 * (lane & 3), no + L);
+            wave_lds_fence();
+            *reinterpret_cast<float4 *>(sB + (lane >> 2) * BP + 4 * (lane & 3)) = rb;
+            *reinterpret_cast<float4 *>(sC + (lane >> 2) * BP + 4 * (lane & 3)) = rc;
+            if (LR) stage_rank_rows(sR, R, lane, rr);
+            wave_lds_fence();
+        }
+        const bool act = FULL || cl + 16 * j < Hc;
+        Stream cur;
+        cur.hv = keep4(act, nx.hv); cur.uv = keep4(act, nx.uv); cur.dv = keep4(act, nx.dv);
+        cur.gy = make_float2(act ? nx.gy.x : 0.f, act ? nx.gy.y : 0.f);
+        const unsigned c = act ? cl + 16 * j : 0;
+        const unsigned roff = c * (unsigned)L;
+        // this channel's small operands (L1 / L2 hits) are requested BEFORE the next iteration's streams: vmcnt retires in
+        // order, so a wait for them must not sit behind the prefetch
+        float4 Av = make_float4(0.f, 0.f, 0.f, 0.f);
+        float wv[RMAX] = {0.f, 0.f, 0.f, 0.f};
+        float bias = 0.f, Dd = 0.f;
+        // unconditional loads from clamped addresses (see fetch); the selects come after the prefetch has been issued
+        const float4 av_raw = *reinterpret_cast<const float4 *>(A + (size_t)g * Hc * NS + (size_t)(c * NS + 4 * s));
+        float w_raw[RMAX] = {0.f, 0.f, 0.f, 0.f};
+        if (LR) {
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) w_raw[r] = (Wdt + (size_t)g * Hc * R)[c * R + min(r, R - 1)];
+        }
+        const float b_raw = ((dbias ? dbias : A) + g * Hc)[c], d_raw = ((Dv ? Dv : A) + g * Hc)[c];
+        __builtin_amdgcn_sched_barrier(0);
+        nx = fetch(it + 1, ln);                                    // in flight until the next iteration's staging
+        __builtin_amdgcn_sched_barrier(0);
+        Av = keep4(act, av_raw);
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) wv[r] = (LR && act && r < R) ? w_raw[r] : 0.f;
+        bias = (act && dbias) ? b_raw : 0.f;
+        Dd = (act && Dv) ? d_raw : 0.f;
+        asm volatile("" : "+v"(Dd));                               // taken here (vmcnt leaves the prefetch alone), not lazily at its use
+        {
+            // ---- activation and staging of this (tile, channel) ----
+            wave_lds_fence();                                      // the previous channel's readers of the staging rows are done
+            if (need_lo) {
+                // odd visit: all 16 steps are needed (the lower 8 re-run forward): lane (cl, s) activates steps 4s .. 4s+3
+                const float4 u4 = cur.uv;
+                const float4 raw = LR ? lowrank_delta(sR, R, s, wv) : cur.dv;
+                const float4 da = act ? activate_delta(raw, bias, softplus, t16 + 4 * s, L) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4 *>(sD + cl * SP16 + 4 * s) = da;
+                *reinterpret_cast<float4 *>(sX + cl * SP16 + 4 * s) = make_float4(da.x * u4.x, da.y * u4.y, da.z * u4.z, da.w * u4.w);
+                *reinterpret_cast<float4 *>(sU + cl * SP16 + 4 * s) = u4;
+            } else {
+                // even visit: only the lower 8 steps: lane (cl, s) activates steps 2s, 2s+1.  They sit in the float4 of quad
+                // lane s >> 1 (components x, y for even s; z, w for odd s): two DPP moves and a select per value.
+                // (all four moves run in every lane BEFORE the select: a DPP read under a partial EXEC mask sees disabled
+                // source lanes as zero)
+                const bool hi = (s & 1) != 0;
+                const float ux0 = dpp_quad_0011(cur.uv.x), ux1 = dpp_quad_0011(cur.uv.z);
+                const float uy0 = dpp_quad_0011(cur.uv.y), uy1 = dpp_quad_0011(cur.uv.w);
+                const float ux = hi ? ux1 : ux0, uy = hi ? uy1 : uy0;
+                float2 raw = make_float2(0.f, 0.f);
+                if (LR) {
+#pragma unroll
+                    for (int r = 0; r < RMAX; ++r)
+                        if (r < R) {                                           // rows beyond the rank are never staged
+                            const float2 rv = *reinterpret_cast<const float2 *>(sR + r * ST + 2 * s);
+                            raw.x += wv[r] * rv.x; raw.y += wv[r] * rv.y;
+                        }
+                } else {
+                    const float rx0 = dpp_quad_0011(cur.dv.x), rx1 = dpp_quad_0011(cur.dv.z);
+                    const float ry0 = dpp_quad_0011(cur.dv.y), ry1 = dpp_quad_0011(cur.dv.w);
+                    raw.x = hi ? rx1 : rx0;
+                    raw.y = hi ? ry1 : ry0;
+                }
+                float2 da;
+                da.x = act ? act_delta(raw.x, bias, softplus, tm + 2 * s < L) : 0.f;
+                da.y = act ? act_delta(raw.y, bias, softplus, tm + 2 * s + 1 < L) : 0.f;
+                *reinterpret_cast<float2 *>(sD + cl * SP16 + 2 * s) = da;
+                *reinterpret_cast<float2 *>(sX + cl * SP16 + 2 * s) = make_float2(da.x * ux, da.y * uy);
+                *reinterpret_cast<float2 *>(sU + cl * SP16 + 2 * s) = make_float2(ux, uy);
+            }
+            *reinterpret_cast<float2 *>(sY + cl * SP8 + 2 * s) = cur.gy;
+            wave_lds_fence();
+        }
+
+        const float Ar[4] = {Av.x, Av.y, Av.z, Av.w};
+        float hent[4] = {cur.hv.x, cur.hv.y, cur.hv.z, cur.hv.w};
+        if (need_lo) {
+            // entry state of the odd tile: 8 steps forward from the saved state, nothing kept
+            float dl[T8], xl[T8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(sD + cl * SP16 + 4 * q);
+                const float4 x4 = *reinterpret_cast<const float4 *>(sX + cl * SP16 + 4 * q);
+                dl[4 * q] = a4.x; dl[4 * q + 1] = a4.y; dl[4 * q + 2] = a4.z; dl[4 * q + 3] = a4.w;
+                xl[4 * q] = x4.x; xl[4 * q + 1] = x4.y; xl[4 * q + 2] = x4.z; xl[4 * q + 3] = x4.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_barrier(0);                 // one state at a time: keeps the B rows of the others out of VGPRs
+                const float *sBn = sB + (4 * s + i) * BP;
+                const float4 b0 = *reinterpret_cast<const float4 *>(sBn), b1 = *reinterpret_cast<const float4 *>(sBn + 4);
+                const float bl[T8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                const float A2 = Ar[i] * LOG2E;
+                float hh = hent[i];
+#pragma unroll
+                for (int k = 0; k < T8; ++k) hh = fast_exp2(dl[k] * A2) * hh + xl[k] * bl[k];
+                hent[i] = hh;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // this tile's 8 steps of delta', delta' u, dy (shared by the lane's 4 states)
+        float dk[T8], xk[T8], yk[T8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(sD + cl * SP16 + ho + 4 * q);
+            const float4 x4 = *reinterpret_cast<const float4 *>(sX + cl * SP16 + ho + 4 * q);
+            const float4 y4 = *reinterpret_cast<const float4 *>(sY + cl * SP8 + 4 * q);
+            dk[4 * q] = a4.x; dk[4 * q + 1] = a4.y; dk[4 * q + 2] = a4.z; dk[4 * q + 3] = a4.w;
+            xk[4 * q] = x4.x; xk[4 * q + 1] = x4.y; xk[4 * q + 2] = x4.z; xk[4 * q + 3] = x4.w;
+            yk[4 * q] = y4.x; yk[4 * q + 1] = y4.y; yk[4 * q + 2] = y4.z; yk[4 * q + 3] = y4.w;
+        }
+        const float4 q4 = sQ[j * 64 + lane], a4c = sA[j * 64 + lane];
+        float qc[4] = {q4.x, q4.y, q4.z, q4.w}, dAc[4] = {a4c.x, a4c.y, a4c.z, a4c.w};
+        float sT[T8], sG[T8];
+#pragma unroll
+        for (int k = 0; k < T8; ++k) { sT[k] = 0.f; sG[k] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float *sBn = sB + (4 * s + i) * BP + ho, *sCn = sC + (4 * s + i) * BP + ho;
+            const float4 b0 = *reinterpret_cast<const float4 *>(sBn), b1 = *reinterpret_cast<const float4 *>(sBn + 4);
+            const float bk[T8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            const float A2 = Ar[i] * LOG2E;
+            float ak[T8], hp[T8 + 1];
+            float hh = hent[i];
+#pragma unroll
+            for (int k = 0; k < T8; ++k) {
+                hp[k] = hh;
+                ak[k] = fast_exp2(dk[k] * A2);
+                hh = ak[k] * hh + xk[k] * bk[k];
+            }
+            hp[T8] = hh;
+            const float4 c0 = *reinterpret_cast<const float4 *>(sCn), c1 = *reinterpret_cast<const float4 *>(sCn + 4);
+            const float ck[T8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            float qq = qc[i], dAi = dAc[i];
+#pragma unroll
+            for (int k = T8 - 1; k >= 0; --k) {
+                const float gh = qq + yk[k] * ck[k];                        // dL/dh_k
+                qq = ak[k] * gh;                                            // carried to step k-1
+                const float t1 = qq * hp[k];                                // dL/da_k * a_k
+                sT[k] += t1 * Ar[i];
+                sG[k] += gh * bk[k];
+                dAi += t1 * dk[k];
+                accB[i][k] += gh * xk[k];                                   // this channel's dB[k][n] term, summed in the lane
+                accC[i][k] += yk[k] * hp[k + 1];                            // dC[k][n] term
+            }
+            qc[i] = qq;
+            dAc[i] = dAi;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        sQ[j * 64 + lane] = make_float4(qc[0], qc[1], qc[2], qc[3]);
+        sA[j * 64 + lane] = make_float4(dAc[0], dAc[1], dAc[2], dAc[3]);
+        // ---- finish d(delta') and du: quad sums, lane s keeps steps 2s, 2s+1 ----
+        {
+            float Ts[2] = {0.f, 0.f}, Gs[2] = {0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < T8; ++k) {
+                const float a = quad_sum(sT[k]), c = quad_sum(sG[k]);
+                if (s == (k >> 1)) { Ts[k & 1] = a; Gs[k & 1] = c; }
+            }
+            const float2 d2 = *reinterpret_cast<const float2 *>(sD + cl * SP16 + ho + 2 * s);
+            const float2 u2 = *reinterpret_cast<const float2 *>(sU + cl * SP16 + ho + 2 * s);
+            const float2 g2 = *reinterpret_cast<const float2 *>(sY + cl * SP8 + 2 * s);
+            const float dl2[2] = {d2.x, d2.y}, uu2[2] = {u2.x, u2.y}, gg2[2] = {g2.x, g2.y};
+            float odd2[2], odu2[2];
+            float ev[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                  // this lane's part of dD, d(bias), dW[0..3]
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                // d softplus(x)/dx = sigmoid(x) = 1 - exp(-softplus(x)); 1 when softplus is off
+                const float sp = softplus ? (1.f - __expf(-dl2[e])) : 1.f;
+                const bool inr = (tm + 2 * s + e) < L && act;
+                odd2[e] = inr ? (Ts[e] + uu2[e] * Gs[e]) * sp : 0.f;        // (sT + u * sG) * softplus'
+                odu2[e] = dl2[e] * Gs[e] + Dd * gg2[e];                     // delta' * sG + D * dy
+                ev[1] += odd2[e];
+                ev[0] += gg2[e] * uu2[e];
+            }
+            if (act) {
+                gstore2<VEC>(dubase, roff + tm + 2 * s, roff + L, make_float2(odu2[0], odu2[1]));
+                if (!LR) gstore2<VEC>(ddbase, roff + tm + 2 * s, roff + L, make_float2(odd2[0], odd2[1]));
+            }
+            if (LR) {
+#pragma unroll
+                for (int r = 0; r < RMAX; ++r)
+                    if (r < R) {
+                        const float w = wv[r];
+                        const float2 rv = *reinterpret_cast<const float2 *>(sR + r * ST + ho + 2 * s);
+                        ev[2 + r] = odd2[0] * rv.x + odd2[1] * rv.y;        // dWdt[d][r] += sum_t d(raw delta) dtr[r][t]
+                        accR[r][0] += odd2[0] * w;                          // d(dtr)[r][t] += d(raw delta) Wdt[d][r]
+                        accR[r][1] += odd2[1] * w;
+                    }
+            }
+#pragma unroll
+            for (int x = 0; x < 6; ++x) ev[x] = quad_sum(ev[x]);
+            if (s == 0) {
+                float4 e0 = sE[(j * 16 + cl) * 2], e1 = sE[(j * 16 + cl) * 2 + 1];
+                e0.x += ev[0]; e0.y += ev[1]; e0.z += ev[2]; e0.w += ev[3];
+                e1.x += ev[4]; e1.y += ev[5];
+                sE[(j * 16 + cl) * 2] = e0;
+                sE[(j * 16 + cl) * 2 + 1] = e1;
+            }
+        }
+
+        if (j == J - 1) {
+            // ---- sums over the 16 channel lanes (lane bits 2..5), once per tile for all J channels ----
+            // value index = kind * 32 + i * 8 + k  (kind 0: dB, 1: dC).  permlane32 swap: lane bit 5 keeps its kind;
+            // permlane16 swap: lane bit 4 keeps states i = 2 * bit4 + {0, 1}; the two low channel bits are an orbit of
+            // row_ror:4, all-reduced.  Lane (bit5 = p, bit4 = q, cl & 3 = r) then stores 4 steps of one state row.
+            float v[32];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < T8; ++k) {
+                    float a = accB[i][k], c = accC[i][k];
+                    swap32(a, c);
+                    v[i * 8 + k] = a + c;
+                    accB[i][k] = 0.f; accC[i][k] = 0.f;
+                }
+#pragma unroll
+            for (int x = 0; x < 16; ++x) { swap16(v[x], v[x + 16]); v[x] += v[x + 16]; }
+#pragma unroll
+            for (int x = 0; x < 16; ++x) { v[x] += row_ror4(v[x]); v[x] += row_ror8(v[x]); }
+            const int p = lane >> 5, q = (lane >> 4) & 1, r4 = cl & 3;
+            float4 o;
+            o.x = r4 == 0 ? v[0] : (r4 == 1 ? v[4] : (r4 == 2 ? v[8] : v[12]));
+            o.y = r4 == 0 ? v[1] : (r4 == 1 ? v[5] : (r4 == 2 ? v[9] : v[13]));
+            o.z = r4 == 0 ? v[2] : (r4 == 1 ? v[6] : (r4 == 2 ? v[10] : v[14]));
+            o.w = r4 == 0 ? v[3] : (r4 == 1 ? v[7] : (r4 == 2 ? v[11] : v[15]));
+            const int n = 4 * s + 2 * q + (r4 >> 1);
+            const unsigned no = (unsigned)n * (unsigned)L;
+            gstore4<VEC>((p ? dC : dB) + bg * NS * L, no + tm + 4 * (r4 & 1), no + L, o);
+            if (LR) {
+                // d(dtr)[r][steps 2s, 2s+1]: 8 values (r, e) -> reduce-scatter over lane bits 5, 4, all-reduce over bits 3, 2
+                float w[8];
+#pragma unroll
+                for (int r = 0; r < RMAX; ++r) { w[2 * r] = accR[r][0]; w[2 * r + 1] = accR[r][1]; accR[r][0] = 0.f; accR[r][1] = 0.f; }
+#pragma unroll
+                for (int x = 0; x < 4; ++x) { swap32(w[x], w[x + 4]); w[x] += w[x + 4]; }
+#pragma unroll
+                for (int x = 0; x < 2; ++x) { swap16(w[x], w[x + 2]); w[x] += w[x + 2]; }
+#pragma unroll
+                for (int x = 0; x < 2; ++x) { w[x] += row_ror4(w[x]); w[x] += row_ror8(w[x]); }
+                const int r = 2 * (lane >> 5) + ((lane >> 4) & 1); // the rank row this lane ends up with
+                if (r < R && (cl & 3) == 0)
+                    gstore2<VEC>(ddelta + bg * R * L, r * (unsigned)L + tm + 2 * s, (r + 1) * (unsigned)L, make_float2(w[0], w[1]));   // ddelta = d(dtr) here
+            }
+        }
+    }
+
+    // per-chunk partial sums of dA (16 per channel), dD, ddelta_bias, dWdt -> selscan_reduce_partials
+    __syncthreads();
+    {
+        const int lane = threadIdx.x, cl = lane >> 2, s = lane & 3;
+        for (int j = 0; j < J; ++j) {
+            if (cl + 16 * j < Hc) {
+                float *prow = part + (crow * dim + g * Hc + cl + 16 * j) * PP;
+                *reinterpret_cast<float4 *>(prow + 4 * s) = sA[j * 64 + lane];
+                if (s == 0) {
+                    *reinterpret_cast<float4 *>(prow + NS) = sE[(j * 16 + cl) * 2];
+                    const float4 e1 = sE[(j * 16 + cl) * 2 + 1];
+                    *reinterpret_cast<float4 *>(prow + NS + 4) = make_float4(e1.x, e1.y, 0.f, 0.f);
+                }
+            }
+        }
+    }
+}
+
 // part[b][chunk][d][PP] -> dA[d][16], dD[d], ddbias[d], dWdt[d][R]: column sums of the (batch * nchunks) x (dim * PP)
 // matrix.  A workgroup owns 64 consecutive columns (256-byte row segments, coalesced) and splits the rows over 16
 // row-groups (the first version gave one workgroup per channel 88-byte segments at a 37 KB stride: 0.14 ms).
@@ -815,6 +1306,12 @@ int make_geom(ScanGeom &gm, int batch, int dim, int L, int N, int G, int max_cb 
     gm.nchunks = (L + TC - 1) / TC;
     if ((size_t)G * gm.nblk > 65535) return MLAGG_E_UNSUPPORTED;
     return 0;
+}
+
+inline bool getenv_flag(const char *name)
+{
+    const char *v = getenv(name);
+    return v && v[0] == '1';
 }
 
 inline int block_threads(const ScanGeom &gm)
@@ -883,7 +1380,10 @@ int scan_backward(const float *u, const float *delta, const float *Wdt, int R, c
     ScanGeom gb;
     if (int rc = make_geom(gb, batch, dim, L, N, G, BWD_CB)) return rc;
     const dim3 gridb(gb.nchunks, G * gb.nblk, batch), blockb(block_threads(gb));
-    const int atomic_bc = gb.nblk > 1;
+    // groups of up to 96 channels (every MLAgg-UNet shape: 96): the group-per-wave kernel; wider groups: the channel-block
+    // kernel with float-atomic accumulation of dB / dC across the blocks of a group
+    const bool group_form = gm.Hc <= 96 && !getenv_flag("MLAGG_SELSCAN_BWD_BLOCKED");
+    const int atomic_bc = !group_form && gb.nblk > 1;
     if (atomic_bc) {
         const size_t bytes = (size_t)batch * G * NS * L * sizeof(float);
         (void)hipMemsetAsync(dB, 0, bytes, st);
@@ -895,9 +1395,23 @@ int scan_backward(const float *u, const float *delta, const float *Wdt, int R, c
                        dout, cq, gm, delta_softplus); }
     { MLAGG_TIMED(K_SELSCAN_PREFIX, st); hipLaunchKernelGGL(selscan_chunk_prefix, dim3((dim * NS + 255) / 256, batch), dim3(256), 0, st, A, cq, cdsum,
                        gm, 1); }
-    const size_t lds3 = (size_t)(3 * gb.CB * UP + 2 * ST * BP + 2 * ST * NS + (LR ? 2 * RMAX * ST + 8 * 128 : 0) + UP + gb.CB * UP) * sizeof(float);
-    { MLAGG_TIMED(K_SELSCAN_BWD, st); hipLaunchKernelGGL(selscan_bwd_kernel<LR>, gridb, blockb, lds3, st, u, delta, Wdt, R, A, B, C, D, delta_bias,
-                       dout, cstate, csub, cq, du, ddelta, dB, dC, part, gb, delta_softplus, atomic_bc); }
+    if (group_form) {
+        // one wave per (batch, group, chunk) walks all channels of the group: dB / dC / d(dtr) leave with plain stores
+        const dim3 gridg(gm.nchunks, G, batch);
+        MLAGG_TIMED(K_SELSCAN_BWD, st);
+#define MLAGG_GROUP_LAUNCH(VEC, FULL) hipLaunchKernelGGL((selscan_bwd_group_kernel<LR, VEC, FULL>), gridg, dim3(64), 0, st, u, delta, Wdt, R, \
+            A, B, C, D, delta_bias, dout, cstate, csub, cq, du, ddelta, dB, dC, part, gm, delta_softplus)
+        const bool vecL = (L & 3) == 0, full = (gm.Hc & 15) == 0;
+        if (vecL && full) MLAGG_GROUP_LAUNCH(true, true);
+        else if (vecL) MLAGG_GROUP_LAUNCH(true, false);
+        else MLAGG_GROUP_LAUNCH(false, false);
+#undef MLAGG_GROUP_LAUNCH
+    } else {
+        const size_t lds3 = (size_t)(3 * gb.CB * UP + 2 * ST * BP + 2 * ST * NS + (LR ? 2 * RMAX * ST + 8 * 128 : 0) + UP + gb.CB * UP) * sizeof(float);
+        MLAGG_TIMED(K_SELSCAN_BWD, st);
+        hipLaunchKernelGGL(selscan_bwd_kernel<LR>, gridb, blockb, lds3, st, u, delta, Wdt, R, A, B, C, D, delta_bias,
+                           dout, cstate, csub, cq, du, ddelta, dB, dC, part, gb, delta_softplus, atomic_bc);
+    }
     { MLAGG_TIMED(K_SELSCAN_REDUCE, st); hipLaunchKernelGGL(selscan_reduce_partials, dim3((dim * PP + 63) / 64), dim3(1024), 0, st, part, dA, dD, ddelta_bias,
                        LR ? dWdt : nullptr, R, gm); }
     return (int)hipGetLastError();
