@@ -77,6 +77,10 @@ __device__ __forceinline__ float dpp_quad_0011(float v)      // quad lane s read
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x50, 0xF, 0xF, true));
 }
+__device__ __forceinline__ float dpp_quad_2233(float v)      // quad lane s reads quad lane 2 + (s >> 1)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xFA, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float quad_sum(float v)
 {
     v += dpp_quad_xor1(v);
@@ -795,7 +799,7 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
 // ------------------------------------------------------------------------------------------
 constexpr int T8 = 8;            // steps per tile of the group kernel
 constexpr int SP16 = 20;         // pitch of the 16-step staging rows
-constexpr int SP8 = 12;          // pitch of the 8-step dy rows
+constexpr int SP8 = 8;           // pitch of the 8-step dy rows (b128 reads of one 16-lane group still hit 16 distinct banks)
 constexpr int JMAX = 6;          // channel slots per lane: groups of up to 96 channels
 
 __device__ __forceinline__ float2 load2(const float *__restrict__ row, int t, int L, bool vec2)
@@ -900,10 +904,11 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
 {
     __shared__ float sB[NS * BP], sC[NS * BP];          // [n][16 steps] of the current 16-step tile
     __shared__ float sR[RMAX * ST];                     // LR: rank rows [r][16 steps]
-    __shared__ float sD[16 * SP16], sX[16 * SP16], sU[16 * SP16];   // per channel lane: delta', delta' u, u
+    __shared__ float sD[16 * SP16], sX[16 * SP16];      // per channel lane: delta', delta' u
     __shared__ float sY[16 * SP8];                      // dy of the current 8 steps
     __shared__ float4 sQ[JMAX * 64], sA[JMAX * 64];     // per (channel slot, lane): reverse carry q[4], dA[4]
-    __shared__ float4 sE[JMAX * 16 * 2];                // per channel: {dD, d(bias), dW0, dW1}, {dW2, dW3, -, -}
+    __shared__ float2 sE[JMAX * 16 * 3];                // per channel: {dD, d(bias)}, {dW0, dW1}, {dW2, dW3}
+    // 20480 bytes in all: 8 waves per CU (2 per SIMD, what 256 VGPRs allow) fill the 160 KiB exactly
 
     const int chunk = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
     const int L = gm.L, Hc = gm.Hc, dim = gm.dim;
@@ -921,7 +926,7 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
             sQ[j * 64 + lane] = q0;
             sA[j * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        for (int i = lane; i < J * 32; i += 64) sE[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = lane; i < J * 48; i += 64) sE[i] = make_float2(0.f, 0.f);
     }
     __syncthreads();
 
@@ -938,12 +943,9 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
     // branch-free: a load inside a conditional block makes the compiler's vmcnt bookkeeping fall back to vmcnt(0) at the
     // next use of ANY loaded value, which would drain the prefetch at once.  Out-of-range iterations / padding lanes read
     // a valid address and the value is dropped.
-    auto fetch = [&](int it, int ln) -> Stream {
+    auto fetch = [&](int m, int j, bool live, int ln) -> Stream {
         Stream f;
-        const bool live = it < n_it;
-        it = min(it, n_it - 1);
         const int cl = ln >> 2, s = ln & 3;
-        const int m = m_first - it / J, j = it % J;
         const bool act = live && (FULL || cl + 16 * j < Hc);
         const int sub = m >> 1, odd = m & 1;
         const int t16 = tc0 + sub * ST, tm = t16 + odd * T8;
@@ -971,7 +973,8 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) { accR[r][0] = 0.f; accR[r][1] = 0.f; }
 
-    Stream nx = fetch(0, threadIdx.x);
+    Stream nx = fetch(m_first, 0, true, threadIdx.x);
+    int m = m_first, j = 0;                                        // (tile, channel slot) of the iteration: counters, no division
 #pragma unroll 1
     for (int it = 0; it < n_it; ++it) {
         // The lane index is made opaque once per iteration: every LDS / global address below is then a value of THIS
@@ -980,13 +983,15 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
         int ln = threadIdx.x;
         asm volatile("" : "+v"(ln));
         const int lane = ln, cl = ln >> 2, s = ln & 3;
-        const int m = m_first - it / J, j = it % J;
         const int sub = m >> 1, odd = m & 1, ho = odd * T8;
         const int t16 = tc0 + sub * ST;                            // first step of the 16-step tile
+        const bool last_slot = j == J - 1;
+        const int mn = last_slot ? max(m - 1, 0) : m, jn = last_slot ? 0 : j + 1;   // the next iteration's (tile, slot)
         const int tm = t16 + ho;                                   // first step of this 8-step tile
         const bool need_lo = odd != 0;                             // odd tile: steps 0..7 of the 16-tile are re-run forward
         if (j == 0 && (odd || m == m_first)) {
             // first visit of the 16-step tile (tiles run in reverse): stage B / C rows and the rank rows of all 16 steps
+            // (requesting them an iteration ahead was measured: no gain, 12 more VGPRs)
             const unsigned no = (unsigned)(lane >> 2) * (unsigned)L;
             const float4 rb = gload4<VEC>(Bm + bg * NS * L, no + t16 + 4 * (lane & 3), no + L);
             const float4 rc = gload4<VEC>(Cm + bg * NS * L, no + t16 + 4 * (lane & 3), no + L);
@@ -1018,7 +1023,7 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
         }
         const float b_raw = ((dbias ? dbias : A) + g * Hc)[c], d_raw = ((Dv ? Dv : A) + g * Hc)[c];
         __builtin_amdgcn_sched_barrier(0);
-        nx = fetch(it + 1, ln);                                    // in flight until the next iteration's staging
+        nx = fetch(mn, jn, it + 1 < n_it, ln);                     // in flight until the next iteration's staging
         __builtin_amdgcn_sched_barrier(0);
         Av = keep4(act, av_raw);
 #pragma unroll
@@ -1026,6 +1031,7 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
         bias = (act && dbias) ? b_raw : 0.f;
         Dd = (act && Dv) ? d_raw : 0.f;
         asm volatile("" : "+v"(Dd));                               // taken here (vmcnt leaves the prefetch alone), not lazily at its use
+        float2 uf;                                                 // u of the two steps this lane finishes
         {
             // ---- activation and staging of this (tile, channel) ----
             wave_lds_fence();                                      // the previous channel's readers of the staging rows are done
@@ -1036,7 +1042,12 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
                 const float4 da = act ? activate_delta(raw, bias, softplus, t16 + 4 * s, L) : make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4 *>(sD + cl * SP16 + 4 * s) = da;
                 *reinterpret_cast<float4 *>(sX + cl * SP16 + 4 * s) = make_float4(da.x * u4.x, da.y * u4.y, da.z * u4.z, da.w * u4.w);
-                *reinterpret_cast<float4 *>(sU + cl * SP16 + 4 * s) = u4;
+                // u of the steps this lane finishes (8 + 2s, 8 + 2s + 1): quad lane 2 + (s >> 1), components x, y / z, w
+                {
+                    const float a0 = dpp_quad_2233(u4.x), a1 = dpp_quad_2233(u4.z), b0 = dpp_quad_2233(u4.y), b1 = dpp_quad_2233(u4.w);
+                    uf.x = (s & 1) ? a1 : a0;
+                    uf.y = (s & 1) ? b1 : b0;
+                }
             } else {
                 // even visit: only the lower 8 steps: lane (cl, s) activates steps 2s, 2s+1.  They sit in the float4 of quad
                 // lane s >> 1 (components x, y for even s; z, w for odd s): two DPP moves and a select per value.
@@ -1065,7 +1076,7 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
                 da.y = act ? act_delta(raw.y, bias, softplus, tm + 2 * s + 1 < L) : 0.f;
                 *reinterpret_cast<float2 *>(sD + cl * SP16 + 2 * s) = da;
                 *reinterpret_cast<float2 *>(sX + cl * SP16 + 2 * s) = make_float2(da.x * ux, da.y * uy);
-                *reinterpret_cast<float2 *>(sU + cl * SP16 + 2 * s) = make_float2(ux, uy);
+                uf = make_float2(ux, uy);
             }
             *reinterpret_cast<float2 *>(sY + cl * SP8 + 2 * s) = cur.gy;
             wave_lds_fence();
@@ -1157,7 +1168,7 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
                 if (s == (k >> 1)) { Ts[k & 1] = a; Gs[k & 1] = c; }
             }
             const float2 d2 = *reinterpret_cast<const float2 *>(sD + cl * SP16 + ho + 2 * s);
-            const float2 u2 = *reinterpret_cast<const float2 *>(sU + cl * SP16 + ho + 2 * s);
+            const float2 u2 = uf;
             const float2 g2 = *reinterpret_cast<const float2 *>(sY + cl * SP8 + 2 * s);
             const float dl2[2] = {d2.x, d2.y}, uu2[2] = {u2.x, u2.y}, gg2[2] = {g2.x, g2.y};
             float odd2[2], odu2[2];
@@ -1190,15 +1201,14 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
 #pragma unroll
             for (int x = 0; x < 6; ++x) ev[x] = quad_sum(ev[x]);
             if (s == 0) {
-                float4 e0 = sE[(j * 16 + cl) * 2], e1 = sE[(j * 16 + cl) * 2 + 1];
-                e0.x += ev[0]; e0.y += ev[1]; e0.z += ev[2]; e0.w += ev[3];
-                e1.x += ev[4]; e1.y += ev[5];
-                sE[(j * 16 + cl) * 2] = e0;
-                sE[(j * 16 + cl) * 2 + 1] = e1;
+                float2 *e = sE + (j * 16 + cl) * 3;
+                float2 e0 = e[0], e1 = e[1], e2 = e[2];
+                e0.x += ev[0]; e0.y += ev[1]; e1.x += ev[2]; e1.y += ev[3]; e2.x += ev[4]; e2.y += ev[5];
+                e[0] = e0; e[1] = e1; e[2] = e2;
             }
         }
 
-        if (j == J - 1) {
+        if (last_slot) {
             // ---- sums over the 16 channel lanes (lane bits 2..5), once per tile for all J channels ----
             // value index = kind * 32 + i * 8 + k  (kind 0: dB, 1: dC).  permlane32 swap: lane bit 5 keeps its kind;
             // permlane16 swap: lane bit 4 keeps states i = 2 * bit4 + {0, 1}; the two low channel bits are an orbit of
@@ -1242,6 +1252,7 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
                     gstore2<VEC>(ddelta + bg * R * L, r * (unsigned)L + tm + 2 * s, (r + 1) * (unsigned)L, make_float2(w[0], w[1]));   // ddelta = d(dtr) here
             }
         }
+        m = mn; j = jn;
     }
 
     // per-chunk partial sums of dA (16 per channel), dD, ddelta_bias, dWdt -> selscan_reduce_partials
@@ -1253,9 +1264,9 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
                 float *prow = part + (crow * dim + g * Hc + cl + 16 * j) * PP;
                 *reinterpret_cast<float4 *>(prow + 4 * s) = sA[j * 64 + lane];
                 if (s == 0) {
-                    *reinterpret_cast<float4 *>(prow + NS) = sE[(j * 16 + cl) * 2];
-                    const float4 e1 = sE[(j * 16 + cl) * 2 + 1];
-                    *reinterpret_cast<float4 *>(prow + NS + 4) = make_float4(e1.x, e1.y, 0.f, 0.f);
+                    const float2 *e = sE + (j * 16 + cl) * 3;
+                    *reinterpret_cast<float4 *>(prow + NS) = make_float4(e[0].x, e[0].y, e[1].x, e[1].y);
+                    *reinterpret_cast<float4 *>(prow + NS + 4) = make_float4(e[2].x, e[2].y, 0.f, 0.f);
                 }
             }
         }
