@@ -27,6 +27,17 @@ IMG = (256, 256)
 BATCH_PER_GPU = 10
 N_CLASSES = 14
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# BASELINE.json configs by their 1-based position; 2 is the headline (the default).  The others print the same JSON line
+# for their own shape / arithmetic type and are never the headline number.
+CONFIGS = {
+    2: dict(img=(256, 256), in_ch=1, classes=14, batch=10, variant="B", precision="fp32", dtype="f32",
+            name="AbdomenMRI-shaped 256x256x1, 14 classes, attention variant B (BASELINE.json configs[1])"),
+    3: dict(img=(224, 224), in_ch=1, classes=4, batch=10, variant="B", precision="bf16", dtype="bf16",
+            name="ACDC-shaped 224x224x1, 4 classes, attention variant B, bf16 operands / fp32 sums (BASELINE.json configs[2])"),
+    5: dict(img=(512, 640), in_ch=3, classes=8, batch=4, variant="A", precision="fp16", dtype="f16",
+            name="Endovis17-shaped 512x640x3, 8 classes, shipped flash scaling (variant A), fp16 operands / fp32 sums + "
+                 "GradScaler (BASELINE.json configs[4])"),
+}
 
 
 def pmc_traffic(kernel, batch):
@@ -92,7 +103,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config (2 = headline)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default: the config's")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true",
@@ -102,6 +114,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    cfg = CONFIGS[args.config]
+    global IMG, N_CLASSES
+    IMG, N_CLASSES = cfg["img"], cfg["classes"]
+    if args.batch is None:
+        args.batch = cfg["batch"]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -128,15 +145,16 @@ def main():
     # The reference sets cudnn.benchmark=True (run_training.py:123-125); here: the committed result of that search
     miopen_db = miopen_tuning.use_tuned_convolutions()
     torch.manual_seed(0)
-    net = model.build_network_architecture(IMG, 1, N_CLASSES, True, "B").to(dev).train()
-    use_graph = args.graph and not ddp and not args.no_graph
+    net = model.build_network_architecture(IMG, cfg["in_ch"], N_CLASSES, True, cfg["variant"], cfg["precision"]).to(dev).train()
+    use_graph = args.graph and not ddp and not args.no_graph and cfg["precision"] == "fp32"
     opt, sched = trainer.configure_optimizers(net, capturable=use_graph)
     sched.step(0)
     step_net = trainer.wrap_ddp(net, dev_index) if ddp else net
-    data, target = trainer.synthetic_batch(args.batch, 1, *IMG, N_CLASSES, seed=1234 + rank, device=dev)
+    data, target = trainer.synthetic_batch(args.batch, cfg["in_ch"], *IMG, N_CLASSES, seed=1234 + rank, device=dev)
+    scaler = torch.amp.GradScaler("cuda") if cfg["precision"] == "fp16" else None      # reference B:152
 
     def eager_step():
-        return trainer.train_step(step_net, opt, data, target, batch_dice=True, ddp=ddp)
+        return trainer.train_step(step_net, opt, data, target, batch_dice=True, ddp=ddp, grad_scaler=scaler)
 
     one_step = eager_step
 
@@ -197,7 +215,7 @@ def main():
         alg = profiling.algorithmic_bytes(dominant, args.batch, IMG)
         achieved = alg / (avg_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dominant, args.batch),
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dominant, args.batch) if args.config == 2 else None,
                 "traffic_source": "static: profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                   "tools/bench_ops.py on the same shapes, gfx950 x2 fetch correction); not collected in this run",
                 "avg_launch_ms": round(avg_ms, 4), "launches_timed": res["count"],
@@ -213,19 +231,18 @@ def main():
     if rank == 0:
         n_img = args.batch * world * args.steps
         line = {
-            "metric": "images/sec (train step) MLAgg-UNet-2D 256x256 bs10",
+            "metric": f"images/sec (train step) MLAgg-UNet-2D {IMG[0]}x{IMG[1]} bs{args.batch}",
             "value": round(n_img / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "nnUNetTrainer_MLAgg_2D_dt_MS train step, AbdomenMRI-shaped 256x256x1, "
-                                   "14 classes, attention variant B (BASELINE.json configs[1])",
+            "scaling": "weak", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
+            "config": {"workload": "nnUNetTrainer_MLAgg_2D_dt_MS train step, " + cfg["name"],
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "final_loss": round(float(loss), 5),
                        "launch": "hipGraph replay of the whole step" if use_graph else "eager",
                        "miopen": "tuned find-db (mlagg-unet_amd/miopen_db)" if miopen_db else "immediate mode"},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == 2:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if ddp:

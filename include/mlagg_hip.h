@@ -25,6 +25,11 @@ extern "C" {
 #define MLAGG_E_NULLPTR     (-2)
 #define MLAGG_E_WORKSPACE   (-3)
 
+/* arithmetic type of the mixed-precision entry points (tensors stay fp32 in memory; see mlagg_linear_lp_*) */
+#define MLAGG_DTYPE_F32  0
+#define MLAGG_DTYPE_BF16 1
+#define MLAGG_DTYPE_F16  2
+
 const char *mlagg_version(void);
 const char *mlagg_error_string(int code);
 
@@ -158,6 +163,14 @@ int mlagg_linear_fwd(const float *x, int x_stride, const float *w, const float *
                      int M, int N, int K, void *stream);
 int mlagg_linear_dgrad(const float *dy, int dy_stride, const float *w, float *dx, int dx_stride, int M, int O, int I,
                        void *stream);
+/* Mixed precision: the same two products with the operands rounded to bf16 / fp16 (dtype = MLAGG_DTYPE_BF16 / _F16) on
+ * their way into the matrix cores and fp32 accumulation -- what torch.autocast makes of nn.Linear in the reference's
+ * default train step (mlagg/nnunetv2/training/nnUNetTrainer/nnUNetTrainer.py:848-851; fp16 + GradScaler :152, bf16 in
+ * BASELINE configs[2]).  x, w, y / dy, dx stay fp32 in memory, same layouts and strides as above. */
+int mlagg_linear_lp_fwd(const float *x, int x_stride, const float *w, const float *bias, float *y, int y_stride,
+                        int M, int N, int K, int dtype, void *stream);
+int mlagg_linear_lp_dgrad(const float *dy, int dy_stride, const float *w, float *dx, int dx_stride, int M, int O, int I,
+                          int dtype, void *stream);
 size_t mlagg_linear_wgrad_workspace_floats(int M, int O, int I);
 int mlagg_linear_wgrad(const float *dy, int dy_stride, const float *x, int x_stride, float *dW, float *db,
                        float *workspace, int M, int O, int I, void *stream);

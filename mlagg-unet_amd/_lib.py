@@ -72,6 +72,8 @@ SIGNATURES = {
     "mlagg_gate_bwd": (_I, [_F, _I, _F, _F, _F, _I, _F, _F, _F, ctypes.c_long, _I, _S]),
     "mlagg_linear_fwd": (_I, [_F, _I, _F, _F, _F, _I, _I, _I, _I, _S]),
     "mlagg_linear_dgrad": (_I, [_F, _I, _F, _F, _I, _I, _I, _I, _S]),
+    "mlagg_linear_lp_fwd": (_I, [_F, _I, _F, _F, _F, _I, _I, _I, _I, _I, _S]),
+    "mlagg_linear_lp_dgrad": (_I, [_F, _I, _F, _F, _I, _I, _I, _I, _I, _S]),
 }
 
 _lib = None

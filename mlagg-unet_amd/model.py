@@ -100,19 +100,31 @@ class Conv2d(nn.Conv2d):
     gradient is one plane-sum launch (inside convolution_backward it is a generic ATen reduction at 1.3-2 TB/s)."""
 
     def forward(self, x):
-        if self.bias is None or not x.is_cuda or self.padding_mode != "zeros":
+        cdt = ops.compute_dtype()
+        if not x.is_cuda or self.padding_mode != "zeros":
             return super().forward(x)
-        y = F.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation, self.groups)
-        return ops.channel_bias(y, self.bias)
+        if self.bias is None and cdt == torch.float32:
+            return super().forward(x)
+        # mixed precision: the convolution runs on 16-bit operands (what autocast makes of it, reference B:848); the
+        # map comes back fp32 for the HIP kernels that follow
+        y = F.conv2d(ops.lp(x, cdt), ops.lp(self.weight, cdt), None, self.stride, self.padding, self.dilation, self.groups)
+        if cdt != torch.float32:
+            y = y.float()
+        return y if self.bias is None else ops.channel_bias(y, self.bias)
 
 
 class ConvTranspose2d(nn.ConvTranspose2d):
     def forward(self, x, output_size=None):
-        if self.bias is None or not x.is_cuda or output_size is not None:
+        cdt = ops.compute_dtype()
+        if not x.is_cuda or output_size is not None:
             return super().forward(x, output_size)
-        y = F.conv_transpose2d(x, self.weight, None, self.stride, self.padding, self.output_padding, self.groups,
-                               self.dilation)
-        return ops.channel_bias(y, self.bias)
+        if self.bias is None and cdt == torch.float32:
+            return super().forward(x, output_size)
+        y = F.conv_transpose2d(ops.lp(x, cdt), ops.lp(self.weight, cdt), None, self.stride, self.padding,
+                               self.output_padding, self.groups, self.dilation)
+        if cdt != torch.float32:
+            y = y.float()
+        return y if self.bias is None else ops.channel_bias(y, self.bias)
 
 
 class GroupNorm(nn.GroupNorm):
@@ -606,8 +618,11 @@ class VSS_Conv_Layer(nn.Module):  # reference M:756-804
 class MLLA_Uper(nn.Module):  # reference T:1183-1407
     def __init__(self, img_size: Sequence[int], patch_size=2, in_channels=1, out_channels=14, embed_dim=96,
                  depths=(2, 2, 2, 2), num_heads=(2, 4, 8, 16), mlp_ratio=2, dropout_path_rate=0.1,
-                 sr_ratio=(16, 8, 4, 2), deep_supervision=True, variant="B"):
+                 sr_ratio=(16, 8, 4, 2), deep_supervision=True, variant="B", precision="fp32"):
         super().__init__()
+        if precision not in ops.PRECISIONS:
+            raise RuntimeError(f"precision {precision!r}: one of {tuple(ops.PRECISIONS)}")
+        self.precision = precision             # arithmetic type of the dense products (ops.compute_precision)
         self.deep_supervision = deep_supervision
         E = embed_dim
         self.mlla = MLLA_Enc(list(img_size), patch_size, in_channels, E, list(depths), list(num_heads), mlp_ratio,
@@ -636,7 +651,7 @@ class MLLA_Uper(nn.Module):  # reference T:1183-1407
     def forward(self, x_in):
         # The network computes in ITS precision whatever the caller's autocast state: the reference loop runs it under
         # autocast('cuda') (B:848), where the first MIOpen convolution would hand fp16 maps to fp32 HIP kernels.
-        with torch.autocast(x_in.device.type, enabled=False):
+        with torch.autocast(x_in.device.type, enabled=False), ops.compute_precision(self.precision):
             x_in = x_in.float()
             if not self.training:
                 return self._forward(x_in)
@@ -666,8 +681,8 @@ class MLLA_Uper(nn.Module):  # reference T:1183-1407
 
 
 def build_network_architecture(patch_size, num_input_channels, num_segmentation_heads, enable_deep_supervision=True,
-                               variant="B"):
+                               variant="B", precision="fp32"):
     """The hyper-parameters hard-coded at reference T:71-89; arguments are the only values that reach
     the model from the plans (patch_size, #channels, #classes)."""
     return MLLA_Uper(tuple(patch_size), 2, num_input_channels, num_segmentation_heads, 96, (2, 2, 2, 2),
-                     (2, 4, 8, 16), 2, 0.1, (16, 8, 4, 2), enable_deep_supervision, variant)
+                     (2, 4, 8, 16), 2, 0.1, (16, 8, 4, 2), enable_deep_supervision, variant, precision)

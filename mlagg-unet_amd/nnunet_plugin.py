@@ -7,10 +7,13 @@ nnunetv2 is not importable in the build container (its dependencies are absent o
 is produced by a factory that receives the base class.
 
 What the class overrides, and why the inherited method cannot stay (B = nnUNetTrainer.py, T = the reference trainer):
-  * ``train_step``  B:833-863 runs the network under ``autocast('cuda')`` with a ``GradScaler``.  The MI355X path of
-                    this class computes in the precision it was built with (``precision`` below), so the step is
-                    ``trainer.train_step`` (zero_grad, forward, loss, backward, clip 12, AdamW) and ``grad_scaler`` is
-                    None; the returned dictionary and the per-step host copy of the loss are the reference's (B:863).
+  * ``train_step``  B:833-863 runs the network under ``autocast('cuda')`` with a ``GradScaler``.  The MI355X network
+                    computes in the precision it was built with (``precision``: "fp32"; "bf16" / "fp16" = 16-bit
+                    operands of every Linear and convolution with fp32 sums, i.e. what autocast does to those layers),
+                    whatever the ambient autocast state, so the step is ``trainer.train_step`` (zero_grad, forward, loss,
+                    backward, clip 12, AdamW).  The ``GradScaler`` of B:152 is kept for "fp16" only (as in the reference,
+                    small gradients would otherwise flush to zero in the 16-bit operands) and dropped otherwise; the
+                    returned dictionary and the per-step host copy of the loss are the reference's (B:863).
   * ``initialize``  B:193-215 wraps with a plain ``DDP(...)``; here ``trainer.wrap_ddp`` (bucket views, no buffer
                     broadcast) and the loss is rebuilt so that it knows about DDP.
   * ``_build_loss`` T:106-129: the fused Dice + CE deep-supervision loss (K9) with the batch-dice exchange as one
@@ -20,7 +23,7 @@ import torch
 
 from . import evaluation, miopen_tuning, model, trainer
 
-PRECISIONS = ("fp32",)
+PRECISIONS = ("fp32", "bf16", "fp16")
 
 
 def make_trainer_class(nnUNetTrainer, variant="B", precision="fp32"):
@@ -39,9 +42,10 @@ def make_trainer_class(nnUNetTrainer, variant="B", precision="fp32"):
             self.num_val_iterations_per_epoch = 50
             self.num_epochs = 500
             self.current_epoch = 0
-            # B:152 creates a GradScaler for the fp16 autocast of B:848; this path does not scale the loss.  Checkpoints
+            # B:152 creates a GradScaler for the fp16 autocast of B:848.  fp32 / bf16 do not scale the loss: checkpoints
             # then carry ``grad_scaler_state: None`` exactly as the reference's CPU runs do (B:1018, 1047-1049).
-            self.grad_scaler = None
+            if precision != "fp16":
+                self.grad_scaler = None
             self.mlagg_precision = precision
             # run_training.py:123-125 sets cudnn.benchmark (MIOpen's exhaustive find); here: the committed find-db
             miopen_tuning.use_tuned_convolutions()
@@ -52,7 +56,7 @@ def make_trainer_class(nnUNetTrainer, variant="B", precision="fp32"):
             label_manager = plans_manager.get_label_manager(dataset_json)          # reference T:68
             return model.build_network_architecture(configuration_manager.patch_size, num_input_channels,
                                                     label_manager.num_segmentation_heads, enable_deep_supervision,
-                                                    variant)
+                                                    variant, precision)
 
         def initialize(self):                                                       # reference B:193-215
             ddp = self.is_ddp
@@ -101,7 +105,7 @@ def make_trainer_class(nnUNetTrainer, variant="B", precision="fp32"):
             if not isinstance(target, list):
                 target = [target]
             loss = trainer.train_step(self.network, self.optimizer, data.float(), [t.float() for t in target],
-                                      clip=12.0, loss_fn=self.loss)
+                                      clip=12.0, loss_fn=self.loss, grad_scaler=self.grad_scaler)
             return {"loss": loss.cpu().numpy()}                                     # the reference's per-step host copy
 
         def validation_step(self, batch):                                           # reference B:880-942

@@ -8,6 +8,43 @@ import torch
 from . import _lib
 
 
+# ------------------------------------------------------------------------------------------------
+# arithmetic type of the dense products.  The reference's default train step runs the network under autocast
+# (nnUNetTrainer.py:848: fp16 + GradScaler; BASELINE configs[2]: bf16): Linear / convolution operands are rounded to 16
+# bits, sums are fp32.  Here tensors stay fp32 in HBM in every mode; in "bf16" / "fp16" mode the projections (K5) and
+# the library convolutions / small GEMMs round their OPERANDS to that type for the matrix cores.
+# ------------------------------------------------------------------------------------------------
+PRECISIONS = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
+_LP_CODE = {torch.bfloat16: 1, torch.float16: 2}            # MLAGG_DTYPE_* of include/mlagg_hip.h
+_COMPUTE = [torch.float32]
+
+
+class compute_precision:
+    """with ops.compute_precision("bf16"): ... -- arithmetic type of the dense products inside the block."""
+
+    def __init__(self, precision):
+        if precision not in PRECISIONS:
+            raise RuntimeError(f"precision {precision!r}: one of {tuple(PRECISIONS)}")
+        self.dtype = PRECISIONS[precision]
+
+    def __enter__(self):
+        _COMPUTE.append(self.dtype)
+        return self
+
+    def __exit__(self, *exc):
+        _COMPUTE.pop()
+        return False
+
+
+def compute_dtype():
+    return _COMPUTE[-1]
+
+
+def lp(t, dtype):
+    """Operand of a library GEMM / convolution in the arithmetic type of the block (identity in fp32 mode)."""
+    return t if (t is None or dtype == torch.float32) else t.to(dtype)
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -301,15 +338,22 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.cdt = cdt = compute_dtype()
         O, I = weight.shape
         M = x.numel() // I
         if M >= WGRAD_MIN_ROWS and I % 4 == 0 and x.is_cuda:
             x2, xs = _mfma_rows(x, "x")
             w = _require(weight.contiguous(), "weight")
             y = torch.empty(x.shape[:-1] + (O,), device=x.device, dtype=torch.float32)
-            _lib.check(_lib.lib().mlagg_linear_fwd(_ptr(x2), xs, _ptr(w), _ptr(bias), _ptr(y), O, M, O, I, _stream()),
-                       "mlagg_linear_fwd")
+            if cdt == torch.float32:
+                _lib.check(_lib.lib().mlagg_linear_fwd(_ptr(x2), xs, _ptr(w), _ptr(bias), _ptr(y), O, M, O, I, _stream()),
+                           "mlagg_linear_fwd")
+            else:
+                _lib.check(_lib.lib().mlagg_linear_lp_fwd(_ptr(x2), xs, _ptr(w), _ptr(bias), _ptr(y), O, M, O, I,
+                                                          _LP_CODE[cdt], _stream()), "mlagg_linear_lp_fwd")
             return y
+        if cdt != torch.float32:
+            return torch.nn.functional.linear(x.to(cdt), weight.to(cdt), lp(bias, cdt)).float()
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
@@ -317,6 +361,7 @@ class LinearFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         dx = dW = db = None
         O, I = weight.shape
+        cdt = ctx.cdt
         dy2, dys = _mfma_rows(dy, "dy")
         M = dy2.shape[0]
         big = M >= WGRAD_MIN_ROWS
@@ -325,11 +370,18 @@ class LinearFn(torch.autograd.Function):
             if big and O % 4 == 0 and I % 4 == 0:
                 w = _require(weight.contiguous(), "weight")
                 dx = torch.empty(x.shape, device=dy.device, dtype=torch.float32)
-                _lib.check(lib.mlagg_linear_dgrad(_ptr(dy2), dys, _ptr(w), _ptr(dx), I, M, O, I, _stream()),
-                           "mlagg_linear_dgrad")
+                if cdt == torch.float32:
+                    _lib.check(lib.mlagg_linear_dgrad(_ptr(dy2), dys, _ptr(w), _ptr(dx), I, M, O, I, _stream()),
+                               "mlagg_linear_dgrad")
+                else:
+                    _lib.check(lib.mlagg_linear_lp_dgrad(_ptr(dy2), dys, _ptr(w), _ptr(dx), I, M, O, I, _LP_CODE[cdt],
+                                                         _stream()), "mlagg_linear_lp_dgrad")
+            elif cdt != torch.float32:
+                dx = dy.to(cdt).matmul(weight.to(cdt)).float()
             else:
                 dx = dy.matmul(weight)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            # weight / bias gradients stay fp32 in every mode (K5w: the token sum is the long one)
             x2, xs = _rows2d(x, "x")
             if big:
                 # dW | db in one allocation: the kernel zero-fills both with a single memset

@@ -272,13 +272,25 @@ def set_deep_supervision_enabled(network, enabled):
 # step
 # ------------------------------------------------------------------------------------------------
 def train_step(network, optimizer, data, target: List[torch.Tensor], batch_dice=True, ddp=False, clip=12.0,
-               loss_fn=None):
+               loss_fn=None, grad_scaler=None):
     """One optimisation step on device-resident tensors; returns the detached loss tensor (the caller
     decides when to synchronise -- the reference's ``.cpu()`` per step, B:863, is a host sync).
-    ``loss_fn(output, target)`` replaces the Dice + CE deep-supervision loss (the trainer plugin passes ``self.loss``)."""
+    ``loss_fn(output, target)`` replaces the Dice + CE deep-supervision loss (the trainer plugin passes ``self.loss``).
+    ``grad_scaler``: the reference's fp16 branch (B:853-858): scaled backward, unscale, clip, step, update -- for networks
+    built with ``precision="fp16"``, whose 16-bit GEMM operands would flush small gradients to zero unscaled."""
     optimizer.zero_grad(set_to_none=True)
     output = network(data)
     loss = deep_supervision_loss(output, target, batch_dice, ddp) if loss_fn is None else loss_fn(output, target)
+    if grad_scaler is not None:
+        grad_scaler.scale(loss).backward()
+        grad_scaler.unscale_(optimizer)
+        if isinstance(optimizer, ClipAdamW):
+            grad_scaler.step(optimizer, max_norm=clip)
+        else:
+            torch.nn.utils.clip_grad_norm_([p for p in network.parameters() if p.grad is not None], clip)
+            grad_scaler.step(optimizer)
+        grad_scaler.update()
+        return loss.detach()
     loss.backward()
     if isinstance(optimizer, ClipAdamW):
         optimizer.step(max_norm=clip)                      # norm, clip coefficient and AdamW on the device, two launches

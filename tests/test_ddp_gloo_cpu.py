@@ -113,7 +113,7 @@ def _plugin_case(rank, world):
     from mlagg_unet_amd import model, nnunet_plugin, trainer
     from torch.nn.parallel import DistributedDataParallel as DDP
 
-    def build(patch_size, in_ch, n_cls, ds=True, variant="B"):
+    def build(patch_size, in_ch, n_cls, ds=True, variant="B", precision="fp32"):
         torch.manual_seed(0)
         return TP.StubNet(in_ch, n_cls, ds)
 

@@ -1,0 +1,106 @@
+"""GPU: the mixed-precision form of the path (reference default train step: autocast, nnUNetTrainer.py:848-858; BASELINE
+configs[2] bf16, configs[4] fp16 + flash scaling).  Tensors stay fp32; Linear / convolution operands are rounded to 16
+bits, sums are fp32.
+
+Tolerances.  A bf16 operand carries 8 significant bits (relative rounding 2^-9 = 2e-3), an fp16 one 11 (5e-4); the
+reference under autocast additionally rounds every Linear / convolution OUTPUT to 16 bits, which this path does not.
+Measured on the goldens: the reference's own bf16-autocast logits sit 2e-2 (max abs) from its fp32 logits at 224 x 224,
+its fp16-autocast loss 1.3 % from its fp32 loss at 512 x 640.  The checks below therefore hold the mixed-precision
+product to the fp32 reference within the reference's own autocast deviation (x2), and to the autocast goldens within
+twice that again."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mlagg_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(16384, 192, 96), (20000, 140, 96), (8200, 96, 384)])
+def test_lp_linear_equals_rounded_operand_product(dtype, M, N, K):
+    """K5 in 16-bit mode: y = round16(x) round16(W)^T + b and dx = round16(dy) round16(W), sums in fp32."""
+    from mlagg_unet_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    xg, wg, bg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    with ops.compute_precision("bf16" if dtype == torch.bfloat16 else "fp16"):
+        y = ops.linear(xg, wg, bg)
+    y.backward(dy.to(DEV))
+    r = lambda t: t.to(dtype).double()                               # noqa: E731
+    y_ref = r(x) @ r(w).T + b.double()
+    dx_ref = r(dy) @ r(w)
+    assert float((y.detach().cpu().double() - y_ref).abs().max()) < 2e-5 * float(y_ref.abs().max())
+    assert float((xg.grad.cpu().double() - dx_ref).abs().max()) < 2e-5 * float(dx_ref.abs().max())
+    dw_ref = dy.double().T @ x.double()                              # weight gradient stays fp32
+    assert float((wg.grad.cpu().double() - dw_ref).abs().max()) < 2e-5 * float(dw_ref.abs().max())
+    assert float((bg.grad.cpu().double() - dy.double().sum(0)).abs().max()) < 1e-3
+
+
+def _run(tag_fp32, precision):
+    from mlagg_unet_amd import model as PM, trainer as TR
+    g = np.load(os.path.join(GOLD, f"full_model_{tag_fp32}.npz"))
+    img = tuple(int(v) for v in g["img"])
+    in_ch, n_cls, batch, variant = int(g["in_ch"]), int(g["n_cls"]), int(g["batch"]), str(g["variant"])
+    m = PM.build_network_architecture(img, in_ch, n_cls, True, variant, precision)
+    O.deterministic_fill_(m.state_dict())
+    m = m.to(DEV).eval()
+    data, target = O.synthetic_batch(batch, in_ch, *img, n_cls, seed=int(g["data_seed"]))
+    out = m(data.to(DEV))
+    assert all(o.dtype == torch.float32 for o in out)
+    loss = TR.deep_supervision_loss(out, [t.to(DEV) for t in target], batch_dice=True)
+    loss.backward()
+    norms = {n: float(p.grad.double().norm()) for n, p in m.named_parameters() if p.grad is not None}
+    return out, float(loss.detach()), norms
+
+
+def _compare(out, loss, norms, g, logit_tol, loss_tol, grad_rtol):
+    worst_logit = 0.0
+    for i, o in enumerate(out):
+        s = int(g[f"out{i}_stride"])
+        worst_logit = max(worst_logit, float((o.detach().cpu()[:, :, ::s, ::s] - torch.from_numpy(g[f"out{i}_sub"]).float()).abs().max()))
+    assert worst_logit < logit_tol, worst_logit
+    assert abs(loss - float(g["loss"])) < loss_tol, (loss, float(g["loss"]))
+    bad = [(str(n), norms[str(n)], float(r)) for n, r in zip(g["grad_names"], g["grad_norms"])
+           if abs(norms[str(n)] - r) > grad_rtol * max(r, 1e-2)]
+    assert len(bad) <= len(norms) // 50, bad[:5]              # 2 % of the 524 tensors may sit outside (tiny gradients)
+    return worst_logit
+
+
+def test_bf16_config_matches_reference_fp32_and_autocast_goldens():
+    """BASELINE configs[2] shape (224 x 224, 4 classes, variant B) in bf16 mode."""
+    out, loss, norms = _run("224_variantB", "bf16")
+    a = _compare(out, loss, norms, np.load(os.path.join(GOLD, "full_model_224_variantB.npz")), 4e-2, 2e-3, 0.05)
+    b = _compare(out, loss, norms, np.load(os.path.join(GOLD, "full_model_224_variantB_bf16.npz")), 8e-2, 4e-3, 0.10)
+    print("bf16 224: max |logit - fp32 reference|", a, " max |logit - bf16-autocast reference|", b)
+
+
+def test_fp16_flash_config_matches_reference_goldens():
+    """BASELINE configs[4] shape (512 x 640 RGB, 8 classes, variant A = the shipped flash scaling) in fp16 mode."""
+    out, loss, norms = _run("512x640_variantA", "fp16")
+    a = _compare(out, loss, norms, np.load(os.path.join(GOLD, "full_model_512x640_variantA.npz")), 2e-2, 2e-3, 0.05)
+    b = _compare(out, loss, norms, np.load(os.path.join(GOLD, "full_model_512x640_variantA_fp16.npz")), 0.5, 0.12, 0.25)
+    print("fp16 512x640: max |logit - fp32 reference|", a, " max |logit - fp16-autocast reference|", b)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_mixed_precision_train_steps_fit_a_batch(precision):
+    """Five optimisation steps on one batch (fp16: through the GradScaler branch of the reference step, B:853-858)."""
+    from mlagg_unet_amd import model as PM, trainer as TR
+    torch.manual_seed(0)
+    net = PM.build_network_architecture((64, 64), 1, 14, True, "B", precision)
+    O.deterministic_fill_(net.state_dict())
+    net = net.to(DEV).eval()
+    opt, _ = TR.configure_optimizers(net)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0) if precision == "fp16" else None
+    data, target = TR.synthetic_batch(2, 1, 64, 64, 14, seed=99, device=DEV)
+    losses = [float(TR.train_step(net, opt, data, target, grad_scaler=scaler)) for _ in range(5)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses

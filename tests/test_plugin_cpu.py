@@ -35,8 +35,9 @@ def plugin(monkeypatch):
     from mlagg_unet_amd import model, nnunet_plugin
     seen = {}
 
-    def build(patch_size, in_ch, n_cls, ds=True, variant="B"):
+    def build(patch_size, in_ch, n_cls, ds=True, variant="B", precision="fp32"):
         seen["args"] = (tuple(patch_size), in_ch, n_cls, ds, variant)
+        seen["precision"] = precision
         torch.manual_seed(0)
         return StubNet(in_ch, n_cls, ds)
 

@@ -44,9 +44,9 @@ def test_plugin_train_step_equals_trainer_train_step():
         got = tr.train_step(b)
         torch.manual_seed(5)
         want = trainer.train_step(twin, twin_opt, b["data"].cuda(), [t.cuda() for t in b["target"]], batch_dice=True)
-        assert isinstance(got["loss"], np.ndarray) and float(got["loss"]) == float(want)
+        assert isinstance(got["loss"], np.ndarray) and abs(float(got["loss"]) - float(want)) < 2e-5
     assert tr.base_calls["train_step"] == 0 and tr.base_calls["_build_loss"] == 0
-    # The losses above are bit-identical.  The parameters agree to a few percent of ONE AdamW step (lr 5e-4): weight
+    # The losses above agree to rounding (the first one bit for bit).  The parameters agree to a few percent of ONE AdamW step (lr 5e-4): weight
     # gradients are sums of ~10^4 cancelling terms that go through float atomics (MIOpen's weight-gradient kernels, K1
     # backward), so their low bits depend on the order the hardware retires the adds in, and AdamW's m / sqrt(v)
     # normalisation turns a 1e-3 relative wobble of a small gradient into 1e-3 of the step.
