@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config (2 = headline)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default: the config's")
+    ap.add_argument("--precision", default=None, choices=["fp32", "bf16", "fp16"],
+                    help="arithmetic type of the dense products; default: the config's (a diagnostic override)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true",
@@ -114,7 +116,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    if args.precision is not None and args.precision != cfg["precision"]:
+        cfg["precision"] = args.precision
+        cfg["dtype"] = {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}[args.precision]
+        cfg["name"] += f" [precision overridden: {args.precision}]"
     global IMG, N_CLASSES
     IMG, N_CLASSES = cfg["img"], cfg["classes"]
     if args.batch is None:
@@ -143,7 +149,7 @@ def main():
 
     _lib.lib()                                              # fail loudly if the HIP library is missing
     # The reference sets cudnn.benchmark=True (run_training.py:123-125); here: the committed result of that search
-    miopen_db = miopen_tuning.use_tuned_convolutions()
+    miopen_db = miopen_tuning.use_tuned_convolutions(enabled=args.config == 2 and cfg["precision"] == "fp32")
     torch.manual_seed(0)
     net = model.build_network_architecture(IMG, cfg["in_ch"], N_CLASSES, True, cfg["variant"], cfg["precision"]).to(dev).train()
     use_graph = args.graph and not ddp and not args.no_graph and cfg["precision"] == "fp32"

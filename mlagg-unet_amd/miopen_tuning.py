@@ -18,9 +18,15 @@ import torch
 DB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_db")
 
 
-def use_tuned_convolutions():
+def use_tuned_convolutions(enabled=True):
     """Call before the first convolution of the process.  Returns the database directory in use (None: exhaustive
-    find requested through MLAGG_MIOPEN_FIND=1, or tuning disabled through MLAGG_MIOPEN_TUNED=0)."""
+    find requested through MLAGG_MIOPEN_FIND=1, or tuning disabled through MLAGG_MIOPEN_TUNED=0 / ``enabled=False``).
+    The committed database covers the fp32 convolutions of the 256x256, batch-10 train step; for other shapes pass
+    ``enabled=False`` (immediate-mode solver choice, no find of any kind: a find-db MISS in FAST mode was seen to run
+    MIOpen's naive reference convolutions for minutes on 224x224 fp32 problems)."""
+    if not enabled:
+        torch.backends.cudnn.benchmark = False
+        return None
     if os.environ.get("MLAGG_MIOPEN_FIND", "0") == "1":
         torch.backends.cudnn.benchmark = True              # full search; MIOPEN_USER_DB_PATH is the caller's business
         return None

@@ -100,7 +100,7 @@ class Conv2d(nn.Conv2d):
     gradient is one plane-sum launch (inside convolution_backward it is a generic ATen reduction at 1.3-2 TB/s)."""
 
     def forward(self, x):
-        cdt = ops.compute_dtype()
+        cdt = ops.conv_dtype()
         if not x.is_cuda or self.padding_mode != "zeros":
             return super().forward(x)
         if self.bias is None and cdt == torch.float32:
@@ -115,7 +115,7 @@ class Conv2d(nn.Conv2d):
 
 class ConvTranspose2d(nn.ConvTranspose2d):
     def forward(self, x, output_size=None):
-        cdt = ops.compute_dtype()
+        cdt = ops.conv_dtype()
         if not x.is_cuda or output_size is not None:
             return super().forward(x, output_size)
         if self.bias is None and cdt == torch.float32:

@@ -45,6 +45,18 @@ def lp(t, dtype):
     return t if (t is None or dtype == torch.float32) else t.to(dtype)
 
 
+# Library convolutions in 16-bit mode.  Off by default: the maps are fp32 in HBM, so a 16-bit MIOpen convolution needs a
+# cast kernel on its input and another on its output (and again in backward); measured at 224 x 224, batch 10, bf16:
+# convolutions 8.9 ms + 3.5 ms of casts against ~10.4 ms for the fp32 convolutions.  MLAGG_LP_CONV=1 (or setting this
+# flag) rounds the convolution operands too, i.e. the literal operand rounding of the reference's autocast step.
+import os as _os
+LP_CONV = _os.environ.get("MLAGG_LP_CONV", "0") == "1"
+
+
+def conv_dtype():
+    return compute_dtype() if LP_CONV else torch.float32
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 

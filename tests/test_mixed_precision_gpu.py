@@ -4,10 +4,14 @@ bits, sums are fp32.
 
 Tolerances.  A bf16 operand carries 8 significant bits (relative rounding 2^-9 = 2e-3), an fp16 one 11 (5e-4); the
 reference under autocast additionally rounds every Linear / convolution OUTPUT to 16 bits, which this path does not.
-Measured on the goldens: the reference's own bf16-autocast logits sit 2e-2 (max abs) from its fp32 logits at 224 x 224,
-its fp16-autocast loss 1.3 % from its fp32 loss at 512 x 640.  The checks below therefore hold the mixed-precision
-product to the fp32 reference within the reference's own autocast deviation (x2), and to the autocast goldens within
-twice that again."""
+Measured between the reference's OWN goldens (tests/golden/full_model_224_variantB{,_bf16}.npz and
+full_model_512x640_variantA{,_fp16}.npz, made by the reference network with and without torch.autocast):
+  bf16 @ 224 x 224 : logits max |autocast - fp32| = 0.53 (mean 0.03 .. 0.12) on logits of magnitude <= 28; loss 1.6e-4;
+                     gradient norms: median 0.2 %, 5 of 524 tensors beyond 5 %, worst 18 %
+  fp16 @ 512 x 640 : logits max 0.056 (mean 0.002 .. 0.01) on magnitude <= 21; loss 0.056 (the loss itself is evaluated
+                     in half precision under CPU autocast); gradient norms: median 0.08 %, 5 tensors beyond 5 %, worst 13 %
+The checks hold the mixed-precision product to the fp32 reference within 1.5x of those deviations, and to the autocast
+goldens within the sum of both deviations."""
 import os
 
 import numpy as np
@@ -71,30 +75,32 @@ def _compare(out, loss, norms, g, logit_tol, loss_tol, grad_rtol):
     assert abs(loss - float(g["loss"])) < loss_tol, (loss, float(g["loss"]))
     bad = [(str(n), norms[str(n)], float(r)) for n, r in zip(g["grad_names"], g["grad_norms"])
            if abs(norms[str(n)] - r) > grad_rtol * max(r, 1e-2)]
-    assert len(bad) <= len(norms) // 50, bad[:5]              # 2 % of the 524 tensors may sit outside (tiny gradients)
+    assert len(bad) <= len(norms) // 50, bad[:5]              # 2 % of the 524 tensors may sit outside (as in the reference's own pair)
     return worst_logit
 
 
 def test_bf16_config_matches_reference_fp32_and_autocast_goldens():
     """BASELINE configs[2] shape (224 x 224, 4 classes, variant B) in bf16 mode."""
     out, loss, norms = _run("224_variantB", "bf16")
-    a = _compare(out, loss, norms, np.load(os.path.join(GOLD, "full_model_224_variantB.npz")), 4e-2, 2e-3, 0.05)
-    b = _compare(out, loss, norms, np.load(os.path.join(GOLD, "full_model_224_variantB_bf16.npz")), 8e-2, 4e-3, 0.10)
+    a = _compare(out, loss, norms, np.load(os.path.join(GOLD, "full_model_224_variantB.npz")), 0.8, 5e-3, 0.05)
+    b = _compare(out, loss, norms, np.load(os.path.join(GOLD, "full_model_224_variantB_bf16.npz")), 1.3, 5e-3, 0.10)
     print("bf16 224: max |logit - fp32 reference|", a, " max |logit - bf16-autocast reference|", b)
 
 
 def test_fp16_flash_config_matches_reference_goldens():
     """BASELINE configs[4] shape (512 x 640 RGB, 8 classes, variant A = the shipped flash scaling) in fp16 mode."""
     out, loss, norms = _run("512x640_variantA", "fp16")
-    a = _compare(out, loss, norms, np.load(os.path.join(GOLD, "full_model_512x640_variantA.npz")), 2e-2, 2e-3, 0.05)
-    b = _compare(out, loss, norms, np.load(os.path.join(GOLD, "full_model_512x640_variantA_fp16.npz")), 0.5, 0.12, 0.25)
+    a = _compare(out, loss, norms, np.load(os.path.join(GOLD, "full_model_512x640_variantA.npz")), 0.085, 2e-3, 0.05)
+    b = _compare(out, loss, norms, np.load(os.path.join(GOLD, "full_model_512x640_variantA_fp16.npz")), 0.14, 0.08, 0.10)
     print("fp16 512x640: max |logit - fp32 reference|", a, " max |logit - fp16-autocast reference|", b)
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp16"])
-def test_mixed_precision_train_steps_fit_a_batch(precision):
-    """Five optimisation steps on one batch (fp16: through the GradScaler branch of the reference step, B:853-858)."""
-    from mlagg_unet_amd import model as PM, trainer as TR
+@pytest.mark.parametrize("precision,lp_conv", [("bf16", False), ("fp16", False), ("bf16", True), ("fp16", True)])
+def test_mixed_precision_train_steps_fit_a_batch(precision, lp_conv, monkeypatch):
+    """Five optimisation steps on one batch (fp16: through the GradScaler branch of the reference step, B:853-858), with
+    the library convolutions in fp32 (default) and with their operands rounded to 16 bits too (ops.LP_CONV)."""
+    from mlagg_unet_amd import model as PM, ops, trainer as TR
+    monkeypatch.setattr(ops, "LP_CONV", lp_conv)
     torch.manual_seed(0)
     net = PM.build_network_architecture((64, 64), 1, 14, True, "B", precision)
     O.deterministic_fill_(net.state_dict())
