@@ -176,6 +176,24 @@ int mlagg_linear_wgrad(const float *dy, int dy_stride, const float *x, int x_str
                        float *workspace, int M, int O, int I, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Boundary #3: `flash_attn.flash_attn_func(q, k, v, causal=False)` as called four times per pooled AggregatedAttention
+ * (nnUNetTrainer_MLAgg_2D_dt_MS.py:173, 745-750): out = softmax(q k^T * softmax_scale) v per (batch, head), 16-bit
+ * tensors (dtype = MLAGG_DTYPE_BF16 / _F16), fp32 arithmetic.  Serves mlagg_unet_amd.shims.flash_attn_func (the
+ * reference's own model file running unmodified); the product network uses the fused K4 launch instead.
+ *   q, out, dout, dq  (B, N, nh, head_dim)     head_dim must be 24 (every MLAgg-UNet stage), P <= 512
+ *   k, v              (B, P, nh, head_dim)
+ *   lse               (B, nh, N) fp32, written by fwd when not NULL (needed by bwd)
+ *   workspace         mlagg_flash_attn_bwd_workspace_floats() floats; after bwd its LAST B*P*nh*2*head_dim floats hold
+ *                     the fp32 gradients (B, P, nh, 2, head_dim): [..., 0, :] = dk, [..., 1, :] = dv
+ * ------------------------------------------------------------------------------------------ */
+int mlagg_flash_attn_fwd(const void *q, const void *k, const void *v, void *out, float *lse, int B, int N, int P, int nh,
+                         int head_dim, float softmax_scale, int dtype, void *stream);
+size_t mlagg_flash_attn_bwd_workspace_floats(int B, int N, int P, int nh, int head_dim);
+int mlagg_flash_attn_bwd(const void *q, const void *k, const void *v, const void *out, const void *dout, const float *lse,
+                         void *dq, float *workspace, int B, int N, int P, int nh, int head_dim, float softmax_scale,
+                         int dtype, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * K6: LayerNorm over the last dimension of token-major rows, x (rows, C) with row stride x_stride,
  * y (rows, C) contiguous.  Replaces nn.LayerNorm at nnUNetTrainer_MLAgg_2D_dt_MS.py:723, 887, 907, 984-1001 and
  * MambaSkip.py:536, 741-742.  Built for C in {48, 96, 192, 384, 768} (mlagg_layernorm_supported).

@@ -74,6 +74,9 @@ SIGNATURES = {
     "mlagg_linear_dgrad": (_I, [_F, _I, _F, _F, _I, _I, _I, _I, _S]),
     "mlagg_linear_lp_fwd": (_I, [_F, _I, _F, _F, _F, _I, _I, _I, _I, _I, _S]),
     "mlagg_linear_lp_dgrad": (_I, [_F, _I, _F, _F, _I, _I, _I, _I, _I, _S]),
+    "mlagg_flash_attn_fwd": (_I, [_F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _FL, _I, _S]),
+    "mlagg_flash_attn_bwd_workspace_floats": (_SZ, [_I, _I, _I, _I, _I]),
+    "mlagg_flash_attn_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _FL, _I, _S]),
 }
 
 _lib = None

@@ -312,6 +312,47 @@ class PooledDiffAttnFn(torch.autograd.Function):
         return dq, dkp, dvp, small[0].reshape(()), small[1:], None, None
 
 
+class FlashAttnFn(torch.autograd.Function):
+    """Boundary #3: softmax(q k^T scale) v on 16-bit (B, N, nh, 24) / (B, P, nh, 24) tensors, fp32 arithmetic."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        if not (q.is_cuda and q.dtype in _LP_CODE and k.dtype == q.dtype and v.dtype == q.dtype):
+            raise RuntimeError("flash_attn_func: fp16 / bf16 tensors on the MI355X device expected "
+                               f"(got {q.dtype}, {k.dtype}, {v.dtype} on {q.device})")
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        B, N, nh, e = q.shape
+        P = k.shape[1]
+        if tuple(k.shape) != (B, P, nh, e) or tuple(v.shape) != (B, P, nh, e):
+            raise RuntimeError(f"flash_attn_func: bad shapes q {tuple(q.shape)} k {tuple(k.shape)} v {tuple(v.shape)}")
+        out = torch.empty_like(q)
+        need = any(ctx.needs_input_grad[:3])
+        lse = torch.empty(B, nh, N, device=q.device, dtype=torch.float32) if need else None
+        _lib.check(_lib.lib().mlagg_flash_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, N, P, nh, e, float(scale),
+                                                   _LP_CODE[q.dtype], _stream()), "mlagg_flash_attn_fwd")
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.scale = float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        B, N, nh, e = q.shape
+        P = k.shape[1]
+        dout = dout.contiguous().to(q.dtype)
+        lib = _lib.lib()
+        dq = torch.empty_like(q)
+        ws = torch.empty(lib.mlagg_flash_attn_bwd_workspace_floats(B, N, P, nh, e), device=q.device, dtype=torch.float32)
+        _lib.check(lib.mlagg_flash_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dq), _ptr(ws),
+                                            B, N, P, nh, e, ctx.scale, _LP_CODE[q.dtype], _stream()), "mlagg_flash_attn_bwd")
+        dkv = ws[B * nh * N:].view(B, P, nh, 2, e)
+        return dq, dkv[:, :, :, 0].to(q.dtype), dkv[:, :, :, 1].to(q.dtype), None
+
+
+def flash_attn(q, k, v, softmax_scale=None):
+    return FlashAttnFn.apply(q, k, v, q.shape[-1] ** -0.5 if softmax_scale is None else softmax_scale)
+
+
 def local_diff_attn(q, kv, lam, subln_w, lepe_w, lepe_b, H, W, nh, scale):
     return LocalDiffAttnFn.apply(q, kv, lam, subln_w, lepe_w, lepe_b, H, W, nh, scale)
 

@@ -7,13 +7,12 @@ files run unmodified on MI355X:
 * ``mamba_ssm.ops.selective_scan_interface.selective_scan_fn``  (imported at MambaSkip.py:18, called at
   M:445-451) -> K1, the HIP selective scan.
 * ``flash_attn.flash_attn_func`` (imported unconditionally at nnUNetTrainer_MLAgg_2D_dt_MS.py:173, called at
-  T:745-750) -> exact softmax attention on PyTorch-ROCm's fused SDPA.  The product network does not use this
-  shim: its pooled branch is the single fused K4 launch (ops.pooled_diff_attn) instead of four calls.
+  T:745-750) -> the HIP attention kernels of csrc/flash_attn.hip (ops.flash_attn: fp16 / bf16 tensors, head_dim 24,
+  forward and backward), with flash-attn's own contract: 16-bit CUDA tensors only.  The product network does not use
+  this shim: its pooled branch is the single fused K4 launch (ops.pooled_diff_attn) instead of four calls.
 """
 import sys
 import types
-
-import torch.nn.functional as F
 
 from . import ops
 
@@ -27,11 +26,9 @@ def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, **
     """q (B, N, nh, e), k/v (B, P, nh, e) -> (B, N, nh, e); default softmax_scale = e^-0.5 (flash-attn)."""
     if dropout_p != 0.0:
         raise RuntimeError("flash_attn_func shim: dropout is not on the MLAgg-UNet path")
-    if not q.is_cuda:
-        raise RuntimeError("flash_attn_func shim: tensors must be on the MI355X device")
-    out = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2),
-                                         is_causal=bool(causal), scale=softmax_scale)
-    return out.transpose(1, 2)
+    if causal:
+        raise RuntimeError("flash_attn_func shim: causal attention is not on the MLAgg-UNet path (T:745-750 pass causal=False)")
+    return ops.flash_attn(q, k, v, softmax_scale)          # raises for fp32 / host tensors, as flash-attn itself does
 
 
 def install():

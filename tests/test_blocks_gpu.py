@@ -160,12 +160,13 @@ def test_shims_expose_reference_import_names():
     from flash_attn import flash_attn_func
     from mamba_ssm.ops.selective_scan_interface import selective_scan_fn
     g = torch.Generator().manual_seed(2)
-    q = torch.randn(2, 50, 3, 24, generator=g)
-    k = torch.randn(2, 16, 3, 24, generator=g)
-    v = torch.randn(2, 16, 3, 24, generator=g)
-    ref = O.softmax_attention_oracle(q, k, v)
+    q = torch.randn(2, 50, 3, 24, generator=g).half()           # flash-attn takes fp16 / bf16 only (SURVEY finding 5)
+    k = torch.randn(2, 16, 3, 24, generator=g).half()
+    v = torch.randn(2, 16, 3, 24, generator=g).half()
+    ref = O.softmax_attention_oracle(q.float(), k.float(), v.float())
     got = flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), causal=False)
-    _close(got, ref, 1e-5, 1e-4, "flash shim")
+    assert got.dtype == torch.float16
+    _close(got.float(), ref, 2e-3, 2e-3, "flash shim")
     u = torch.randn(1, 8, 40, generator=g)
     A = -torch.rand(8, 16, generator=g)
     Bm = torch.randn(1, 2, 16, 40, generator=g)
