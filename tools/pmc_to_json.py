@@ -18,7 +18,8 @@ import sys
 
 # rocprof's template spellings of the low-rank scan kernels -> the library's profile names (bench.py looks these up)
 LIB_NAMES = {"selscan_fwd_kernel<false, true>": "selscan_fwd_kernel<false>", "selscan_fwd_kernel<true, true>": "selscan_fwd_kernel<true>",
-             "selscan_bwd_kernel<true>": "selscan_bwd_kernel", "selscan_bwd_local_kernel<true>": "selscan_bwd_local_kernel"}
+             "selscan_bwd_kernel<true>": "selscan_bwd_kernel", "selscan_bwd_local_kernel<true>": "selscan_bwd_local_kernel",
+             "selscan_bwd_group_kernel": "selscan_bwd_kernel"}     # round 2: the group-per-wave form serves the same entry point
 
 
 def load(d):
