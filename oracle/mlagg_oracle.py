@@ -5,8 +5,8 @@ reference algorithm.  Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu
 leg of ``bench.py`` may import it; the product package (``mlagg-unet_amd/``) never does.
 
 Pinning status: the restatement is checked against the reference's own model classes
-imported in the build container (``oracle/validate_against_reference.py``; fixtures under
-``tests/golden/``).  The third-party arithmetic the reference calls but does not vendor
+imported in the build container: ``tests/golden/make_golden.py`` runs them and stores their
+outputs under ``tests/golden/``; ``tests/test_oracle_golden.py`` holds this file to those fixtures.  The third-party arithmetic the reference calls but does not vendor
 (mamba-ssm ``selective_scan_fn``, flash-attn, MONAI Unetr blocks, timm DropPath) is
 restated from its published semantics -- **parity unpinned** at those four boundaries
 (SURVEY.md section 8c).
