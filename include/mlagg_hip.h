@@ -270,6 +270,19 @@ int mlagg_channel_sum(const float *g, float *out, float *workspace, int B, int C
 int mlagg_column_sum(const float *x, int x_stride, float *out, int rows, int cols, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K13: epilogue of the library convolutions on NCHW maps (B, C, HW): y = act(x + bias[c] + res), act 0 = none (in place on
+ * x, y ignored), 1 = GELU (erf form; x is overwritten with the pre-activation, y receives the result).  Replaces the
+ * bias add / GELU / residual add chain behind the convolutions of MedNeXtBlock, MedNeXtDownBlock, PatchExpand and project
+ * (nnUNetTrainer_MLAgg_2D_dt_MS.py:307-324, 358-366, 498-546, 984-1001).  bias, res may be NULL.
+ * Backward of the GELU form: dpre = dy * gelu'(pre), dbias[c] = sum of dpre over batch and pixels (NULL to skip;
+ * workspace: mlagg_channel_sum_workspace_floats(B, C) floats).
+ * ------------------------------------------------------------------------------------------ */
+int mlagg_channel_epilogue_fwd(float *x, const float *bias, const float *res, float *y, int B, int C, long HW, int act,
+                               void *stream);
+int mlagg_channel_gelu_bwd(const float *pre, const float *dy, float *dpre, float *dbias, float *workspace, int B, int C,
+                           long HW, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * K9: Dice + cross-entropy statistics and gradient of one deep-supervision level.  Replaces softmax, one-hot scatter,
  * masked products, spatial sums, log_softmax + nll and all their backward kernels of DC_and_CE_loss
  * (loss/compound_losses.py:31-57, loss/dice.py:73-117, loss/robust_ce_loss.py:12-16).

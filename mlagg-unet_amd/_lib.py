@@ -77,6 +77,8 @@ SIGNATURES = {
     "mlagg_flash_attn_fwd": (_I, [_F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _FL, _I, _S]),
     "mlagg_flash_attn_bwd_workspace_floats": (_SZ, [_I, _I, _I, _I, _I]),
     "mlagg_flash_attn_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _FL, _I, _S]),
+    "mlagg_channel_epilogue_fwd": (_I, [_F, _F, _F, _F, _I, _I, ctypes.c_long, _I, _S]),
+    "mlagg_channel_gelu_bwd": (_I, [_F, _F, _F, _F, _F, _I, _I, ctypes.c_long, _S]),
 }
 
 _lib = None

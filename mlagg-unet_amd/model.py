@@ -112,6 +112,18 @@ class Conv2d(nn.Conv2d):
             y = y.float()
         return y if self.bias is None else ops.channel_bias(y, self.bias)
 
+    def fused(self, x, res=None, act=ops.EPI_NONE):
+        """act(conv(x) + bias + res): the convolution in MIOpen, everything behind it in one K13 pass."""
+        if not x.is_cuda or self.padding_mode != "zeros":
+            y = super().forward(x)
+            y = y if res is None else y + res
+            return F.gelu(y) if act == ops.EPI_GELU else y
+        cdt = ops.conv_dtype()
+        y = F.conv2d(ops.lp(x, cdt), ops.lp(self.weight, cdt), None, self.stride, self.padding, self.dilation, self.groups)
+        if cdt != torch.float32:
+            y = y.float()
+        return ops.channel_epilogue(y, self.bias, res, act)
+
 
 class ConvTranspose2d(nn.ConvTranspose2d):
     def forward(self, x, output_size=None):
@@ -125,6 +137,18 @@ class ConvTranspose2d(nn.ConvTranspose2d):
         if cdt != torch.float32:
             y = y.float()
         return y if self.bias is None else ops.channel_bias(y, self.bias)
+
+    def fused(self, x, res=None):
+        """conv_transpose(x) + bias + res in one K13 pass behind the MIOpen call."""
+        if not x.is_cuda:
+            y = super().forward(x)
+            return y if res is None else y + res
+        cdt = ops.conv_dtype()
+        y = F.conv_transpose2d(ops.lp(x, cdt), ops.lp(self.weight, cdt), None, self.stride, self.padding,
+                               self.output_padding, self.groups, self.dilation)
+        if cdt != torch.float32:
+            y = y.float()
+        return ops.channel_epilogue(y, self.bias, res)
 
 
 class GroupNorm(nn.GroupNorm):
@@ -351,8 +375,8 @@ class Project(nn.Module):  # reference T:972-1001
         return _TokensToMap.apply(norm(_MapToTokens.apply(x)), x.shape[2], x.shape[3])
 
     def forward(self, x):
-        x = self.conv2(self._ln(self.norm1, F.gelu(self.conv1(x))))
-        return x if self.last else self._ln(self.norm2, F.gelu(x))
+        x = self._ln(self.norm1, self.conv1.fused(x, act=ops.EPI_GELU))
+        return self.conv2(x) if self.last else self._ln(self.norm2, self.conv2.fused(x, act=ops.EPI_GELU))
 
 
 class PatchEmbed(nn.Module):  # reference T:1004-1043
@@ -374,14 +398,14 @@ class MedNeXtBlock(nn.Module):  # reference T:230-324
         self.conv2 = Conv2d(cin, exp_r * cin, 1)
         self.conv3 = Conv2d(exp_r * cin, cout, 1)
 
-    def body(self, x):
-        # conv1 is depthwise 3x3 (stride 1, or 2 in the down block): K2n instead of MIOpen's naive fallback
+    def body(self, x, res=None):
+        # conv1 is depthwise 3x3 (stride 1, or 2 in the down block): K2n instead of MIOpen's naive fallback; the bias,
+        # GELU and residual behind the two 1x1 convolutions are one K13 pass each
         x1 = ops.dwconv3x3_nchw(x, self.conv1.weight, self.conv1.bias, self.conv1.stride[0])
-        return self.conv3(F.gelu(self.conv2(self.norm(x1))))
+        return self.conv3.fused(self.conv2.fused(self.norm(x1), act=ops.EPI_GELU), res=res)
 
     def forward(self, x):
-        y = self.body(x)
-        return x + y if self.do_res else y
+        return self.body(x, x if self.do_res else None)
 
 
 class MedNeXtDownBlock(MedNeXtBlock):  # reference T:327-366
@@ -390,7 +414,7 @@ class MedNeXtDownBlock(MedNeXtBlock):  # reference T:327-366
         self.res_conv = Conv2d(cin, cout, 1, stride=2)
 
     def forward(self, x):
-        return self.body(x) + self.res_conv(x)
+        return self.body(x, self.res_conv(x))
 
 
 class PatchExpand(nn.Module):  # reference T:479-546
@@ -401,7 +425,8 @@ class PatchExpand(nn.Module):  # reference T:479-546
         self.norm = GroupNorm(cin, cin)
 
     def forward(self, x):
-        return F.pad(self.conv1(self.norm(x)) , (1, 0, 1, 0)) + F.pad(self.res_conv(x), (1, 0, 1, 0))
+        # pad(a) + pad(b) = pad(a + b): one padded copy, and the sum rides in conv1's epilogue
+        return F.pad(self.conv1.fused(self.norm(x), res=self.res_conv(x)), (1, 0, 1, 0))
 
 
 class OutBlock(nn.Module):  # reference T:549-561

@@ -851,6 +851,59 @@ def channel_bias(x, bias):
     return ChannelBiasFn.apply(x, bias)
 
 
+EPI_NONE, EPI_GELU = 0, 1
+
+
+class ChannelEpilogueFn(torch.autograd.Function):
+    """K13: y = act(x + bias[c] + res) on the NCHW output `x` of a library convolution, one pass.  `x` is consumed: without an
+    activation it is updated in place and returned; with GELU it is overwritten with the pre-activation (kept for backward)
+    and the result is a new map."""
+
+    @staticmethod
+    def forward(ctx, x, bias, res, act):
+        x = _require(x, "x")
+        if not x.is_contiguous():
+            raise RuntimeError("channel_epilogue: contiguous NCHW map expected")
+        res = None if res is None else _require(res.contiguous(), "res", x.shape)
+        B, C = x.shape[:2]
+        hw = x.numel() // (B * C)
+        y = torch.empty_like(x) if act == EPI_GELU else None
+        _lib.check(_lib.lib().mlagg_channel_epilogue_fwd(_ptr(x), _ptr(bias), _ptr(res), _ptr(y), B, C, hw, int(act), _stream()),
+                   "mlagg_channel_epilogue_fwd")
+        ctx.meta = (int(act), bias is not None, res is not None)
+        if act == EPI_GELU:
+            # x now holds the pre-activation.  It is the fresh output of the convolution call in front of this function
+            # (nothing else reads it, convolution backward does not need its own output), so it is simply kept.
+            ctx.save_for_backward(x)
+            return y
+        ctx.mark_dirty(x)
+        return x
+
+    @staticmethod
+    def backward(ctx, dy):
+        act, has_bias, has_res = ctx.meta
+        dy = _require(dy.contiguous(), "dy")
+        B, C = dy.shape[:2]
+        hw = dy.numel() // (B * C)
+        lib = _lib.lib()
+        db = torch.empty(C, device=dy.device, dtype=torch.float32) if has_bias else None
+        ws = torch.empty(lib.mlagg_channel_sum_workspace_floats(B, C), device=dy.device, dtype=torch.float32) if has_bias else None
+        if act == EPI_GELU:
+            (pre,) = ctx.saved_tensors
+            dx = torch.empty_like(dy)
+            _lib.check(lib.mlagg_channel_gelu_bwd(_ptr(pre), _ptr(dy), _ptr(dx), _ptr(db), _ptr(ws), B, C, hw, _stream()),
+                       "mlagg_channel_gelu_bwd")
+        else:
+            dx = dy
+            if has_bias:
+                _lib.check(lib.mlagg_channel_sum(_ptr(dy), _ptr(db), _ptr(ws), B, C, hw, _stream()), "mlagg_channel_sum")
+        return dx, db, (dx if has_res else None), None
+
+
+def channel_epilogue(x, bias=None, res=None, act=EPI_NONE):
+    return ChannelEpilogueFn.apply(x, bias, res, act)
+
+
 def column_sum(x2):
     """Sum over the rows of a (rows, cols) matrix with unit inner stride."""
     _require(x2, "x")

@@ -464,3 +464,33 @@ def test_clip_adamw_matches_torch(max_norm):
     v_ref = sb["state"][3]["exp_avg_sq"]
     assert float((sa["state"][3]["exp_avg_sq"] - v_ref).abs().max()) < 1e-4 * float(v_ref.abs().max())   # (g * coef)^2 rounding
     assert float(unused) == 1.0 and 6 not in sa["state"]
+
+
+@gpu
+@pytest.mark.parametrize("act", [0, 1])
+@pytest.mark.parametrize("B,C,H,W,with_res,with_bias", [(2, 96, 32, 32, True, True), (3, 7, 5, 9, False, True), (1, 192, 16, 16, True, False)])
+def test_channel_epilogue_matches_torch(act, B, C, H, W, with_res, with_bias):
+    """K13: act(conv_out + bias + res) and its backward (d(pre), d(res), d(bias)) against torch in double precision."""
+    from mlagg_unet_amd import ops
+    g = torch.Generator().manual_seed(B * C + act)
+    x = torch.randn(B, C, H, W, generator=g)
+    b = torch.randn(C, generator=g) if with_bias else None
+    r = torch.randn(B, C, H, W, generator=g) if with_res else None
+    gy = torch.randn(B, C, H, W, generator=g)
+    xr = x.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if with_bias else None
+    rr = r.double().requires_grad_(True) if with_res else None
+    pre = xr + (br.view(1, -1, 1, 1) if with_bias else 0) + (rr if with_res else 0)
+    yr = torch.nn.functional.gelu(pre) if act else pre
+    yr.backward(gy.double())
+    xg = x.to(DEV).requires_grad_(True)
+    bg = b.to(DEV).requires_grad_(True) if with_bias else None
+    rg = r.to(DEV).requires_grad_(True) if with_res else None
+    y = ops.channel_epilogue(xg * 1.0, bg, rg, act)          # * 1.0: a fresh map, as a convolution output is
+    y.backward(gy.to(DEV))
+    _close(y, yr.float(), 1e-5, 1e-5, "epilogue y")
+    _close(xg.grad, xr.grad.float(), 1e-5, 1e-5, "epilogue dx")
+    if with_res:
+        _close(rg.grad, rr.grad.float(), 1e-5, 1e-5, "epilogue dres")
+    if with_bias:
+        _close(bg.grad, br.grad.float(), 2e-4, 1e-4, "epilogue dbias")
