@@ -270,6 +270,20 @@ int mlagg_channel_sum(const float *g, float *out, float *workspace, int B, int C
 int mlagg_column_sum(const float *x, int x_stride, float *out, int rows, int cols, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K1' for volumes: cross-scan / cross-merge by permutation table, the re-ordering of the 3-D selective scan
+ * (`SS3D.forward_corev0`, mlagg/nnunetv2/training/nnUNetTrainer/variants/mamba/UMambaEnc_SS3D.py:244-296: K = 12 directions
+ * = six axis orders of (D, H, W) and their reversals; the stack / permute / flip / cat chains at :251-259 and :284-295).
+ *   idx  (K, L) int32: natural (d, h, w) position of scan step l of direction k
+ *   scan   seq[b][k * CB + c][l] = tok[b][idx[k][l]][k * blk_stride + c]       tok (B, L, *) rows of tok_stride floats
+ *   merge  the transpose; blk_stride = 0 sums the K directions into the same CB columns (tok_stride must equal CB; float
+ *          atomics: the sum order is not fixed)
+ * ------------------------------------------------------------------------------------------ */
+int mlagg_index_scan(const float *tok, long tok_stride, int blk_stride, const int *idx, float *seq, int B, int L, int K, int CB,
+                     void *stream);
+int mlagg_index_merge(const float *seq, const int *idx, float *tok, long tok_stride, int blk_stride, int B, int L, int K, int CB,
+                      void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * K13: epilogue of the library convolutions on NCHW maps (B, C, HW): y = act(x + bias[c] + res), act 0 = none (in place on
  * x, y ignored), 1 = GELU (erf form; x is overwritten with the pre-activation, y receives the result).  Replaces the
  * bias add / GELU / residual add chain behind the convolutions of MedNeXtBlock, MedNeXtDownBlock, PatchExpand and project

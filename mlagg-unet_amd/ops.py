@@ -641,6 +641,79 @@ class CrossScanBCFn(torch.autograd.Function):
         return dx, None, None, None
 
 
+class IndexScanFn(torch.autograd.Function):
+    """K1' for volumes: token-major (B, L, width) -> scan rows (B, K*CB, L) by permutation table idx (K, L) int32; direction k
+    reads columns [k*blk, k*blk + CB) of the source (blk = 0: every direction reads the same CB columns)."""
+
+    @staticmethod
+    def forward(ctx, tok, idx, CB, blk, col0):
+        tok = _require(tok.contiguous(), "tok")
+        B, L, width = tok.shape
+        K = idx.shape[0]
+        if idx.dtype != torch.int32 or tuple(idx.shape) != (K, L) or not idx.is_cuda or col0 + (K - 1) * blk + CB > width:
+            raise RuntimeError("index_scan: idx must be an int32 (K, L) device table and the column blocks must fit the rows")
+        seq = torch.empty(B, K * CB, L, device=tok.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mlagg_index_scan(tok.data_ptr() + 4 * col0, width, blk, _ptr(idx), _ptr(seq), B, L, K, CB, _stream()),
+                   "mlagg_index_scan")
+        ctx.save_for_backward(idx)
+        ctx.meta = (CB, blk, col0, width)
+        return seq
+
+    @staticmethod
+    def backward(ctx, dseq):
+        (idx,) = ctx.saved_tensors
+        CB, blk, col0, width = ctx.meta
+        dseq = _require(dseq.contiguous(), "dseq")
+        B, _, L = dseq.shape
+        K = idx.shape[0]
+        if blk == 0 and width == CB:
+            dtok = torch.empty(B, L, width, device=dseq.device, dtype=torch.float32)      # the summed form zero-fills itself
+            _lib.check(_lib.lib().mlagg_index_merge(_ptr(dseq), _ptr(idx), _ptr(dtok), width, 0, B, L, K, CB, _stream()),
+                       "mlagg_index_merge")
+            return dtok, None, None, None, None
+        if blk == 0:
+            raise RuntimeError("index_scan: a shared source must be exactly CB columns wide")
+        dtok = torch.zeros(B, L, width, device=dseq.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mlagg_index_merge(_ptr(dseq), _ptr(idx), dtok.data_ptr() + 4 * col0, width, blk, B, L, K, CB, _stream()),
+                   "mlagg_index_merge")
+        return dtok, None, None, None, None
+
+
+class IndexMergeFn(torch.autograd.Function):
+    """(B, K*CB, L) scan-order outputs -> (B, L, CB) token-major SUM of the K directions (SS3D.forward's torch.sum(y, dim=1))."""
+
+    @staticmethod
+    def forward(ctx, seq, idx, CB):
+        seq = _require(seq.contiguous(), "seq")
+        B, rows, L = seq.shape
+        K = idx.shape[0]
+        if rows != K * CB or tuple(idx.shape) != (K, L) or idx.dtype != torch.int32:
+            raise RuntimeError(f"index_merge: bad shapes seq {tuple(seq.shape)} idx {tuple(idx.shape)}")
+        tok = torch.empty(B, L, CB, device=seq.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mlagg_index_merge(_ptr(seq), _ptr(idx), _ptr(tok), CB, 0, B, L, K, CB, _stream()), "mlagg_index_merge")
+        ctx.save_for_backward(idx)
+        ctx.CB = CB
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        (idx,) = ctx.saved_tensors
+        dtok = _require(dtok.contiguous(), "dtok")
+        B, L, CB = dtok.shape
+        K = idx.shape[0]
+        dseq = torch.empty(B, K * CB, L, device=dtok.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mlagg_index_scan(_ptr(dtok), CB, 0, _ptr(idx), _ptr(dseq), B, L, K, CB, _stream()), "mlagg_index_scan")
+        return dseq, None, None
+
+
+def index_scan(tok, idx, CB, blk=0, col0=0):
+    return IndexScanFn.apply(tok, idx, CB, blk, col0)
+
+
+def index_merge(seq, idx, CB):
+    return IndexMergeFn.apply(seq, idx, CB)
+
+
 def cross_scan(tok, HW, CB, nblk):
     return CrossScanFn.apply(tok, HW, CB, nblk)
 

@@ -279,6 +279,34 @@ def golden_msmm(M):
     print("msmm", [float(y.abs().mean()) for y in ys])
 
 
+def golden_ss3d():
+    """The reference's 3-D selective-scan block SS3D (variants/mamba/UMambaEnc_SS3D.py:126-357) on a small volume: block output,
+    input gradient and every parameter gradient.  Extra stand-ins: the dynamic_network_architectures / MONAI / nnunetv2 names
+    that file imports at module level and never uses inside SS3D."""
+    class _Any:
+        def __init__(self, *a, **k):
+            pass
+    _mod("dynamic_network_architectures.building_blocks")
+    _mod("dynamic_network_architectures.building_blocks.helper", get_matching_convtransp=None, convert_conv_op_to_dim=None,
+         get_matching_instancenorm=None, convert_dim_to_conv_op=None, maybe_convert_scalar_to_list=None, get_matching_pool_op=None)
+    _mod("dynamic_network_architectures.building_blocks.residual", BasicBlockD=_Any)
+    sys.modules["monai.networks.blocks"].MLPBlock = _Any
+    _mod("nnunetv2.utilities.network_initialization", InitWeights_He=None)
+    S = importlib.import_module("nnunetv2.training.nnUNetTrainer.variants.mamba.UMambaEnc_SS3D")
+    blk = S.SS3D(d_model=16).eval()                            # d_inner 32, dt_rank 1, d_state 16, K = 12
+    O.deterministic_fill_(blk.state_dict(), seed=12)
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(2, 4, 6, 5, 16, generator=g).requires_grad_(True)      # (B, D, H, W, C): all three extents differ
+    y = blk(x)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    names, norms = grad_summary(blk)
+    np.savez_compressed(os.path.join(HERE, "ss3d.npz"), x=x.detach().numpy(), y=y.detach().numpy(), gy=gy.numpy(),
+                        gx=x.grad.numpy(), grad_names=np.asarray(names), grad_norms=norms,
+                        **{"grad/" + n: p.grad.numpy() for n, p in blk.named_parameters()})
+    print("ss3d", float(y.abs().mean()), [str(n) for n in names])
+
+
 def golden_loss():
     from nnunetv2.training.loss.compound_losses import DC_and_CE_loss
     from nnunetv2.training.loss.deep_supervision import DeepSupervisionWrapper
@@ -413,6 +441,9 @@ if __name__ == "__main__":
         for tag in sys.argv[sys.argv.index("--config") + 1:]:
             golden_full_model_config(T, tag)
         sys.exit(0)
+    if "--only-ss3d" in sys.argv:
+        golden_ss3d()
+        sys.exit(0)
     if "--only-256" in sys.argv:
         golden_full_model_256(T)
         sys.exit(0)
@@ -432,3 +463,4 @@ if __name__ == "__main__":
     golden_full_model_256(T)
     for tag in CONFIG_GOLDENS:
         golden_full_model_config(T, tag)
+    golden_ss3d()
