@@ -63,7 +63,8 @@ class DataLoader2D:
     reference uses); a RandomState for worker threads."""
 
     def __init__(self, dataset, batch_size, patch_size, final_patch_size, all_labels, oversample_foreground_percent=0.0,
-                 rng=None, pin_memory=None):
+                 rng=None, pin_memory=None, has_ignore=False):
+        self.has_ignore = bool(has_ignore)             # label_manager.has_ignore_label (base_data_loader.py:42)
         self.ds, self.batch_size = dataset, int(batch_size)
         self.indices = dataset.keys()
         self.patch_size = tuple(int(v) for v in patch_size)
@@ -78,14 +79,15 @@ class DataLoader2D:
     def get_do_oversample(self, j):                    # base_data_loader.py:45-49
         return not j < round(self.batch_size * (1 - self.oversample))
 
-    def _bbox(self, shape, force_fg, locs):            # base_data_loader.py:63-139 (no ignore label)
+    def _bbox(self, shape, force_fg, locs):            # base_data_loader.py:63-139; `locs`: voxels of the chosen class / region
+        # on the chosen slice (with an ignore label and no forced foreground: of ALL annotated labels, :91-97)
         need = self.need_to_pad.copy()
         for d in range(2):
             if need[d] + shape[d] < self.patch_size[d]:
                 need[d] = self.patch_size[d] - shape[d]
         lbs = [-need[i] // 2 for i in range(2)]
         ubs = [shape[i] + need[i] // 2 + need[i] % 2 - self.patch_size[i] for i in range(2)]
-        if force_fg and locs is not None and len(locs) > 0:
+        if (force_fg or self.has_ignore) and locs is not None and len(locs) > 0:
             v = locs[self.rng.choice(len(locs))]
             return [max(lbs[i], int(v[i + 1]) - self.patch_size[i] // 2) for i in range(2)]
         return [self.rng.randint(lbs[i], ubs[i] + 1) for i in range(2)]
@@ -108,9 +110,15 @@ class DataLoader2D:
             if force_fg:
                 cl = self.ds.properties(key)["class_locations"]
                 eligible = [i for i in cl.keys() if len(cl[i]) > 0]
+                # data_loader_2d.py:29-35: the all-annotated-labels key competes only when nothing else is present
+                if len(eligible) > 1 and self.annotated_classes_key in [i for i in eligible if isinstance(i, tuple)]:
+                    eligible.remove(self.annotated_classes_key)
                 if eligible:
                     sel = eligible[self.rng.choice(len(eligible))]
                     locs_all = cl[sel]
+            elif self.has_ignore:                          # data_loader_2d.py:21-23
+                sel = self.annotated_classes_key
+                locs_all = self.ds.properties(key)["class_locations"][sel]
             sl = self.rng.choice(locs_all[:, 1]) if sel is not None else self.rng.choice(len(data[0]))
             if sel is not None:
                 # data_loader_2d.py:55-57: the locations of that class on that slice; get_bbox is told the class
@@ -168,7 +176,8 @@ class PrefetchLoader:
         for i in range(num_workers):
             clone = DataLoader2D(loader.ds, loader.batch_size, loader.patch_size,
                                  tuple(np.array(loader.patch_size) - loader.need_to_pad), loader.annotated_classes_key,
-                                 loader.oversample, rng=np.random.RandomState(seed + i), pin_memory=loader.pin)
+                                 loader.oversample, rng=np.random.RandomState(seed + i), pin_memory=loader.pin,
+                                 has_ignore=loader.has_ignore)
             t = threading.Thread(target=self._work, args=(clone,), daemon=True)
             t.start()
             self.workers.append(t)

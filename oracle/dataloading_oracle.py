@@ -27,7 +27,30 @@ def sample_foreground_locations(seg, classes, seed=1234):
     return out
 
 
-def write_synthetic_dataset(folder, n_cases=4, seed=3, labels=(1, 2, 3), unpack=False, small=True):
+def sample_locations_of(seg, classes_or_regions, seed=1234):
+    """DefaultPreprocessor._sample_foreground_locations (preprocessing/preprocessors/default_preprocessor.py:206-233): a key
+    may be one label or a tuple of labels (a region, or -- with an ignore label -- all annotated labels)."""
+    num_samples, min_cov = 10000, 0.01
+    rnd = np.random.RandomState(seed)
+    out = {}
+    for c in classes_or_regions:
+        k = c if not isinstance(c, list) else tuple(c)
+        if isinstance(c, (tuple, list)):
+            mask = np.zeros_like(seg, dtype=bool)
+            for ci in c:
+                mask |= seg == ci
+            locs = np.argwhere(mask)
+        else:
+            locs = np.argwhere(seg == c)
+        if len(locs) == 0:
+            out[k] = []
+            continue
+        n = max(min(num_samples, len(locs)), int(np.ceil(len(locs) * min_cov)))
+        out[k] = locs[rnd.choice(len(locs), n, replace=False)]
+    return out
+
+
+def write_synthetic_dataset(folder, n_cases=4, seed=3, labels=(1, 2, 3), unpack=False, small=True, ignore_label=None):
     """A tiny `nnUNet_preprocessed/<dataset>/2d`-style folder: <case>.npz {data (C, D, H, W) f32, seg (1, D, H, W) i16 with
     -1 outside the 'nonzero' region} + <case>.pkl {class_locations}.  Case 1 has no foreground; case 2 is smaller than
     the patch in one axis (when `small`)."""
@@ -46,9 +69,16 @@ def write_synthetic_dataset(folder, n_cases=4, seed=3, labels=(1, 2, 3), unpack=
                 seg[0, d:d + 2, y:y + 6, x:x + 6] = lab
         seg[0, :, :2, :] = -1
         name = f"case_{i:03d}"
+        if ignore_label is not None:
+            # partially annotated case: a band of every slice carries the ignore label; class_locations also gets the
+            # tuple of all annotated labels (default_preprocessor.py:118-125)
+            seg[0, :, H // 2:H // 2 + 6, :] = ignore_label
+            locs = sample_locations_of(seg, list(labels) + [[0] + list(labels)])
+        else:
+            locs = sample_foreground_locations(seg, list(labels))
         np.savez_compressed(os.path.join(folder, name + ".npz"), data=data, seg=seg)
         with open(os.path.join(folder, name + ".pkl"), "wb") as fh:
-            pickle.dump({"class_locations": sample_foreground_locations(seg, list(labels))}, fh)
+            pickle.dump({"class_locations": locs}, fh)
         if unpack:
             np.save(os.path.join(folder, name + ".npy"), data)
             np.save(os.path.join(folder, name + "_seg.npy"), seg)
@@ -74,7 +104,9 @@ class Dataset:
 
 
 class DataLoader2D:
-    def __init__(self, dataset, batch_size, patch_size, final_patch_size, all_labels, oversample_foreground_percent=0.0):
+    def __init__(self, dataset, batch_size, patch_size, final_patch_size, all_labels, oversample_foreground_percent=0.0,
+                 has_ignore=False):
+        self.has_ignore = has_ignore
         self.ds, self.batch_size = dataset, batch_size
         self.indices = list(dataset.keys())
         self.patch_size, self.final_patch_size = patch_size, final_patch_size
@@ -96,15 +128,23 @@ class DataLoader2D:
                 need[d] = self.patch_size[d] - shape[d]
         lbs = [-need[i] // 2 for i in range(dim)]
         ubs = [shape[i] + need[i] // 2 + need[i] % 2 - self.patch_size[i] for i in range(dim)]
-        if not force_fg:
+        if not force_fg and not self.has_ignore:
             lb = [np.random.randint(lbs[i], ubs[i] + 1) for i in range(dim)]
         else:
-            eligible = [i for i in class_locations.keys() if len(class_locations[i]) > 0]
-            if len(eligible) == 0:
-                sel = None
+            if not force_fg:                                   # ignore label: a patch around an ANNOTATED voxel (:91-97)
+                sel = self.annotated_classes_key
+                if len(class_locations[sel]) == 0:
+                    sel = None
             else:
-                sel = eligible[np.random.choice(len(eligible))] if (overwrite_class is None or overwrite_class not in eligible) \
-                    else overwrite_class
+                eligible = [i for i in class_locations.keys() if len(class_locations[i]) > 0]
+                tmp = [i == self.annotated_classes_key if isinstance(i, tuple) else False for i in eligible]
+                if any(tmp) and len(eligible) > 1:
+                    eligible.pop(np.where(tmp)[0][0])
+                if len(eligible) == 0:
+                    sel = None
+                else:
+                    sel = eligible[np.random.choice(len(eligible))] if (overwrite_class is None or overwrite_class not in eligible) \
+                        else overwrite_class
             vox = class_locations[sel] if sel is not None else None
             if vox is not None and len(vox) > 0:
                 v = vox[np.random.choice(len(vox))]
@@ -121,9 +161,12 @@ class DataLoader2D:
             force_fg = self.get_do_oversample(j)
             data, seg, props = self.ds.load_case(key)
             if not force_fg:
-                sel = None
+                sel = self.annotated_classes_key if self.has_ignore else None
             else:
                 eligible = [i for i in props["class_locations"].keys() if len(props["class_locations"][i]) > 0]
+                tmp = [i == self.annotated_classes_key if isinstance(i, tuple) else False for i in eligible]
+                if any(tmp) and len(eligible) > 1:
+                    eligible.pop(np.where(tmp)[0][0])
                 sel = eligible[np.random.choice(len(eligible))] if len(eligible) > 0 else None
             if sel is not None:
                 sl = np.random.choice(props["class_locations"][sel][:, 1])

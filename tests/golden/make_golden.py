@@ -417,12 +417,16 @@ def golden_dataloader():
         all_labels = [0, 1, 2, 3]
         has_ignore_label = False
 
+    class LMIgnore(LM):
+        has_ignore_label = True                      # label 4 = ignore: partially annotated cases (base_data_loader.py:91-97)
+
     out = {}
-    for tag, unpack, patch, final, bs, fg in (("npz", False, (40, 48), (32, 32), 4, 0.33), ("npy", True, (32, 32), (32, 32), 5, 0.5)):
+    for tag, unpack, patch, final, bs, fg in (("npz", False, (40, 48), (32, 32), 4, 0.33), ("npy", True, (32, 32), (32, 32), 5, 0.5),
+                                              ("ign", True, (36, 36), (32, 32), 6, 0.33)):
         folder = tempfile.mkdtemp()
-        DO.write_synthetic_dataset(folder, unpack=unpack)
-        dl = D2.nnUNetDataLoader2D(DS.nnUNetDataset(folder), bs, patch, final, LM(), oversample_foreground_percent=fg,
-                                   sampling_probabilities=None, pad_sides=None)
+        DO.write_synthetic_dataset(folder, unpack=unpack, ignore_label=4 if tag == "ign" else None)
+        dl = D2.nnUNetDataLoader2D(DS.nnUNetDataset(folder), bs, patch, final, LMIgnore() if tag == "ign" else LM(),
+                                   oversample_foreground_percent=fg, sampling_probabilities=None, pad_sides=None)
         np.random.seed(7)
         for it in range(3):
             b = dl.generate_train_batch()

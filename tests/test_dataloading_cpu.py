@@ -11,18 +11,20 @@ from mlagg_unet_amd import dataloading as DL
 from oracle import dataloading_oracle as DO
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "dataloader.npz"))
-CASES = {"npz": (False, (40, 48), (32, 32), 4, 0.33), "npy": (True, (32, 32), (32, 32), 5, 0.5)}
+CASES = {"npz": (False, (40, 48), (32, 32), 4, 0.33), "npy": (True, (32, 32), (32, 32), 5, 0.5),
+         "ign": (True, (36, 36), (32, 32), 6, 0.33)}          # "ign": dataset with an ignore label (partially annotated cases)
 
 
-@pytest.mark.parametrize("tag", ["npz", "npy"])
+@pytest.mark.parametrize("tag", ["npz", "npy", "ign"])
 def test_oracle_and_product_reproduce_reference_batches(tag, tmp_path):
     unpack, patch, final, bs, fg = CASES[tag]
-    DO.write_synthetic_dataset(str(tmp_path), unpack=unpack)
+    ign = tag == "ign"
+    DO.write_synthetic_dataset(str(tmp_path), unpack=unpack, ignore_label=4 if ign else None)
     labels = [0, 1, 2, 3]
-    ora = DO.DataLoader2D(DO.Dataset(str(tmp_path)), bs, patch, final, labels, fg)
+    ora = DO.DataLoader2D(DO.Dataset(str(tmp_path)), bs, patch, final, labels, fg, has_ignore=ign)
     np.random.seed(7)
     ob = [ora.generate_train_batch() for _ in range(3)]
-    prod = DL.DataLoader2D(DL.Dataset(str(tmp_path)), bs, patch, final, labels, fg, pin_memory=False)
+    prod = DL.DataLoader2D(DL.Dataset(str(tmp_path)), bs, patch, final, labels, fg, pin_memory=False, has_ignore=ign)
     np.random.seed(7)
     pb = [prod.generate_train_batch() for _ in range(3)]
     for it in range(3):
@@ -33,6 +35,8 @@ def test_oracle_and_product_reproduce_reference_batches(tag, tmp_path):
         assert np.array_equal(pb[it]["data"].numpy(), GOLD[f"{tag}_data_{it}"])
         assert np.array_equal(pb[it]["seg"].numpy(), GOLD[f"{tag}_seg_{it}"])
     assert (GOLD[f"{tag}_seg_0"] == -1).any()                    # padding / outside-body label is present in the fixture
+    if ign:
+        assert any((GOLD[f"ign_seg_{it}"] == 4).any() for it in range(3))      # the ignore label reaches the batches
 
 
 def test_oversampled_samples_contain_foreground(tmp_path):
