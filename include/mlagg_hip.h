@@ -54,7 +54,7 @@ int mlagg_profile_collect(double *ms, int *counts);
  *   chunk_state        workspace AND saved-for-backward tensor, mlagg_selscan_state_floats() floats:
  *                      [batch][nchunks][dim][N] states entering each 64-step chunk, followed by
  *                      [batch][nchunks][dim] per-chunk sums of softplus'd delta and
- *                      [batch][nchunks][3][dim][N] states entering the 2nd..4th 16-step sub-tile of each chunk.
+ *                      [batch][nchunks][7][dim][N] states entering the 2nd..8th 8-step tile of each chunk.
  * ------------------------------------------------------------------------------------------ */
 size_t mlagg_selscan_state_floats(int batch, int dim, int L, int N);
 int mlagg_selscan_fwd(const float *u, const float *delta, const float *A, const float *B, const float *C,

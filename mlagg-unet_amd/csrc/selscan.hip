@@ -35,6 +35,7 @@ constexpr int NS = 16;    // d_state (fixed: reference uses 16, MambaSkip.py:271
 constexpr int ST = 16;    // steps per LDS sub-tile
 constexpr int TC = 64;    // steps per chunk
 constexpr int NSUB = TC / ST;
+constexpr int NT8 = TC / 8 - 1;   // saved entry states per chunk besides the chunk's own: one per 8-step tile (round 2; was per 16)
 constexpr int UP = ST + 4;   // row pitch of the u / delta / dy tiles (floats): conflict-free b128 reads
 constexpr int BP = 20;       // pitch of the [t][n] B / C tiles
 constexpr int PP = 24;       // pitch of a per-chunk partial row: dA[16], dD, ddelta_bias, dWdt[4], pad
@@ -72,14 +73,6 @@ __device__ __forceinline__ float dpp_quad_xor1(float v)
 __device__ __forceinline__ float dpp_quad_xor2(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float dpp_quad_0011(float v)      // quad lane s reads quad lane s >> 1
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x50, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float dpp_quad_2233(float v)      // quad lane s reads quad lane 2 + (s >> 1)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xFA, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float quad_sum(float v)
 {
@@ -254,8 +247,8 @@ __global__ void __launch_bounds__(128) selscan_fwd_kernel(const float *__restric
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
         const int t0 = tc0 + sub * ST;
-        if (FINAL && sub > 0 && id.act)       // state entering sub-tiles 1..3: saved so that backward does not re-sweep the chunk
-            *reinterpret_cast<float4 *>(csub + ((srow / gm.dim * (NSUB - 1) + (sub - 1)) * gm.dim + id.d) * NS + 4 * id.s) =
+        if (FINAL && sub > 0 && id.act)       // state entering 8-step tile 2 * sub: saved so that backward does not re-sweep the chunk
+            *reinterpret_cast<float4 *>(csub + ((srow / gm.dim * NT8 + (2 * sub - 1)) * gm.dim + id.d) * NS + 4 * id.s) =
                 make_float4(h[0], h[1], h[2], h[3]);
         __syncthreads();
         if (id.act) {
@@ -274,6 +267,9 @@ __global__ void __launch_bounds__(128) selscan_fwd_kernel(const float *__restric
             float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                if (FINAL && q == 2)            // ... and the state entering the odd 8-step tile 2 * sub + 1
+                    *reinterpret_cast<float4 *>(csub + ((srow / gm.dim * NT8 + 2 * sub) * gm.dim + id.d) * NS + 4 * id.s) =
+                        make_float4(h[0], h[1], h[2], h[3]);
                 const float4 dv = *reinterpret_cast<const float4 *>(sd + id.cl * UP + 4 * q);
                 const float4 uv = *reinterpret_cast<const float4 *>(su + id.cl * UP + 4 * q);
                 float yq[4];
@@ -573,7 +569,7 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
         float hent[4] = {0.f, 0.f, 0.f, 0.f};      // the 4 states entering this sub-tile (saved by the forward pass)
         if (id.act) {
             const float *src = sub == 0 ? cstate + srow * NS
-                                        : csub + ((srow / gm.dim * (NSUB - 1) + (sub - 1)) * gm.dim + id.d) * NS;
+                                        : csub + ((srow / gm.dim * NT8 + (2 * sub - 1)) * gm.dim + id.d) * NS;
             const float4 h0 = *reinterpret_cast<const float4 *>(src + 4 * id.s);
             hent[0] = h0.x; hent[1] = h0.y; hent[2] = h0.z; hent[3] = h0.w;
         }
@@ -787,8 +783,9 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
 // lane (the dB / dC products are the accumulating operand of an FMA: free) and cross lanes once per 8-step tile for all
 // J channels -- 0.7 instead of 4 cross-lane instructions per (step, state) pair.  Nothing is shared with another wave:
 // no barrier, no LDS / global atomics, no memset of dB / dC, one staging of the B / C tile per chunk and group.
-//   * time tile: 8 steps (accumulators: 4 states x 8 steps x {dB, dC} = 64 VGPRs).  The forward pass saves entry
-//     states every 16 steps; the odd 8-step tile re-runs the 8 steps in front of it from the saved state.
+//   * time tile: 8 steps (accumulators: 4 states x 8 steps x {dB, dC} = 64 VGPRs); the forward pass saves the state
+//     entering every 8-step tile (a first version kept the 16-step saves and re-ran 8 forward steps for the odd tiles:
+//     8 % more VALU work, u and the saved state fetched twice).
 //   * the channel loop is ROLLED (unrolled, the compiler keeps ~150 VGPRs of every channel body alive: 700 spills at
 //     J = 6); what a channel carries from tile to tile sits in LDS: reverse carry q[4] and dA[4] per lane, dD / d(bias) /
 //     dWdt[R] per channel (quad-reduced).
@@ -798,7 +795,6 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
 // ~22 KB of LDS per wave: 7 waves per CU.
 // ------------------------------------------------------------------------------------------
 constexpr int T8 = 8;            // steps per tile of the group kernel
-constexpr int SP16 = 20;         // pitch of the 16-step staging rows
 constexpr int SP8 = 8;           // pitch of the 8-step dy rows (b128 reads of one 16-lane group still hit 16 distinct banks)
 constexpr int JMAX = 6;          // channel slots per lane: groups of up to 96 channels
 
@@ -904,11 +900,11 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
 {
     __shared__ float sB[NS * BP], sC[NS * BP];          // [n][16 steps] of the current 16-step tile
     __shared__ float sR[RMAX * ST];                     // LR: rank rows [r][16 steps]
-    __shared__ float sD[16 * SP16], sX[16 * SP16];      // per channel lane: delta', delta' u
+    __shared__ float sD[16 * SP8], sX[16 * SP8];        // per channel lane: delta', delta' u of the current 8 steps
     __shared__ float sY[16 * SP8];                      // dy of the current 8 steps
     __shared__ float4 sQ[JMAX * 64], sA[JMAX * 64];     // per (channel slot, lane): reverse carry q[4], dA[4]
     __shared__ float2 sE[JMAX * 16 * 3];                // per channel: {dD, d(bias)}, {dW0, dW1}, {dW2, dW3}
-    // 20480 bytes in all: 8 waves per CU (2 per SIMD, what 256 VGPRs allow) fill the 160 KiB exactly
+    // 18.4 KB in all: 8 waves per CU (2 per SIMD, what ~240 VGPRs allow)
 
     const int chunk = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
     const int L = gm.L, Hc = gm.Hc, dim = gm.dim;
@@ -939,7 +935,7 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
     const size_t grow = ((size_t)b * dim + g * Hc) * L;            // first row of the group in the (B, D, L) tensors
     const float *ubase = u + grow, *gbase = dout + grow, *dbase = LR ? u : delta + grow;
     float *dubase = du + grow, *ddbase = LR ? du : ddelta + grow;
-    struct Stream { float4 uv; float2 gy; float4 hv; float4 dv; };   // dv: raw delta of the plain (not low-rank) form
+    struct Stream { float2 uv; float2 gy; float4 hv; float2 dv; };   // per lane: steps 2s, 2s+1 of the tile; dv: raw delta of the plain form
     // branch-free: a load inside a conditional block makes the compiler's vmcnt bookkeeping fall back to vmcnt(0) at the
     // next use of ANY loaded value, which would drain the prefetch at once.  Out-of-range iterations / padding lanes read
     // a valid address and the value is dropped.
@@ -947,20 +943,17 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
         Stream f;
         const int cl = ln >> 2, s = ln & 3;
         const bool act = live && (FULL || cl + 16 * j < Hc);
-        const int sub = m >> 1, odd = m & 1;
-        const int t16 = tc0 + sub * ST, tm = t16 + odd * T8;
+        const int tm = tc0 + m * T8;
         // uniform 64-bit bases + 32-bit lane offsets: the loads take the SGPR-base form (no 64-bit VALU address arithmetic)
         const unsigned c = act ? cl + 16 * j : 0;
         const unsigned roff = c * (unsigned)L;
-        const float *sbase = sub == 0 ? cstate + (crow * dim + g * Hc) * NS : csub + ((crow * (NSUB - 1) + (sub - 1)) * dim + g * Hc) * NS;
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        // the state entering 8-step tile m: the chunk's entry state (m = 0) or the forward pass's per-tile save
+        const float *sbase = m == 0 ? cstate + (crow * dim + g * Hc) * NS : csub + ((crow * NT8 + (m - 1)) * dim + g * Hc) * NS;
         const float4 hv = *reinterpret_cast<const float4 *>(sbase + (size_t)(c * NS + 4 * s));
         const float2 gy = gload2<VEC>(gbase, roff + tm + 2 * s, roff + L);
-        // both visits of a 16-step tile fetch all 16 steps of u, 4 per lane (one code path: no branch between a prefetch
-        // and its use)
-        const float4 uv = gload4<VEC>(ubase, roff + t16 + 4 * s, roff + L);
-        f.dv = z4;
-        if (!LR) f.dv = gload4<VEC>(dbase, roff + t16 + 4 * s, roff + L);
+        const float2 uv = gload2<VEC>(ubase, roff + tm + 2 * s, roff + L);
+        f.dv = make_float2(0.f, 0.f);
+        if (!LR) f.dv = gload2<VEC>(dbase, roff + tm + 2 * s, roff + L);
         f.hv = hv; f.uv = uv; f.gy = gy;        // raw: the consumer zeroes padding lanes (a select here would wait for the load)
         return f;
     };
@@ -988,7 +981,6 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
         const bool last_slot = j == J - 1;
         const int mn = last_slot ? max(m - 1, 0) : m, jn = last_slot ? 0 : j + 1;   // the next iteration's (tile, slot)
         const int tm = t16 + ho;                                   // first step of this 8-step tile
-        const bool need_lo = odd != 0;                             // odd tile: steps 0..7 of the 16-tile are re-run forward
         if (j == 0 && (odd || m == m_first)) {
             // first visit of the 16-step tile (tiles run in reverse): stage B / C rows and the rank rows of all 16 steps
             // (requesting them an iteration ahead was measured: no gain, 12 more VGPRs)
@@ -1005,7 +997,9 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
         }
         const bool act = FULL || cl + 16 * j < Hc;
         Stream cur;
-        cur.hv = keep4(act, nx.hv); cur.uv = keep4(act, nx.uv); cur.dv = keep4(act, nx.dv);
+        cur.hv = keep4(act, nx.hv);
+        cur.uv = make_float2(act ? nx.uv.x : 0.f, act ? nx.uv.y : 0.f);
+        cur.dv = make_float2(act ? nx.dv.x : 0.f, act ? nx.dv.y : 0.f);
         cur.gy = make_float2(act ? nx.gy.x : 0.f, act ? nx.gy.y : 0.f);
         const unsigned c = act ? cl + 16 * j : 0;
         const unsigned roff = c * (unsigned)L;
@@ -1035,48 +1029,23 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
         {
             // ---- activation and staging of this (tile, channel) ----
             wave_lds_fence();                                      // the previous channel's readers of the staging rows are done
-            if (need_lo) {
-                // odd visit: all 16 steps are needed (the lower 8 re-run forward): lane (cl, s) activates steps 4s .. 4s+3
-                const float4 u4 = cur.uv;
-                const float4 raw = LR ? lowrank_delta(sR, R, s, wv) : cur.dv;
-                const float4 da = act ? activate_delta(raw, bias, softplus, t16 + 4 * s, L) : make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4 *>(sD + cl * SP16 + 4 * s) = da;
-                *reinterpret_cast<float4 *>(sX + cl * SP16 + 4 * s) = make_float4(da.x * u4.x, da.y * u4.y, da.z * u4.z, da.w * u4.w);
-                // u of the steps this lane finishes (8 + 2s, 8 + 2s + 1): quad lane 2 + (s >> 1), components x, y / z, w
-                {
-                    const float a0 = dpp_quad_2233(u4.x), a1 = dpp_quad_2233(u4.z), b0 = dpp_quad_2233(u4.y), b1 = dpp_quad_2233(u4.w);
-                    uf.x = (s & 1) ? a1 : a0;
-                    uf.y = (s & 1) ? b1 : b0;
-                }
-            } else {
-                // even visit: only the lower 8 steps: lane (cl, s) activates steps 2s, 2s+1.  They sit in the float4 of quad
-                // lane s >> 1 (components x, y for even s; z, w for odd s): two DPP moves and a select per value.
-                // (all four moves run in every lane BEFORE the select: a DPP read under a partial EXEC mask sees disabled
-                // source lanes as zero)
-                const bool hi = (s & 1) != 0;
-                const float ux0 = dpp_quad_0011(cur.uv.x), ux1 = dpp_quad_0011(cur.uv.z);
-                const float uy0 = dpp_quad_0011(cur.uv.y), uy1 = dpp_quad_0011(cur.uv.w);
-                const float ux = hi ? ux1 : ux0, uy = hi ? uy1 : uy0;
-                float2 raw = make_float2(0.f, 0.f);
+            {
+                // lane (cl, s) activates steps 2s, 2s+1 of this 8-step tile
+                float2 raw = cur.dv;
                 if (LR) {
 #pragma unroll
                     for (int r = 0; r < RMAX; ++r)
                         if (r < R) {                                           // rows beyond the rank are never staged
-                            const float2 rv = *reinterpret_cast<const float2 *>(sR + r * ST + 2 * s);
+                            const float2 rv = *reinterpret_cast<const float2 *>(sR + r * ST + ho + 2 * s);
                             raw.x += wv[r] * rv.x; raw.y += wv[r] * rv.y;
                         }
-                } else {
-                    const float rx0 = dpp_quad_0011(cur.dv.x), rx1 = dpp_quad_0011(cur.dv.z);
-                    const float ry0 = dpp_quad_0011(cur.dv.y), ry1 = dpp_quad_0011(cur.dv.w);
-                    raw.x = hi ? rx1 : rx0;
-                    raw.y = hi ? ry1 : ry0;
                 }
                 float2 da;
                 da.x = act ? act_delta(raw.x, bias, softplus, tm + 2 * s < L) : 0.f;
                 da.y = act ? act_delta(raw.y, bias, softplus, tm + 2 * s + 1 < L) : 0.f;
-                *reinterpret_cast<float2 *>(sD + cl * SP16 + 2 * s) = da;
-                *reinterpret_cast<float2 *>(sX + cl * SP16 + 2 * s) = make_float2(da.x * ux, da.y * uy);
-                uf = make_float2(ux, uy);
+                *reinterpret_cast<float2 *>(sD + cl * SP8 + 2 * s) = da;
+                *reinterpret_cast<float2 *>(sX + cl * SP8 + 2 * s) = make_float2(da.x * cur.uv.x, da.y * cur.uv.y);
+                uf = cur.uv;
             }
             *reinterpret_cast<float2 *>(sY + cl * SP8 + 2 * s) = cur.gy;
             wave_lds_fence();
@@ -1084,36 +1053,12 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
 
         const float Ar[4] = {Av.x, Av.y, Av.z, Av.w};
         float hent[4] = {cur.hv.x, cur.hv.y, cur.hv.z, cur.hv.w};
-        if (need_lo) {
-            // entry state of the odd tile: 8 steps forward from the saved state, nothing kept
-            float dl[T8], xl[T8];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const float4 a4 = *reinterpret_cast<const float4 *>(sD + cl * SP16 + 4 * q);
-                const float4 x4 = *reinterpret_cast<const float4 *>(sX + cl * SP16 + 4 * q);
-                dl[4 * q] = a4.x; dl[4 * q + 1] = a4.y; dl[4 * q + 2] = a4.z; dl[4 * q + 3] = a4.w;
-                xl[4 * q] = x4.x; xl[4 * q + 1] = x4.y; xl[4 * q + 2] = x4.z; xl[4 * q + 3] = x4.w;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_sched_barrier(0);                 // one state at a time: keeps the B rows of the others out of VGPRs
-                const float *sBn = sB + (4 * s + i) * BP;
-                const float4 b0 = *reinterpret_cast<const float4 *>(sBn), b1 = *reinterpret_cast<const float4 *>(sBn + 4);
-                const float bl[T8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-                const float A2 = Ar[i] * LOG2E;
-                float hh = hent[i];
-#pragma unroll
-                for (int k = 0; k < T8; ++k) hh = fast_exp2(dl[k] * A2) * hh + xl[k] * bl[k];
-                hent[i] = hh;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
         // this tile's 8 steps of delta', delta' u, dy (shared by the lane's 4 states)
         float dk[T8], xk[T8], yk[T8];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const float4 a4 = *reinterpret_cast<const float4 *>(sD + cl * SP16 + ho + 4 * q);
-            const float4 x4 = *reinterpret_cast<const float4 *>(sX + cl * SP16 + ho + 4 * q);
+            const float4 a4 = *reinterpret_cast<const float4 *>(sD + cl * SP8 + 4 * q);
+            const float4 x4 = *reinterpret_cast<const float4 *>(sX + cl * SP8 + 4 * q);
             const float4 y4 = *reinterpret_cast<const float4 *>(sY + cl * SP8 + 4 * q);
             dk[4 * q] = a4.x; dk[4 * q + 1] = a4.y; dk[4 * q + 2] = a4.z; dk[4 * q + 3] = a4.w;
             xk[4 * q] = x4.x; xk[4 * q + 1] = x4.y; xk[4 * q + 2] = x4.z; xk[4 * q + 3] = x4.w;
@@ -1167,7 +1112,7 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
                 const float a = quad_sum(sT[k]), c = quad_sum(sG[k]);
                 if (s == (k >> 1)) { Ts[k & 1] = a; Gs[k & 1] = c; }
             }
-            const float2 d2 = *reinterpret_cast<const float2 *>(sD + cl * SP16 + ho + 2 * s);
+            const float2 d2 = *reinterpret_cast<const float2 *>(sD + cl * SP8 + 2 * s);
             const float2 u2 = uf;
             const float2 g2 = *reinterpret_cast<const float2 *>(sY + cl * SP8 + 2 * s);
             const float dl2[2] = {d2.x, d2.y}, uu2[2] = {u2.x, u2.y}, gg2[2] = {g2.x, g2.y};
@@ -1336,7 +1281,7 @@ inline int block_threads(const ScanGeom &gm)
 extern "C" size_t mlagg_selscan_state_floats(int batch, int dim, int L, int N)
 {
     const size_t nchunks = (L + TC - 1) / TC;
-    return (size_t)batch * nchunks * dim * (N + 1 + (NSUB - 1) * N);     // chunk entry states, chunk delta sums, sub-tile entry states
+    return (size_t)batch * nchunks * dim * (N + 1 + NT8 * N);     // chunk entry states, chunk delta sums, 8-step tile entry states
 }
 
 extern "C" size_t mlagg_selscan_bwd_workspace_floats(int batch, int dim, int L, int N)

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.mlagg_version().startswith(b"mlagg_hip")
     assert b"unsupported" in lib.mlagg_error_string(-1)
     # size queries are pure host arithmetic
-    assert lib.mlagg_selscan_state_floats(10, 384, 21760, 16) == 10 * 340 * 384 * (16 + 1 + 3 * 16)   # chunk states, sums, sub-tile states
+    assert lib.mlagg_selscan_state_floats(10, 384, 21760, 16) == 10 * 340 * 384 * (16 + 1 + 7 * 16)   # chunk states, sums, 8-step tile states
     assert lib.mlagg_local_attn_bwd_workspace_floats(2, 8, 8, 1) >= 2 * 64 * 76
     names = [lib.mlagg_profile_kernel_name(i).decode() for i in range(lib.mlagg_profile_kernel_count())]
     assert "selscan_bwd_kernel" in names and len(set(names)) == len(names)
