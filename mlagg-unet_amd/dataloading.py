@@ -138,18 +138,27 @@ class DataLoader2D:
         return {"data": data_t, "seg": seg_t, "keys": keys}
 
 
-def to_device(batch, device, n_levels=5, stream=None):
-    """Host batch -> (data (B, C, H, W) fp32, [target_s (B, 1, H/2^s, W/2^s) fp32 labels]) on `device`."""
+def targets_from_seg(seg, n_levels=5):
+    """RemoveLabelTransform(-1, 0) (B:701) + DownsampleSegForDSTransform2, order 0 (B:730): the deep-supervision targets."""
+    seg = torch.where(seg < 0, torch.zeros_like(seg), seg)
+    targets = [seg]
+    for s in range(1, n_levels):
+        size = (seg.shape[2] >> s, seg.shape[3] >> s)
+        targets.append(torch.nn.functional.interpolate(seg, size=size, mode="nearest-exact"))
+    return targets
+
+
+def to_device(batch, device, n_levels=5, stream=None, augmenter=None):
+    """Host batch -> (data (B, C, H, W) fp32, [target_s (B, 1, H/2^s, W/2^s) fp32 labels]) on `device`; with an
+    `augmenter` (augmentation.GpuAugmenter) the training transforms run on the device in between."""
     device = torch.device(device)
     ctx = torch.cuda.stream(stream) if stream is not None else _Null()
     with ctx:
         data = batch["data"].to(device, non_blocking=True)
         seg = batch["seg"].to(device, non_blocking=True).float()
-        seg = torch.where(seg < 0, torch.zeros_like(seg), seg)                     # RemoveLabelTransform(-1, 0)
-        targets = [seg]
-        for s in range(1, n_levels):
-            size = (seg.shape[2] >> s, seg.shape[3] >> s)
-            targets.append(torch.nn.functional.interpolate(seg, size=size, mode="nearest-exact"))
+        if augmenter is not None:
+            data, seg = augmenter(data, seg)
+        targets = targets_from_seg(seg, n_levels)
     return data, targets
 
 
@@ -166,7 +175,7 @@ class PrefetchLoader:
     (numpy's slicing / copies release the GIL); batches arrive on the device through a side stream, and `next()` makes the
     caller's current stream wait for that copy only."""
 
-    def __init__(self, loader, device, num_workers=4, depth=6, seed=1234, n_levels=5):
+    def __init__(self, loader, device, num_workers=4, depth=6, seed=1234, n_levels=5, augmenter=None):
         self.device = torch.device(device)
         self.q = queue.Queue(maxsize=depth)
         self.stop = threading.Event()
@@ -178,20 +187,21 @@ class PrefetchLoader:
                                  tuple(np.array(loader.patch_size) - loader.need_to_pad), loader.annotated_classes_key,
                                  loader.oversample, rng=np.random.RandomState(seed + i), pin_memory=loader.pin,
                                  has_ignore=loader.has_ignore)
-            t = threading.Thread(target=self._work, args=(clone,), daemon=True)
+            aug = augmenter.clone(seed + 7919 * (i + 1)) if augmenter is not None else None
+            t = threading.Thread(target=self._work, args=(clone, aug), daemon=True)
             t.start()
             self.workers.append(t)
 
-    def _work(self, loader):
+    def _work(self, loader, augmenter=None):
         while not self.stop.is_set():
             try:
                 b = loader.generate_train_batch()
                 if self.copy_stream is not None:
-                    data, targets = to_device(b, self.device, self.n_levels, self.copy_stream)
+                    data, targets = to_device(b, self.device, self.n_levels, self.copy_stream, augmenter)
                     ev = torch.cuda.Event()
                     ev.record(self.copy_stream)
                 else:
-                    data, targets = to_device(b, self.device, self.n_levels)
+                    data, targets = to_device(b, self.device, self.n_levels, None, augmenter)
                     ev = None
                 item = (data, targets, ev, b)                 # keep the pinned host batch alive until consumed
             except BaseException as e:                        # missing .pkl, bad .npz, out of memory on the copy stream ...

@@ -1,0 +1,109 @@
+"""Training augmentation (second half; reference nnUNetTrainer.get_training_transforms B:645-733): the
+device program of mlagg-unet_amd/augmentation.py, run here on host tensors, against the scipy / numpy restatement of
+batchgenerators' transforms (oracle/augmentation_oracle.py; third-party, unpinned) with identical parameters.
+Tolerance: the data channel is fp32 on the product side and float64 inside scipy -- 2e-5 absolute on images of amplitude ~5
+(cubic-spline prefilter as an fp32 matmul); segmentations bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import mlagg_unet_amd  # noqa: F401
+from mlagg_unet_amd import augmentation as AUG
+from mlagg_unet_amd import dataloading as DL
+from oracle import augmentation_oracle as AO
+from oracle import dataloading_oracle as DO
+from tests import _augmentation_cases as K
+
+TOL = 2e-5
+
+
+def test_initial_patch_size_of_the_reference_configurations():
+    # compute_initial_patch_size.py:4-25 with B:361-377's rotation ranges and the (0.85, 1.25) scale range of B:378-382
+    rot = AUG.rotation_for_2d((256, 256))
+    assert rot == pytest.approx((-np.pi, np.pi))
+    assert tuple(AUG.get_patch_size((256, 256), rot, (0, 0), (0, 0), (0.85, 1.25))) == (301, 301)
+    assert tuple(AUG.get_patch_size((512, 640), AUG.rotation_for_2d((512, 640)), (0, 0), (0, 0), (0.85, 1.25))) == (752, 752)
+    small = AUG.rotation_for_2d((128, 256))                                    # anisotropic patch: +-15 degrees
+    assert small == pytest.approx((-15 / 360 * 2 * np.pi, 15 / 360 * 2 * np.pi))
+    got = AUG.get_patch_size((128, 256), small, (0, 0), (0, 0), (0.85, 1.25))
+    c, s = np.cos(small[1]), np.sin(small[1])
+    assert tuple(got) == (int((128 * c + 256 * s) / 0.85), int(256 / 0.85))
+    # 3-D: each axis rotated alone, the per-axis maximum kept: c . Rx = (c0, c1 cos + c2 sin, -c1 sin + c2 cos)
+    got3 = AUG.get_patch_size((64, 128, 128), (-0.5, 0.5), (0, 0), (0, 0), (0.85, 1.25))
+    assert tuple(got3) == (75, int((128 * np.cos(0.5) + 128 * np.sin(0.5)) / 0.85), int(128 / 0.85))
+
+
+def test_parameter_draw_frequencies():
+    p = AUG.draw_params(np.random.RandomState(0), 20000, 2)
+    for key, prob in (("do_rot", 0.2), ("do_scale", 0.2), ("do_noise", 0.1), ("do_blur", 0.2), ("do_bright", 0.15),
+                      ("do_contrast", 0.15), ("do_lowres", 0.25), ("do_gamma_inv", 0.1), ("do_gamma", 0.3)):
+        assert abs(p[key].mean() - prob) < 0.01, key
+    assert abs(p["blur_ch"][p["do_blur"]].mean() - 0.5) < 0.02 and abs(p["lowres_ch"][p["do_lowres"]].mean() - 0.5) < 0.02
+    assert abs(p["mirror"].mean() - 0.5) < 0.01
+    sc = p["scale"][p["do_scale"]]
+    assert sc.min() >= 0.7 and sc.max() <= 1.4 and abs((sc < 1).mean() - 0.5) < 0.03      # two-sided draw around 1
+    g = p["gamma"][p["do_gamma"]]
+    assert g.min() >= 0.7 and g.max() <= 1.5 and abs((g < 1).mean() - 0.5) < 0.03
+    assert np.all(p["angle"][~p["do_rot"]] == 0) and np.all(p["scale"][~p["do_scale"]] == 1)
+    assert not AUG.draw_params(np.random.RandomState(0), 64, 1, mirror_axes=(1,))["mirror"][:, 0].any()
+
+
+@pytest.mark.parametrize("keys", K.STAGES, ids=lambda k: k[0])
+def test_each_transform_matches_the_oracle(keys):
+    shape = K.IN if keys[0] == "do_rot" else K.OUT
+    data, seg = K.images(shape=shape)
+    p = K.only(K.forced_params(), keys)
+    noise = np.random.RandomState(5).randn(K.B, K.C, *K.OUT).astype(np.float32)
+    got_d, got_s = AUG.GpuAugmenter(K.OUT, "cpu").apply(torch.from_numpy(data), torch.from_numpy(seg), p, torch.from_numpy(noise))
+    want_d, want_s = AO.apply(data.copy(), seg.copy(), K.OUT, p, noise)
+    assert np.abs(got_d.numpy() - want_d).max() < TOL
+    assert np.array_equal(got_s.numpy(), want_s)
+    if keys[0] not in ("do_rot",):
+        assert np.abs(got_d.numpy() - data).max() > 1e-3              # the transform did something
+
+
+def test_whole_chain_matches_the_oracle():
+    data, seg = K.images()
+    p = K.forced_params()
+    noise = np.random.RandomState(5).randn(K.B, K.C, *K.OUT).astype(np.float32)
+    got_d, got_s = AUG.GpuAugmenter(K.OUT, "cpu").apply(torch.from_numpy(data), torch.from_numpy(seg), p, torch.from_numpy(noise))
+    want_d, want_s = AO.apply(data.copy(), seg.copy(), K.OUT, p, noise)
+    assert np.abs(got_d.numpy() - want_d).max() < TOL
+    assert np.array_equal(got_s.numpy(), want_s)
+    assert set(np.unique(want_s)) <= {-1.0, 0.0, 1.0, 2.0, 3.0}
+
+
+def test_segmentation_outside_the_image_and_identity_cases():
+    data, seg = K.images()
+    seg[:] = 2                                                          # a constant label: outside the image nothing is assigned
+    p = K.only(K.forced_params(), ["do_rot", "do_scale"])
+    p["do_rot"][:], p["do_scale"][:] = False, True
+    p["scale"][:] = 1.4                                                 # 48x56 * 1.4 < 75x83: all inside
+    p["scale"][0] = 2.5                                                 # beyond the loader patch: border -> 0 (zeros init, cval -1)
+    _, s = AUG.GpuAugmenter(K.OUT, "cpu").apply(torch.from_numpy(data), torch.from_numpy(seg), p, torch.zeros(K.B, K.C, *K.OUT))
+    assert (s[1:] == 2).all() and (s[0, 0, 0, 0] == 0) and (s[0, 0, K.OUT[0] // 2, K.OUT[1] // 2] == 2)
+    _, want = AO.apply(data.copy(), seg.copy(), K.OUT, p, np.zeros((K.B, K.C) + K.OUT, np.float32))
+    assert np.array_equal(s.numpy(), want)
+    # nothing drawn: the chain is the centre crop
+    q = K.only(p, [])
+    d, s = AUG.GpuAugmenter(K.OUT, "cpu").apply(torch.from_numpy(data), torch.from_numpy(seg), q, torch.zeros(K.B, K.C, *K.OUT))
+    y0, x0 = (K.IN[0] - K.OUT[0]) // 2, (K.IN[1] - K.OUT[1]) // 2
+    assert np.array_equal(d.numpy(), data[:, :, y0:y0 + K.OUT[0], x0:x0 + K.OUT[1]])
+
+
+def test_loader_with_augmenter_feeds_train_shapes(tmp_path):
+    DO.write_synthetic_dataset(str(tmp_path), unpack=True, small=False)
+    aug = AUG.GpuAugmenter((64, 64), "cpu", seed=3)
+    init = aug.initial_patch_size()
+    assert init == (75, 75)
+    dl = DL.DataLoader2D(DL.Dataset(str(tmp_path)), 4, init, (64, 64), [0, 1, 2, 3], 0.33, rng=np.random.RandomState(1),
+                         pin_memory=False)
+    feed = DL.PrefetchLoader(dl, "cpu", num_workers=2, depth=2, augmenter=aug)
+    try:
+        for _ in range(4):
+            data, targets = feed.next()
+            assert data.shape == (4, 1, 64, 64) and data.dtype == torch.float32 and torch.isfinite(data).all()
+            assert [tuple(t.shape[-2:]) for t in targets] == [(64, 64), (32, 32), (16, 16), (8, 8), (4, 4)]
+            assert all(set(torch.unique(t).tolist()) <= {0.0, 1.0, 2.0, 3.0} for t in targets)
+    finally:
+        feed.close()
