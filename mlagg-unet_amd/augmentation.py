@@ -128,66 +128,106 @@ def draw_params(rng, batch, channels, rotation=(-math.pi, math.pi), mirror_axes=
 # ------------------------------------------------------------------------------------------------
 # cubic B-spline machinery (scipy.ndimage semantics)
 # ------------------------------------------------------------------------------------------------
-_PREFILTER = {}
+_POLE = math.sqrt(3.0) - 2.0                     # pole of the cubic B-spline prefilter
+_TAPS = 16                                       # |pole|^16 = 7e-10: the truncated impulse response is exact in fp32
+_KERNELS = {}
+
+
+def _prefilter_kernel(device):
+    """Impulse response of the cubic B-spline prefilter, h[k] = 6 z / (z^2 - 1) * z^|k| (z = sqrt(3) - 2), cut at +-16."""
+    key = str(device)
+    h = _KERNELS.get(key)
+    if h is None:
+        k = np.arange(-_TAPS, _TAPS + 1)
+        h = torch.from_numpy(6.0 * _POLE / (_POLE * _POLE - 1.0) * _POLE ** np.abs(k)).to(device=device, dtype=torch.float32)
+        _KERNELS[key] = h
+    return h
+
+
+def _boundary_index(i, n, kind):
+    """Source index of position i of an n-long axis extended as scipy's "mirror" (d c b | a b c d | c b a) or "reflect"
+    (d c b a | a b c d | d c b a; called symmetric here); any distance (tiny low-resolution images)."""
+    if kind == "mirror":
+        period = max(2 * (n - 1), 1)
+        i = i.abs() % period
+        return torch.where(i > n - 1, period - i, i)
+    period = 2 * n
+    i = torch.where(i < 0, -i - 1, i) % period
+    return torch.where(i > n - 1, period - 1 - i, i)
+
+
+def band_matrix(n, taps, kind, device):
+    """(.., K) filter taps (K odd, centred) -> (.., n, n) matrices T with (T x)[i] = sum_k taps[k] x[ext(i + k - K//2)]:
+    a 1-D correlation with the boundary rule folded in.  Filters then run as plain (batched) matrix products -- library
+    GEMMs for any image size, no convolution-solver search for the ever-changing shapes of the low-resolution transform."""
+    K = taps.shape[-1]
+    src = _boundary_index(torch.arange(n, device=device).view(n, 1) + torch.arange(K, device=device).view(1, K) - K // 2, n, kind)
+    lead = taps.shape[:-1]
+    T = torch.zeros(*lead, n, n, device=device, dtype=torch.float32)
+    return T.scatter_add_(-1, src.expand(*lead, n, K), taps.unsqueeze(-2).expand(*lead, n, K).contiguous())
+
+
+_MATRICES = {}
 
 
 def _prefilter_matrix(n, device):
-    """Inverse of the cubic B-spline collocation matrix with mirror boundary (c[-1] = c[1]): what scipy's spline_filter
-    computes for mode "constant" / "mirror".  (n, n) fp32 on `device`, built in float64 once per size."""
     key = (n, str(device))
-    if key not in _PREFILTER:
-        Bm = np.zeros((n, n))
-        for i in range(n):
-            Bm[i, i] += 4.0 / 6.0
-            Bm[i, (i - 1) if i > 0 else min(1, n - 1)] += 1.0 / 6.0
-            Bm[i, (i + 1) if i < n - 1 else max(n - 2, 0)] += 1.0 / 6.0
-        _PREFILTER[key] = torch.from_numpy(np.linalg.inv(Bm)).to(device=device, dtype=torch.float32)
-    return _PREFILTER[key]
+    m = _MATRICES.get(key)                       # loader worker threads share the cache: get / set only, never check-then-read
+    if m is None:
+        m = band_matrix(n, _prefilter_kernel(device), "mirror", device)
+        if len(_MATRICES) > 64:                  # the low-resolution transform asks for ever new sizes
+            _MATRICES.clear()
+        _MATRICES[key] = m
+    return m
 
 
 def spline_coefficients(x):
-    """(.., H, W) image -> cubic B-spline coefficients (prefilter along both axes)."""
+    """(.., H, W) image -> cubic B-spline coefficients with scipy's "mirror" boundary (what spline_filter computes for
+    mode "constant"): the recursive filter's impulse response decays as 0.268^|k|, so it is a 33-tap band matrix per axis."""
     H, W = x.shape[-2:]
     return _prefilter_matrix(H, x.device) @ x @ _prefilter_matrix(W, x.device).T
 
 
 def _mirror_index(i, n):
-    i = torch.where(i < 0, -i, i)
+    i = i.abs()
     return torch.where(i > n - 1, 2 * (n - 1) - i, i).clamp_(0, n - 1)
 
 
 def _bspline3_weights(t):
+    """(.., P) fractional offsets -> (.., 4, P) weights of the taps floor - 1 .. floor + 2."""
     t2, t3 = t * t, t * t * t
-    return ((1 - t) ** 3 / 6.0, (3 * t3 - 6 * t2 + 4) / 6.0, (-3 * t3 + 3 * t2 + 3 * t + 1) / 6.0, t3 / 6.0)
+    return torch.stack([(1 - t) ** 3 / 6.0, (3 * t3 - 6 * t2 + 4) / 6.0, (-3 * t3 + 3 * t2 + 3 * t + 1) / 6.0, t3 / 6.0], -2)
 
 
 def sample(img, coords, order, cval):
     """scipy.ndimage.map_coordinates(img, coords, order, mode="constant", cval) for a batch: img (B, C, H, W), coords
-    (B, 2, Ho, Wo) in pixel units (row, column) -> (B, C, Ho, Wo).  order 3 expects `img` to be spline coefficients."""
+    (B, 2, Ho, Wo) in pixel units (row, column) -> (B, C, Ho, Wo).  order 3 expects `img` to be spline coefficients.
+    All taps of all channels in one gather."""
     B, C, H, W = img.shape
-    y, x = coords[:, 0], coords[:, 1]
+    out_shape = coords.shape[2:]
+    y, x = coords[:, 0].reshape(B, -1), coords[:, 1].reshape(B, -1)                # (B, P)
     inside = (y >= 0) & (y <= H - 1) & (x >= 0) & (x <= W - 1)
     fy, fx = torch.floor(y), torch.floor(x)
     ty, tx = y - fy, x - fx
     if order == 3:
-        wy, wx, first = _bspline3_weights(ty), _bspline3_weights(tx), -1
+        wy, wx, first, n = _bspline3_weights(ty), _bspline3_weights(tx), -1, 4      # (B, 4, P)
     else:
-        wy, wx, first = (1 - ty, ty), (1 - tx, tx), 0
-    flat = img.reshape(B, C, H * W)
-    out = torch.zeros(B, C, *y.shape[1:], device=img.device, dtype=img.dtype)
-    for i, wyi in enumerate(wy):
-        yi = _mirror_index(fy.long() + first + i, H)
-        for j, wxj in enumerate(wx):
-            xj = _mirror_index(fx.long() + first + j, W)
-            idx = (yi * W + xj).reshape(B, 1, -1).expand(-1, C, -1)
-            out += (wyi * wxj).unsqueeze(1) * flat.gather(2, idx).view_as(out)
-    return torch.where(inside.unsqueeze(1), out, torch.full_like(out, cval))
+        wy, wx, first, n = torch.stack([1 - ty, ty], -2), torch.stack([1 - tx, tx], -2), 0, 2
+    taps = torch.arange(n, device=img.device).view(1, n, 1) + first
+    yi = _mirror_index(fy.long().unsqueeze(1) + taps, H)                            # (B, n, P)
+    xj = _mirror_index(fx.long().unsqueeze(1) + taps, W)
+    idx = (yi.unsqueeze(2) * W + xj.unsqueeze(1)).reshape(B, 1, -1)                 # (B, 1, n * n * P)
+    w = (wy.unsqueeze(2) * wx.unsqueeze(1)).reshape(B, 1, n * n, -1)
+    vals = img.reshape(B, C, H * W).gather(2, idx.expand(-1, C, -1)).view(B, C, n * n, -1)
+    out = (vals * w).sum(2)
+    out = torch.where(inside.unsqueeze(1), out, torch.full_like(out, cval))
+    return out.view(B, C, *out_shape)
 
 
 # ------------------------------------------------------------------------------------------------
 # transforms (device; per-sample parameters as tensors)
 # ------------------------------------------------------------------------------------------------
-def spatial_transform(data, seg, patch_size, do, angle, scale):
+def spatial_transform(data, seg, patch_size, do, angle, scale, labels=None):
     """batchgenerators augment_spatial (2-D, no elastic deformation, random_crop False): output pixel grid centred on the
     input centre, rotated by `angle` and scaled by `scale` where `do`; other samples are centre-cropped."""
     B, C, Hi, Wi = data.shape
@@ -203,47 +243,41 @@ def spatial_transform(data, seg, patch_size, do, angle, scale):
     x = (-cy * sin + cx * cos) * sc + (Wi / 2.0 - 0.5)
     coords = torch.stack([y, x], 1)
     out_d = sample(spline_coefficients(data), coords, 3, 0.0)
-    # segmentation: one linear interpolation per label value present, ascending; >= 0.5 assigns (interpolate_img, is_seg)
-    out_s = torch.zeros(B, seg.shape[1], Ho, Wo, device=dev, dtype=seg.dtype)
-    for c in torch.unique(seg).tolist():
-        r = sample((seg == c).to(torch.float32), coords, 1, -1.0)
-        out_s = torch.where(r >= 0.5, torch.full_like(out_s, c), out_s)
+    # segmentation: one linear interpolation per label value, ascending; the last label whose interpolated indicator reaches
+    # 0.5 is assigned, nothing where none does (interpolate_img, is_seg).  All indicator maps are channels of ONE gather.
+    if labels is None:
+        lab = torch.unique(seg)                                              # sorted; the dataset's label list avoids this pass
+    else:
+        lab = labels if torch.is_tensor(labels) else torch.tensor(sorted(labels), device=dev, dtype=seg.dtype)
+    onehot = (seg == lab.view(1, -1, 1, 1)).to(torch.float32)               # seg has one channel on this path
+    r = sample(onehot, coords, 1, -1.0)                                      # (B, K, Ho, Wo)
+    rank = ((r >= 0.5) * torch.arange(1, len(lab) + 1, device=dev).view(1, -1, 1, 1)).amax(1, keepdim=True)
+    out_s = torch.where(rank > 0, lab[(rank - 1).clamp_(min=0)], torch.zeros((), device=dev, dtype=seg.dtype))
     # untouched samples: centre crop (crop() with crop_type "center")
     y0, x0 = (Hi - Ho) // 2, (Wi - Wo) // 2
     m = do.view(B, 1, 1, 1)
     return (torch.where(m, out_d, data[:, :, y0:y0 + Ho, x0:x0 + Wo]), torch.where(m, out_s, seg[:, :, y0:y0 + Ho, x0:x0 + Wo]))
 
 
-def _symmetric_pad(x, r, dim):
-    """scipy's "reflect" extension (d c b a | a b c d | d c b a) by r pixels along `dim`."""
-    n = x.shape[dim]
-    lo = x.narrow(dim, 0, r).flip(dim)
-    hi = x.narrow(dim, n - r, r).flip(dim)
-    return torch.cat([lo, x, hi], dim)
-
-
-def gaussian_blur(data, do, sigma):
-    """scipy.ndimage.gaussian_filter(img, sigma, order=0) (truncate 4, mode "reflect") per (sample, channel) where `do`."""
+def gaussian_blur(data, do, sigma, radius):
+    """scipy.ndimage.gaussian_filter(img, sigma, order=0) (truncate 4, mode "reflect") per (sample, channel) where `do`;
+    `radius` = int(4 max(sigma) + 0.5), from the host-side parameters (no device read-back)."""
     B, C, H, W = data.shape
-    R = int(4.0 * float(sigma.max()) + 0.5)
-    if R == 0 or not bool(do.any()):
+    if radius == 0:
         return data
-    t = torch.arange(-R, R + 1, device=data.device, dtype=torch.float32).view(1, 1, -1)
+    t = torch.arange(-radius, radius + 1, device=data.device, dtype=torch.float32).view(1, 1, -1)
     s = sigma.view(B, C, 1)
-    lw = torch.floor(4.0 * s + 0.5)
-    w = torch.exp(-0.5 * (t / s) ** 2) * (t.abs() <= lw)
-    w = (w / w.sum(-1, keepdim=True)).reshape(B * C, 1, 2 * R + 1)
-    x = data.reshape(1, B * C, H, W)
-    x = F.conv2d(_symmetric_pad(x, R, 3), w.unsqueeze(2), groups=B * C)              # along W (last axis first, as scipy)
-    x = F.conv2d(_symmetric_pad(x, R, 2), w.unsqueeze(3), groups=B * C)
-    return torch.where(do.view(B, C, 1, 1), x.view(B, C, H, W), data)
+    w = torch.exp(-0.5 * (t / s) ** 2) * (t.abs() <= torch.floor(4.0 * s + 0.5))      # each channel's own truncation
+    w = w / w.sum(-1, keepdim=True)
+    x = band_matrix(H, w, "symmetric", data.device) @ data @ band_matrix(W, w, "symmetric", data.device).transpose(-1, -2)
+    return torch.where(do.view(B, C, 1, 1), x, data)
 
 
 def simulate_low_resolution(data, do, zoom):
     """SimulateLowResolutionTransform: skimage resize to round(shape * zoom) with order 0, back with order 3 (mode "edge")."""
     B, C, H, W = data.shape
     out = data.clone()
-    for b, c in torch.nonzero(do).tolist():                   # few (p 0.25 x 0.5): each (sample, channel) has its own low-res size
+    for b, c in np.argwhere(np.asarray(do)).tolist():         # few (p 0.25 x 0.5): each (sample, channel) has its own low-res size
         z = float(zoom[b, c])
         h, w = int(round(H * z)), int(round(W * z))
         img = data[b, c]
@@ -298,11 +332,13 @@ class GpuAugmenter:
     """(loader batch on the host) -> augmented (data, [targets]) on the device: the reference's training transform chain
     (B:677-733) behind `dataloading.DataLoader2D`.  `patch_size`: the network's; the loader delivers `get_patch_size(...)`."""
 
-    def __init__(self, patch_size, device, rotation=None, mirror_axes=(0, 1), seed=None):
+    def __init__(self, patch_size, device, rotation=None, mirror_axes=(0, 1), seed=None, labels=None):
         self.patch_size = tuple(int(v) for v in patch_size)
         self.device = torch.device(device)
         self.rotation = rotation_for_2d(self.patch_size) if rotation is None else rotation
         self.mirror_axes = tuple(mirror_axes)
+        # every value the loader's segmentation can hold (label_manager.all_labels and the -1 padding), ascending
+        self.labels = None if labels is None else torch.tensor(sorted(set(labels) | {-1}), dtype=torch.float32, device=self.device)
         self.rng = np.random.RandomState(seed)
 
     def initial_patch_size(self):
@@ -313,21 +349,26 @@ class GpuAugmenter:
         dev = data.device
         T = lambda a, dt=torch.float32: torch.as_tensor(np.asarray(a), device=dev).to(dt)      # noqa: E731
         data, seg = spatial_transform(data, seg.to(torch.float32), self.patch_size, T(p["do_rot"] | p["do_scale"], torch.bool),
-                                      T(p["angle"] * p["do_rot"]), T(np.where(p["do_scale"], p["scale"], 1.0)))
+                                      T(p["angle"] * p["do_rot"]), T(np.where(p["do_scale"], p["scale"], 1.0)),
+                                      None if self.labels is None else self.labels.to(data.device))
         if noise is None:
             noise = torch.randn_like(data)
         data = data + noise * T(p["noise_std"] * p["do_noise"]).view(-1, 1, 1, 1)
-        data = gaussian_blur(data, T(p["blur_ch"] & p["do_blur"][:, None], torch.bool), T(p["blur_sigma"]))
+        blur = p["blur_ch"] & p["do_blur"][:, None]
+        radius = int(4.0 * float(p["blur_sigma"][blur].max()) + 0.5) if blur.any() else 0
+        data = gaussian_blur(data, T(blur, torch.bool), T(p["blur_sigma"]), radius)
         data = torch.where(T(p["do_bright"], torch.bool).view(-1, 1, 1, 1), data * T(p["bright"]).view(*p["bright"].shape, 1, 1), data)
         data = contrast_transform(data, T(p["do_contrast"], torch.bool), T(p["contrast"]))
-        data = simulate_low_resolution(data, T(p["lowres_ch"] & p["do_lowres"][:, None], torch.bool), p["lowres_zoom"])
+        data = simulate_low_resolution(data, p["lowres_ch"] & p["do_lowres"][:, None], p["lowres_zoom"])
         data = gamma_transform(data, T(p["do_gamma_inv"], torch.bool), T(p["gamma_inv"]), invert=True)
         data = gamma_transform(data, T(p["do_gamma"], torch.bool), T(p["gamma"]), invert=False)
         return mirror_transform(data, seg, T(p["mirror"], torch.bool))
 
     def clone(self, seed):
         """The same chain with its own parameter stream (one per loader worker)."""
-        return GpuAugmenter(self.patch_size, self.device, self.rotation, self.mirror_axes, seed)
+        twin = GpuAugmenter(self.patch_size, self.device, self.rotation, self.mirror_axes, seed)
+        twin.labels = self.labels
+        return twin
 
     def __call__(self, data, seg):
         """(B, C, Hi, Wi) data and (B, 1, Hi, Wi) seg of the loader's initial patch size, on the device -> the augmented

@@ -61,7 +61,7 @@ __device__ __forceinline__ float softplus_f(float x)
 {
     const float e = __expf(-fabsf(x));
     const float small = e * (1.f - e * (0.5f - e * (1.f / 3.f)));
-    const float big = __logf(1.f + e);
+    const float big = __builtin_amdgcn_logf(1.f + e) * 0.6931471805599453f;   // bare v_log_f32 (log2): 1 + e >= 1, no denormal path needed
     return fmaxf(x, 0.f) + (e < 0.01f ? small : big);
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -827,12 +827,26 @@ __device__ __forceinline__ float act_delta(float raw, float bias, int softplus, 
 
 // Loads / stores of the group kernel.  VEC (L % 4 == 0: every MLAgg-UNet shape): branch-free -- the address is clamped
 // and the value selected, so that no conditional block (and no s_waitcnt at its end) sits between a prefetch and its use.
-template <bool VEC>
+// uniform base + a 32-bit BYTE offset per lane: the form the `global_load ... v_off, s[base:base+1]` encoding takes (an
+// element offset scaled in 64 bits costs a v_mov + v_lshl_add_u64 per access)
+template <typename T>
+__device__ __forceinline__ T ldg_at(const float *__restrict__ base, unsigned elem)
+{
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (size_t)(elem * 4u));
+}
+template <typename T>
+__device__ __forceinline__ void stg_at(float *__restrict__ base, unsigned elem, const T &v)
+{
+    *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + (size_t)(elem * 4u)) = v;
+}
+// NOCHK: the caller knows [t, t+n) lies inside the row (sequence length a multiple of the chunk): no clamp, no select
+template <bool VEC, bool NOCHK = false>
 __device__ __forceinline__ float4 gload4(const float *__restrict__ base, unsigned t, unsigned end)   // elements [t, t+4) of base, zero at / beyond `end`
 {
+    if (NOCHK) return ldg_at<float4>(base, t);
     if (VEC) {
         const bool ok = t < end;
-        const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)(ok ? t : 0u));
+        const float4 v = ldg_at<float4>(base, ok ? t : 0u);
         return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
     }
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -842,12 +856,13 @@ __device__ __forceinline__ float4 gload4(const float *__restrict__ base, unsigne
     if (t + 3 < end) v.w = base[t + 3];
     return v;
 }
-template <bool VEC>
+template <bool VEC, bool NOCHK = false>
 __device__ __forceinline__ float2 gload2(const float *__restrict__ base, unsigned t, unsigned end)
 {
+    if (NOCHK) return ldg_at<float2>(base, t);
     if (VEC) {
         const bool ok = t < end;
-        const float2 v = *reinterpret_cast<const float2 *>(base + (size_t)(ok ? t : 0u));
+        const float2 v = ldg_at<float2>(base, ok ? t : 0u);
         return make_float2(ok ? v.x : 0.f, ok ? v.y : 0.f);
     }
     float2 v = make_float2(0.f, 0.f);
@@ -855,11 +870,13 @@ __device__ __forceinline__ float2 gload2(const float *__restrict__ base, unsigne
     if (t + 1 < end) v.y = base[t + 1];
     return v;
 }
-template <bool VEC>
+template <bool VEC, bool NOCHK = false>
 __device__ __forceinline__ void gstore4(float *__restrict__ base, unsigned t, unsigned end, float4 v)
 {
-    if (VEC) {
-        if (t < end) *reinterpret_cast<float4 *>(base + (size_t)t) = v;
+    if (NOCHK) {
+        stg_at<float4>(base, t, v);
+    } else if (VEC) {
+        if (t < end) stg_at<float4>(base, t, v);
     } else {
         if (t < end) base[t] = v.x;
         if (t + 1 < end) base[t + 1] = v.y;
@@ -867,11 +884,13 @@ __device__ __forceinline__ void gstore4(float *__restrict__ base, unsigned t, un
         if (t + 3 < end) base[t + 3] = v.w;
     }
 }
-template <bool VEC>
+template <bool VEC, bool NOCHK = false>
 __device__ __forceinline__ void gstore2(float *__restrict__ base, unsigned t, unsigned end, float2 v)
 {
-    if (VEC) {
-        if (t < end) *reinterpret_cast<float2 *>(base + (size_t)t) = v;
+    if (NOCHK) {
+        stg_at<float2>(base, t, v);
+    } else if (VEC) {
+        if (t < end) stg_at<float2>(base, t, v);
     } else {
         if (t < end) base[t] = v.x;
         if (t + 1 < end) base[t + 1] = v.y;
@@ -888,8 +907,11 @@ __device__ __forceinline__ float4 keep4(bool c, const float4 &v)
 }
 
 // FULL: the group is a whole number of 16-channel slots (Hc % 16 == 0, every MLAgg-UNet shape): no padding lanes, so the
-// ~30 selects per (tile, channel) that zero them disappear.
-template <bool LR, bool VEC, bool FULL>
+// ~30 selects per (tile, channel) that zero them disappear.  WHOLE (needs VEC and FULL): L is a multiple of the 64-step
+// chunk (the headline 256^2 shape: 21760 = 340 * 64), every access is in range: no clamps / range selects at all.
+// RT: 0 = delta is a tensor; RMAX = low-rank form with a run-time rank R <= RMAX; 1 .. RMAX-1 = rank known (R == RT: the
+// model's R = 3 skips the fourth, padding, rank row everywhere).
+template <int RT, bool VEC, bool FULL, bool WHOLE>
 __global__ void __launch_bounds__(64, 2)
 selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ delta, const float *__restrict__ Wdt, int R,
                          const float *__restrict__ A, const float *__restrict__ Bm, const float *__restrict__ Cm,
@@ -906,6 +928,9 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
     __shared__ float2 sE[JMAX * 16 * 3];                // per channel: {dD, d(bias)}, {dW0, dW1}, {dW2, dW3}
     // 18.4 KB in all: 8 waves per CU (2 per SIMD, what ~240 VGPRs allow)
 
+    constexpr bool LR = RT > 0;
+    constexpr bool RDYN = RT == RMAX;                   // rank rows beyond the run-time R are skipped one by one
+    static_assert(!WHOLE || (VEC && FULL), "WHOLE implies VEC and FULL");
     const int chunk = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
     const int L = gm.L, Hc = gm.Hc, dim = gm.dim;
     const int J = (Hc + 15) >> 4;
@@ -929,7 +954,7 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
     // Tiles run in reverse, channels inside a tile forward: ONE flat loop over (tile, channel) so that the HBM streams of
     // the NEXT (tile, channel) -- u, dy, the saved entry state -- are in flight while this one computes (with ~2 waves
     // per SIMD and no prefetch, half of all wave cycles were s_waitcnt: PMC SQ_WAIT_ANY, profiles/round2_a).
-    const int m_first = min(TC / T8 - 1, (L - 1 - tc0) / T8);     // last tile that starts inside the sequence
+    const int m_first = WHOLE ? TC / T8 - 1 : min(TC / T8 - 1, (L - 1 - tc0) / T8);     // last tile that starts inside the sequence
     const int n_it = (m_first + 1) * J;
 
     const size_t grow = ((size_t)b * dim + g * Hc) * L;            // first row of the group in the (B, D, L) tensors
@@ -942,18 +967,18 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
     auto fetch = [&](int m, int j, bool live, int ln) -> Stream {
         Stream f;
         const int cl = ln >> 2, s = ln & 3;
-        const bool act = live && (FULL || cl + 16 * j < Hc);
+        const bool act = WHOLE || (live && (FULL || cl + 16 * j < Hc));    // WHOLE: the (tile, slot) passed in is always a real one
         const int tm = tc0 + m * T8;
         // uniform 64-bit bases + 32-bit lane offsets: the loads take the SGPR-base form (no 64-bit VALU address arithmetic)
         const unsigned c = act ? cl + 16 * j : 0;
         const unsigned roff = c * (unsigned)L;
         // the state entering 8-step tile m: the chunk's entry state (m = 0) or the forward pass's per-tile save
         const float *sbase = m == 0 ? cstate + (crow * dim + g * Hc) * NS : csub + ((crow * NT8 + (m - 1)) * dim + g * Hc) * NS;
-        const float4 hv = *reinterpret_cast<const float4 *>(sbase + (size_t)(c * NS + 4 * s));
-        const float2 gy = gload2<VEC>(gbase, roff + tm + 2 * s, roff + L);
-        const float2 uv = gload2<VEC>(ubase, roff + tm + 2 * s, roff + L);
+        const float4 hv = ldg_at<float4>(sbase, c * NS + 4 * s);
+        const float2 gy = gload2<VEC, WHOLE>(gbase, roff + tm + 2 * s, roff + L);
+        const float2 uv = gload2<VEC, WHOLE>(ubase, roff + tm + 2 * s, roff + L);
         f.dv = make_float2(0.f, 0.f);
-        if (!LR) f.dv = gload2<VEC>(dbase, roff + tm + 2 * s, roff + L);
+        if (!LR) f.dv = gload2<VEC, WHOLE>(dbase, roff + tm + 2 * s, roff + L);
         f.hv = hv; f.uv = uv; f.gy = gy;        // raw: the consumer zeroes padding lanes (a select here would wait for the load)
         return f;
     };
@@ -985,10 +1010,10 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
             // first visit of the 16-step tile (tiles run in reverse): stage B / C rows and the rank rows of all 16 steps
             // (requesting them an iteration ahead was measured: no gain, 12 more VGPRs)
             const unsigned no = (unsigned)(lane >> 2) * (unsigned)L;
-            const float4 rb = gload4<VEC>(Bm + bg * NS * L, no + t16 + 4 * (lane & 3), no + L);
-            const float4 rc = gload4<VEC>(Cm + bg * NS * L, no + t16 + 4 * (lane & 3), no + L);
+            const float4 rb = gload4<VEC, WHOLE>(Bm + bg * NS * L, no + t16 + 4 * (lane & 3), no + L);
+            const float4 rc = gload4<VEC, WHOLE>(Cm + bg * NS * L, no + t16 + 4 * (lane & 3), no + L);
             float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (LR && lane < 4 * R) rr = gload4<VEC>(delta + bg * R * L, no + t16 + 4 * (lane & 3), no + L);
+            if (LR && lane < 4 * R) rr = gload4<VEC, WHOLE>(delta + bg * R * L, no + t16 + 4 * (lane & 3), no + L);
             wave_lds_fence();
             *reinterpret_cast<float4 *>(sB + (lane >> 2) * BP + 4 * (lane & 3)) = rb;
             *reinterpret_cast<float4 *>(sC + (lane >> 2) * BP + 4 * (lane & 3)) = rc;
@@ -1009,19 +1034,19 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
         float wv[RMAX] = {0.f, 0.f, 0.f, 0.f};
         float bias = 0.f, Dd = 0.f;
         // unconditional loads from clamped addresses (see fetch); the selects come after the prefetch has been issued
-        const float4 av_raw = *reinterpret_cast<const float4 *>(A + (size_t)g * Hc * NS + (size_t)(c * NS + 4 * s));
+        const float4 av_raw = ldg_at<float4>(A + (size_t)g * Hc * NS, c * NS + 4 * s);
         float w_raw[RMAX] = {0.f, 0.f, 0.f, 0.f};
         if (LR) {
 #pragma unroll
-            for (int r = 0; r < RMAX; ++r) w_raw[r] = (Wdt + (size_t)g * Hc * R)[c * R + min(r, R - 1)];
+            for (int r = 0; r < RT; ++r) w_raw[r] = ldg_at<float>(Wdt + (size_t)g * Hc * R, c * R + (RDYN ? min(r, R - 1) : r));
         }
-        const float b_raw = ((dbias ? dbias : A) + g * Hc)[c], d_raw = ((Dv ? Dv : A) + g * Hc)[c];
+        const float b_raw = ldg_at<float>((dbias ? dbias : A) + g * Hc, c), d_raw = ldg_at<float>((Dv ? Dv : A) + g * Hc, c);
         __builtin_amdgcn_sched_barrier(0);
         nx = fetch(mn, jn, it + 1 < n_it, ln);                     // in flight until the next iteration's staging
         __builtin_amdgcn_sched_barrier(0);
         Av = keep4(act, av_raw);
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) wv[r] = (LR && act && r < R) ? w_raw[r] : 0.f;
+        for (int r = 0; r < RT; ++r) wv[r] = (act && (!RDYN || r < R)) ? w_raw[r] : 0.f;
         bias = (act && dbias) ? b_raw : 0.f;
         Dd = (act && Dv) ? d_raw : 0.f;
         asm volatile("" : "+v"(Dd));                               // taken here (vmcnt leaves the prefetch alone), not lazily at its use
@@ -1034,15 +1059,15 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
                 float2 raw = cur.dv;
                 if (LR) {
 #pragma unroll
-                    for (int r = 0; r < RMAX; ++r)
-                        if (r < R) {                                           // rows beyond the rank are never staged
+                    for (int r = 0; r < RT; ++r)
+                        if (!RDYN || r < R) {                                  // rows beyond the rank are never staged
                             const float2 rv = *reinterpret_cast<const float2 *>(sR + r * ST + ho + 2 * s);
                             raw.x += wv[r] * rv.x; raw.y += wv[r] * rv.y;
                         }
                 }
                 float2 da;
-                da.x = act ? act_delta(raw.x, bias, softplus, tm + 2 * s < L) : 0.f;
-                da.y = act ? act_delta(raw.y, bias, softplus, tm + 2 * s + 1 < L) : 0.f;
+                da.x = act ? act_delta(raw.x, bias, softplus, WHOLE || tm + 2 * s < L) : 0.f;
+                da.y = act ? act_delta(raw.y, bias, softplus, WHOLE || tm + 2 * s + 1 < L) : 0.f;
                 *reinterpret_cast<float2 *>(sD + cl * SP8 + 2 * s) = da;
                 *reinterpret_cast<float2 *>(sX + cl * SP8 + 2 * s) = make_float2(da.x * cur.uv.x, da.y * cur.uv.y);
                 uf = cur.uv;
@@ -1106,11 +1131,22 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
         sA[j * 64 + lane] = make_float4(dAc[0], dAc[1], dAc[2], dAc[3]);
         // ---- finish d(delta') and du: quad sums, lane s keeps steps 2s, 2s+1 ----
         {
-            float Ts[2] = {0.f, 0.f}, Gs[2] = {0.f, 0.f};
+            // reduce-scatter over the quad: 8 per-step sums in, lane s leaves with steps 2s, 2s+1 (18 instead of the 24
+            // instructions of 8 all-reduces + selects)
+            float Ts[2], Gs[2];
+            {
+                const bool hi = s & 2, lo = s & 1;
+                float kt[4], kg[4];
 #pragma unroll
-            for (int k = 0; k < T8; ++k) {
-                const float a = quad_sum(sT[k]), c = quad_sum(sG[k]);
-                if (s == (k >> 1)) { Ts[k & 1] = a; Gs[k & 1] = c; }
+                for (int x = 0; x < 4; ++x) {
+                    kt[x] = (hi ? sT[x + 4] : sT[x]) + dpp_quad_xor2(hi ? sT[x] : sT[x + 4]);
+                    kg[x] = (hi ? sG[x + 4] : sG[x]) + dpp_quad_xor2(hi ? sG[x] : sG[x + 4]);
+                }
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {
+                    Ts[y] = (lo ? kt[y + 2] : kt[y]) + dpp_quad_xor1(lo ? kt[y] : kt[y + 2]);
+                    Gs[y] = (lo ? kg[y + 2] : kg[y]) + dpp_quad_xor1(lo ? kg[y] : kg[y + 2]);
+                }
             }
             const float2 d2 = *reinterpret_cast<const float2 *>(sD + cl * SP8 + 2 * s);
             const float2 u2 = uf;
@@ -1122,20 +1158,20 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
             for (int e = 0; e < 2; ++e) {
                 // d softplus(x)/dx = sigmoid(x) = 1 - exp(-softplus(x)); 1 when softplus is off
                 const float sp = softplus ? (1.f - __expf(-dl2[e])) : 1.f;
-                const bool inr = (tm + 2 * s + e) < L && act;
+                const bool inr = WHOLE || ((tm + 2 * s + e) < L && act);
                 odd2[e] = inr ? (Ts[e] + uu2[e] * Gs[e]) * sp : 0.f;        // (sT + u * sG) * softplus'
                 odu2[e] = dl2[e] * Gs[e] + Dd * gg2[e];                     // delta' * sG + D * dy
                 ev[1] += odd2[e];
                 ev[0] += gg2[e] * uu2[e];
             }
             if (act) {
-                gstore2<VEC>(dubase, roff + tm + 2 * s, roff + L, make_float2(odu2[0], odu2[1]));
-                if (!LR) gstore2<VEC>(ddbase, roff + tm + 2 * s, roff + L, make_float2(odd2[0], odd2[1]));
+                gstore2<VEC, WHOLE>(dubase, roff + tm + 2 * s, roff + L, make_float2(odu2[0], odu2[1]));
+                if (!LR) gstore2<VEC, WHOLE>(ddbase, roff + tm + 2 * s, roff + L, make_float2(odd2[0], odd2[1]));
             }
             if (LR) {
 #pragma unroll
-                for (int r = 0; r < RMAX; ++r)
-                    if (r < R) {
+                for (int r = 0; r < RT; ++r)
+                    if (!RDYN || r < R) {
                         const float w = wv[r];
                         const float2 rv = *reinterpret_cast<const float2 *>(sR + r * ST + ho + 2 * s);
                         ev[2 + r] = odd2[0] * rv.x + odd2[1] * rv.y;        // dWdt[d][r] += sum_t d(raw delta) dtr[r][t]
@@ -1144,7 +1180,7 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
                     }
             }
 #pragma unroll
-            for (int x = 0; x < 6; ++x) ev[x] = quad_sum(ev[x]);
+            for (int x = 0; x < 2 + RT; ++x) ev[x] = quad_sum(ev[x]);
             if (s == 0) {
                 float2 *e = sE + (j * 16 + cl) * 3;
                 float2 e0 = e[0], e1 = e[1], e2 = e[2];
@@ -1180,7 +1216,7 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
             o.w = r4 == 0 ? v[3] : (r4 == 1 ? v[7] : (r4 == 2 ? v[11] : v[15]));
             const int n = 4 * s + 2 * q + (r4 >> 1);
             const unsigned no = (unsigned)n * (unsigned)L;
-            gstore4<VEC>((p ? dC : dB) + bg * NS * L, no + tm + 4 * (r4 & 1), no + L, o);
+            gstore4<VEC, WHOLE>((p ? dC : dB) + bg * NS * L, no + tm + 4 * (r4 & 1), no + L, o);
             if (LR) {
                 // d(dtr)[r][steps 2s, 2s+1]: 8 values (r, e) -> reduce-scatter over lane bits 5, 4, all-reduce over bits 3, 2
                 float w[8];
@@ -1194,7 +1230,7 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
                 for (int x = 0; x < 2; ++x) { w[x] += row_ror4(w[x]); w[x] += row_ror8(w[x]); }
                 const int r = 2 * (lane >> 5) + ((lane >> 4) & 1); // the rank row this lane ends up with
                 if (r < R && (cl & 3) == 0)
-                    gstore2<VEC>(ddelta + bg * R * L, r * (unsigned)L + tm + 2 * s, (r + 1) * (unsigned)L, make_float2(w[0], w[1]));   // ddelta = d(dtr) here
+                    gstore2<VEC, WHOLE>(ddelta + bg * R * L, r * (unsigned)L + tm + 2 * s, (r + 1) * (unsigned)L, make_float2(w[0], w[1]));   // ddelta = d(dtr) here
             }
         }
         m = mn; j = jn;
@@ -1355,12 +1391,18 @@ int scan_backward(const float *u, const float *delta, const float *Wdt, int R, c
         // one wave per (batch, group, chunk) walks all channels of the group: dB / dC / d(dtr) leave with plain stores
         const dim3 gridg(gm.nchunks, G, batch);
         MLAGG_TIMED(K_SELSCAN_BWD, st);
-#define MLAGG_GROUP_LAUNCH(VEC, FULL) hipLaunchKernelGGL((selscan_bwd_group_kernel<LR, VEC, FULL>), gridg, dim3(64), 0, st, u, delta, Wdt, R, \
-            A, B, C, D, delta_bias, dout, cstate, csub, cq, du, ddelta, dB, dC, part, gm, delta_softplus)
-        const bool vecL = (L & 3) == 0, full = (gm.Hc & 15) == 0;
-        if (vecL && full) MLAGG_GROUP_LAUNCH(true, true);
-        else if (vecL) MLAGG_GROUP_LAUNCH(true, false);
-        else MLAGG_GROUP_LAUNCH(false, false);
+#define MLAGG_GROUP_LAUNCH(RT, VEC, FULL, WHOLE) hipLaunchKernelGGL((selscan_bwd_group_kernel<RT, VEC, FULL, WHOLE>), gridg, dim3(64), 0, st, u, delta, \
+            Wdt, R, A, B, C, D, delta_bias, dout, cstate, csub, cq, du, ddelta, dB, dC, part, gm, delta_softplus)
+        constexpr int RGEN = LR ? RMAX : 0;
+        const bool vecL = (L & 3) == 0, full = (gm.Hc & 15) == 0, whole = L % TC == 0;
+        constexpr int RFAST = LR ? 3 : 0;
+        if ((!LR || R == 3) && vecL && full) {                    // the model's shapes: rank 3, 96-channel groups
+            if (whole) MLAGG_GROUP_LAUNCH(RFAST, true, true, true);
+            else MLAGG_GROUP_LAUNCH(RFAST, true, true, false);
+        }
+        else if (vecL && full) MLAGG_GROUP_LAUNCH(RGEN, true, true, false);
+        else if (vecL) MLAGG_GROUP_LAUNCH(RGEN, true, false, false);
+        else MLAGG_GROUP_LAUNCH(RGEN, false, false, false);
 #undef MLAGG_GROUP_LAUNCH
     } else {
         const size_t lds3 = (size_t)(3 * gb.CB * UP + 2 * ST * BP + 2 * ST * NS + (LR ? 2 * RMAX * ST + 8 * 128 : 0) + UP + gb.CB * UP) * sizeof(float);

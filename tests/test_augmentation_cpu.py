@@ -93,7 +93,7 @@ def test_segmentation_outside_the_image_and_identity_cases():
 
 def test_loader_with_augmenter_feeds_train_shapes(tmp_path):
     DO.write_synthetic_dataset(str(tmp_path), unpack=True, small=False)
-    aug = AUG.GpuAugmenter((64, 64), "cpu", seed=3)
+    aug = AUG.GpuAugmenter((64, 64), "cpu", seed=3, labels=[0, 1, 2, 3])
     init = aug.initial_patch_size()
     assert init == (75, 75)
     dl = DL.DataLoader2D(DL.Dataset(str(tmp_path)), 4, init, (64, 64), [0, 1, 2, 3], 0.33, rng=np.random.RandomState(1),

@@ -32,7 +32,7 @@ def test_device_transforms_match_the_oracle(keys):
 def test_augmented_prefetch_drives_a_train_step(tmp_path):
     from mlagg_unet_amd import model, trainer
     DO.write_synthetic_dataset(str(tmp_path), unpack=True, small=False)
-    aug = AUG.GpuAugmenter((64, 64), "cuda:0", seed=3)
+    aug = AUG.GpuAugmenter((64, 64), "cuda:0", seed=3, labels=[0, 1, 2, 3])
     dl = DL.DataLoader2D(DL.Dataset(str(tmp_path)), 2, aug.initial_patch_size(), (64, 64), [0, 1, 2, 3], 0.33)
     feed = DL.PrefetchLoader(dl, "cuda:0", num_workers=2, depth=3, augmenter=aug)
     try:

@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--cpu-batches", type=int, default=3)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    aug = AUG.GpuAugmenter((256, 256), dev, seed=0)
+    aug = AUG.GpuAugmenter((256, 256), dev, seed=0, labels=[0, 1, 2, 3])
     init = aug.initial_patch_size()
     rng = np.random.RandomState(0)
     data = torch.from_numpy(rng.randn(10, 1, *init).astype(np.float32)).pin_memory()
