@@ -24,7 +24,7 @@ LIB_NAMES = {"selscan_fwd_kernel<false, true>": "selscan_fwd_kernel<false>", "se
 
 def load(d):
     out = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(d + "/*/*_counter_collection.csv"):
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             m = re.search(r"([a-z_0-9]+_kernel(?:<(?:true|false|\d+)(?:, ?(?:true|false|\d+))?>)?|selscan_[a-z_]+)", r["Kernel_Name"])
             if m:
