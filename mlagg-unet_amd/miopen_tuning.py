@@ -36,7 +36,21 @@ def use_tuned_convolutions(enabled=True):
         return None
     private = tempfile.mkdtemp(prefix="mlagg_miopen_db_")  # per process: MIOpen rewrites the files it opens
     for f in files:
-        shutil.copy(f, private)
+        if f.endswith(".ufdb.txt"):
+            # MIOpen re-validates a find-db record against its KERNEL cache, which is empty on a fresh box: the first
+            # listed solver whose binary is missing makes it re-time every solver of the record ("Find-db regenerating"),
+            # among them the naive reference convolutions (up to 0.4 s per launch: 17 s of the first step).  They are
+            # never the fastest, so they are dropped from the records and switched off for the re-timing.
+            with open(f) as src, open(os.path.join(private, os.path.basename(f)), "w") as dst:
+                for line in src:
+                    key, _, rec = line.rstrip("\n").partition("=")
+                    keep = [e for e in rec.split(";") if e and not e.startswith("ConvDirectNaiveConv")]
+                    if keep:
+                        dst.write(key + "=" + ";".join(keep) + "\n")
+        else:
+            shutil.copy(f, private)
+    for d in ("FWD", "BWD", "WRW"):
+        os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + d, "0")
     os.environ["MIOPEN_USER_DB_PATH"] = private
     os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")       # database hit -> tuned solver, miss -> heuristic, never a search
     torch.backends.cudnn.benchmark = True
