@@ -28,6 +28,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 LAMBDA_INIT = 0.8  # T:638
+SCAN_LITERAL_INDEXING = False   # tools/cpu_baseline_literal.py: time the scan loop exactly as selective_scan_ref writes it
 
 
 # --------------------------------------------------------------------------------------
@@ -60,9 +61,16 @@ def selective_scan_oracle(u, delta, A, B, C, D=None, z=None, delta_bias=None,
     Ct = Cf.permute(0, 1, 3, 2)                                            # (b, d, l, n)
     x = u.new_zeros(b, d, n)
     ys = []
-    for dA_i, dBu_i, C_i in zip(dA.unbind(2), dBu.unbind(2), Ct.unbind(2)):
-        x = dA_i * x + dBu_i
-        ys.append((x * C_i).sum(-1))
+    if SCAN_LITERAL_INDEXING:
+        # selective_scan_ref's own loop shape: `deltaA[:, :, i]` slices.  Same values; the backward of every slice
+        # zero-fills a (b, d, l, n) tensor, so a step is O(L^2) (figure (a)).
+        for i in range(l):
+            x = dA[:, :, i] * x + dBu[:, :, i]
+            ys.append((x * Ct[:, :, i]).sum(-1))
+    else:
+        for dA_i, dBu_i, C_i in zip(dA.unbind(2), dBu.unbind(2), Ct.unbind(2)):
+            x = dA_i * x + dBu_i
+            ys.append((x * C_i).sum(-1))
     y = torch.stack(ys, dim=2)
     out = y if D is None else y + u * D.float().view(1, d, 1)
     if z is not None:

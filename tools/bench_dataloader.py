@@ -96,8 +96,23 @@ def main():
     torch.cuda.synchronize()
     real = (time.perf_counter() - t0) / a.steps
     pf.close()
+    # the full training input path: loader at the initial patch size + the augmentation chain on the device (B:666-701)
+    from mlagg_unet_amd import augmentation  # noqa: E402
+    aug = augmentation.GpuAugmenter(patch, dev, seed=0, labels=labels)
+    dl = DL.DataLoader2D(ds, B, aug.initial_patch_size(), patch, labels, 0.33)
+    pf = DL.PrefetchLoader(dl, dev, num_workers=a.workers, depth=6, augmenter=aug)
+    for _ in range(3):
+        trainer.train_step(net, opt, *pf.next())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        trainer.train_step(net, opt, *pf.next())
+    torch.cuda.synchronize()
+    augd = (time.perf_counter() - t0) / a.steps
+    pf.close()
     print(f"train step, resident synthetic batch : {syn * 1e3:.2f} ms  ({B / syn:.1f} images/s)")
     print(f"train step, PrefetchLoader ({a.workers} threads): {real * 1e3:.2f} ms  ({B / real:.1f} images/s)")
+    print(f"train step, PrefetchLoader + device augmentation: {augd * 1e3:.2f} ms  ({B / augd:.1f} images/s)")
 
 
 if __name__ == "__main__":
