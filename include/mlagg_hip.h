@@ -104,7 +104,7 @@ int mlagg_local_attn_fwd(const float *q, int q_stride, const float *kv, int kv_s
                          float *out, int out_stride, int batch, int H, int W, int nh, float scale,
                          void *stream);
 /* Backward: gather form, no atomics on dq/dkv.  `workspace` = mlagg_local_attn_bwd_workspace_floats().
- * dlam / dsubln_w / dlepe_w / dlepe_b are ACCUMULATED into (caller zero-fills). */
+ * dlam / dsubln_w are ACCUMULATED into (caller zero-fills); dlepe_w / dlepe_b are written. */
 size_t mlagg_local_attn_bwd_workspace_floats(int batch, int H, int W, int nh);
 int mlagg_local_attn_bwd(const float *q, int q_stride, const float *kv, int kv_stride,
                          const float *lam, const float *subln_w, const float *lepe_w,
@@ -142,7 +142,7 @@ int mlagg_pooled_attn_bwd(const float *q, int q_stride, const float *kp, int kp_
  * Replaces nn.Conv2d(groups=C) at nnUNetTrainer_MLAgg_2D_dt_MS.py:890 (dwc + SiLU), T:781-782 (LePE of
  * the pooled branch), MambaSkip.py:521-523 (conv2d + SiLU) and M:553 (ConvolutionalGLU.dwconv).
  *   pre: (batch, H*W, C) contiguous pre-activation saved for backward when silu (NULL otherwise /
- *        inference).  Backward ACCUMULATES into dw (C, 9) and dbias (C) (caller zero-fills).
+ *        inference).  Backward WRITES dw (C, 9) and dbias (C) (no zero-fill needed).
  * ------------------------------------------------------------------------------------------ */
 int mlagg_dwconv3x3_fwd(const float *x, int x_stride, const float *w, const float *bias, float *y,
                         int y_stride, float *pre, int batch, int H, int W, int C, int silu, void *stream);

@@ -180,7 +180,8 @@ dwconv_bwd_weight_kernel(const float *__restrict__ x, int x_stride, const float 
     }
 }
 
-// part[rows][C][10] -> dw[C][9] += , dbias[C] += ; workgroup = 64 columns x 16 row-groups
+// part[rows][C][10] -> dw[C][9], dbias[C] (ACC: += into what is there); workgroup = 64 columns x 16 row-groups
+template <bool ACC>
 __global__ void __launch_bounds__(1024)
 dwconv_wgrad_reduce_kernel(const float *__restrict__ part, int rows, int C, float *__restrict__ dw,
                            float *__restrict__ dbias)
@@ -204,8 +205,8 @@ dwconv_wgrad_reduce_kernel(const float *__restrict__ part, int rows, int C, floa
 #pragma unroll
         for (int k = 0; k < 16; ++k) s += red[k][cx];
         const int c = i / 10, j = i - c * 10;
-        if (j < 9) dw[c * 9 + j] += s;
-        else if (dbias) dbias[c] += s;
+        if (j < 9) dw[c * 9 + j] = ACC ? dw[c * 9 + j] + s : s;
+        else if (dbias) dbias[c] = ACC ? dbias[c] + s : s;
     }
 }
 
@@ -228,7 +229,7 @@ size_t dwconv_wgrad_workspace_floats(int batch, int H, int W, int C)
 
 void dwconv_wgrad_launch(const float *x, int x_stride, const float *dy, int dy_stride, const float *pre, float *dw,
                          float *dbias, float *part, int batch, int H, int W, int C, int silu, hipStream_t st,
-                         float *gbuf)
+                         float *gbuf, bool accumulate)
 {
     const int chunks = H;
     const dim3 grid(chunks, (C + 63) / 64, batch);
@@ -240,8 +241,12 @@ void dwconv_wgrad_launch(const float *x, int x_stride, const float *dy, int dy_s
         else
             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<false>, grid, dim3(256), 0, st, x, x_stride, dy, dy_stride, pre,
                                part, gbuf, batch, H, W, C);
-        hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3((C * 10 + 63) / 64), dim3(1024), 0, st, part,
-                           batch * chunks, C, dw, dbias);
+        if (accumulate)
+            hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel<true>, dim3((C * 10 + 63) / 64), dim3(1024), 0, st, part,
+                               batch * chunks, C, dw, dbias);
+        else
+            hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel<false>, dim3((C * 10 + 63) / 64), dim3(1024), 0, st, part,
+                               batch * chunks, C, dw, dbias);
     }
 }
 }  // namespace mlagg_internal

@@ -87,8 +87,8 @@ column_sum_interleaved_kernel(const float *__restrict__ part, int rows, int cols
 }
 
 size_t dwconv_wgrad_workspace_floats(int batch, int H, int W, int C);
-// dw (C, 9) and dbias (C, may be NULL) are ACCUMULATED into; part = workspace of the size above
+// dw (C, 9) and dbias (C, may be NULL) are written (accumulate: added to); part = workspace of the size above
 void dwconv_wgrad_launch(const float *x, int x_stride, const float *dy, int dy_stride, const float *pre, float *dw,
                          float *dbias, float *part, int batch, int H, int W, int C, int silu, hipStream_t st,
-                         float *gbuf = nullptr);
+                         float *gbuf = nullptr, bool accumulate = false);
 }  // namespace mlagg_internal

@@ -212,8 +212,8 @@ class DWConv3x3Fn(torch.autograd.Function):
         B, N, C = x.shape
         dy, dys = _rows(dy, "dy")
         dx = torch.empty(B, N, C, device=x.device, dtype=torch.float32)
-        dw = torch.zeros(C, 9, device=x.device, dtype=torch.float32)
-        db = torch.zeros(C, device=x.device, dtype=torch.float32) if has_bias else None
+        dw = torch.empty(C, 9, device=x.device, dtype=torch.float32)
+        db = torch.empty(C, device=x.device, dtype=torch.float32) if has_bias else None
         lib = _lib.lib()
         ws = torch.empty(lib.mlagg_dwconv3x3_bwd_workspace_floats(B, H, W, C), device=x.device, dtype=torch.float32)
         _lib.check(lib.mlagg_dwconv3x3_bwd(_ptr(x), x.stride(1), _ptr(w), _ptr(dy), dys, _ptr(pre), _ptr(dx), C,
