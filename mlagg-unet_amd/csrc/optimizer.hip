@@ -84,7 +84,9 @@ adamw_update_kernel(const TensorRow *__restrict__ table, const int2 *__restrict_
     float coef = 1.f;
     if (a.max_norm > 0.f) {
         const float norm = (float)sqrt(*sumsq);
-        coef = fminf(a.max_norm / (norm + 1e-6f), 1.f);
+        // a non-finite norm poisons EVERY parameter, as clip_grad_norm_'s NaN coefficient does (fminf(NaN, 1) = 1 would
+        // keep stepping the finite gradients and hide the failure)
+        coef = (norm == norm && norm < __builtin_huge_valf()) ? fminf(a.max_norm / (norm + 1e-6f), 1.f) : __builtin_nanf("");
     }
     float *p = t.p + lo, *m = t.m + lo, *v = t.v + lo;
     const float *g = t.g + lo;

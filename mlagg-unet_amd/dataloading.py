@@ -71,6 +71,9 @@ class DataLoader2D:
         self.need_to_pad = (np.array(patch_size) - np.array(final_patch_size)).astype(int)
         self.oversample = float(oversample_foreground_percent)
         self.annotated_classes_key = tuple(all_labels)
+        flat = [int(v) for lab in all_labels for v in (lab if isinstance(lab, (tuple, list)) else (lab,))]
+        # a larger value in a case file is refused (generate_train_batch); nnU-Net's ignore label is the next integer
+        self.max_label = (max(flat) + int(self.has_ignore)) if flat else None
         self.rng = np.random if rng is None else rng
         data, seg = dataset.arrays(self.indices[0])
         self.channels, self.seg_channels = data.shape[0], seg.shape[0]
@@ -135,6 +138,11 @@ class DataLoader2D:
             h, w = v1[0] - v0[0], v1[1] - v0[1]
             data_all[j, :, o0[0]:o0[0] + h, o0[1]:o0[1] + w] = data[:, sl, v0[0]:v1[0], v0[1]:v1[1]]
             seg_all[j, :, o0[0]:o0[0] + h, o0[1]:o0[1] + w] = seg[:, sl, v0[0]:v1[0], v0[1]:v1[1]]
+        if self.max_label is not None and int(seg_all.max()) > self.max_label:
+            # torch's nll_loss (the reference's CE) fails on a label >= C; the fused loss kernel would quietly count such a
+            # pixel as "no class hit", so a corrupt case is stopped here, on the host, where the check costs nothing
+            raise RuntimeError(f"segmentation label {int(seg_all.max())} > {self.max_label} (largest label of the dataset) "
+                               f"in cases {sorted(set(map(str, keys)))}")
         return {"data": data_t, "seg": seg_t, "keys": keys}
 
 

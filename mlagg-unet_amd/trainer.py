@@ -125,9 +125,13 @@ class ClipAdamW(torch.optim.Optimizer):
 
     def __init__(self, params, lr=5e-4, betas=(0.9, 0.999), eps=1e-4, weight_decay=3e-5):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) != 1:
+            # the clip norm is the norm over ALL parameters (clip_grad_norm_(network.parameters(), 12), B:855): one group
+            raise RuntimeError("ClipAdamW: one parameter group (the reference passes network.parameters(), T:138)")
         self._steps = 0
         self._work = {}
         self._sumsq = None
+        self._stepped = None                          # ids of the parameters of the first step
 
     def _state_of(self, p):
         st = self.state[p]
@@ -146,6 +150,7 @@ class ClipAdamW(torch.optim.Optimizer):
     def load_state_dict(self, sd):
         super().load_state_dict(sd)
         self._work.clear()                            # the moment tensors were replaced: cached addresses are stale
+        self._stepped = None
         steps = [int(st["step"]) for st in self.state.values() if st and "step" in st]
         self._steps = max(steps) if steps else 0
 
@@ -154,6 +159,10 @@ class ClipAdamW(torch.optim.Optimizer):
         from . import _lib
         lib = _lib.lib()
         chunk = lib.mlagg_adamw_chunk_elements()
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         self._steps += 1
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.grad is not None]
@@ -161,6 +170,13 @@ class ClipAdamW(torch.optim.Optimizer):
                 continue
             dev = ps[0].device
             key = tuple(id(p) for p in ps)
+            # ONE step counter serves every parameter (bias correction is a launch argument): right as long as the same
+            # parameters receive a gradient every step, which holds on this path; a changing set would silently give the
+            # late-comers torch.optim.AdamW's step-1 correction at step k, so it is refused
+            if self._stepped is None:
+                self._stepped = key
+            elif key != self._stepped:
+                raise RuntimeError("ClipAdamW: the set of parameters with a gradient changed between steps")
             if key not in self._work:
                 # per parameter set: the work list and the static columns of the pointer table (uploaded once)
                 for p in ps:
@@ -190,7 +206,7 @@ class ClipAdamW(torch.optim.Optimizer):
                                                  float(max_norm), self._steps, torch.cuda.current_stream().cuda_stream),
                        "mlagg_adamw_clip_step")
             self._keepalive = table                   # the table must outlive the asynchronous launches
-        return None
+        return loss
 
     def grad_norm(self):
         """||g||_2 of the last step (device tensor; reading it synchronises)."""

@@ -467,6 +467,60 @@ def test_clip_adamw_matches_torch(max_norm):
 
 
 @gpu
+def test_clip_adamw_checkpoint_round_trip_and_failure_modes():
+    """state_dict after 2 steps loads into a fresh ClipAdamW AND into torch.optim.AdamW (the reference's checkpoint format,
+    nnUNetTrainer.save_checkpoint B:1023-1043); one more step in each lands on the same parameters.  A non-finite gradient
+    poisons every parameter as clip_grad_norm_'s NaN coefficient does; two parameter groups and a changing set of
+    parameters with gradients are refused."""
+    from mlagg_unet_amd import trainer as TR
+    g = torch.Generator().manual_seed(11)
+    shapes = [(5,), (64, 9), (300, 129)]
+
+    def params():
+        gg = torch.Generator().manual_seed(3)
+        return [torch.nn.Parameter(torch.randn(s, generator=gg).to(DEV)) for s in shapes]
+    pa = params()
+    oa = TR.ClipAdamW(pa, 5e-4, eps=1e-4, weight_decay=3e-5)
+    grads = [[torch.randn(s, generator=g).to(DEV) for s in shapes] for _ in range(3)]
+    for it in range(2):
+        for p, gr in zip(pa, grads[it]):
+            p.grad = gr.clone()
+        oa.step(max_norm=12.0)
+    sd = oa.state_dict()
+    pb, pc = [torch.nn.Parameter(p.detach().clone()) for p in pa], [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    ob = TR.ClipAdamW(pb, 5e-4, eps=1e-4, weight_decay=3e-5)
+    oc = torch.optim.AdamW(pc, 5e-4, eps=1e-4, weight_decay=3e-5)
+    ob.load_state_dict(sd)
+    oc.load_state_dict(sd)
+    for ps, opt in ((pa, oa), (pb, ob), (pc, oc)):
+        for p, gr in zip(ps, grads[2]):
+            p.grad = gr.clone()
+        if opt is oc:
+            torch.nn.utils.clip_grad_norm_(pc, 12.0)
+            opt.step()
+        else:
+            opt.step(max_norm=12.0)
+    for x, y, z in zip(pa, pb, pc):
+        assert torch.equal(x, y)                                                  # resumed == uninterrupted, bit for bit
+        assert float((x - z).abs().max()) < 2e-6
+    assert float(ob.state_dict()["state"][0]["step"]) == 3.0 == float(oc.state_dict()["state"][0]["step"])
+    # closure: evaluated, its value returned
+    for p, gr in zip(pa, grads[0]):
+        p.grad = gr.clone()
+    assert oa.step(lambda: 7.5, max_norm=12.0) == 7.5
+    # non-finite gradient norm: every parameter becomes NaN (torch: the clip coefficient is NaN)
+    pa[1].grad[0, 0] = float("nan")
+    oa.step(max_norm=12.0)
+    assert all(bool(torch.isnan(p).all()) for p in pa)
+    # refused configurations
+    with pytest.raises(RuntimeError):
+        TR.ClipAdamW([{"params": pb[:1]}, {"params": pb[1:]}])
+    pb[0].grad = None
+    with pytest.raises(RuntimeError):
+        ob.step(max_norm=12.0)
+
+
+@gpu
 @pytest.mark.parametrize("act", [0, 1])
 @pytest.mark.parametrize("B,C,H,W,with_res,with_bias", [(2, 96, 32, 32, True, True), (3, 7, 5, 9, False, True), (1, 192, 16, 16, True, False)])
 def test_channel_epilogue_matches_torch(act, B, C, H, W, with_res, with_bias):

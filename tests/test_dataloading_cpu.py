@@ -98,3 +98,14 @@ def test_prefetch_loader_on_cpu(tmp_path):
             assert data.shape == (3, 1, 32, 32) and len(targets) == 5 and torch.isfinite(data).all()
     finally:
         pf.close()
+
+
+def test_out_of_range_label_is_refused(tmp_path):
+    """A label above the dataset's largest would make torch's nll_loss fail in the reference; the fused loss kernel has no
+    such check, so the loader refuses the batch."""
+    DO.write_synthetic_dataset(str(tmp_path), unpack=True)
+    dl = DL.DataLoader2D(DL.Dataset(str(tmp_path)), 4, (32, 32), (32, 32), [0, 1, 2], 0.0, rng=np.random.RandomState(0),
+                         pin_memory=False)                      # the files hold label 3
+    with pytest.raises(RuntimeError, match="segmentation label 3 > 2"):
+        for _ in range(20):
+            dl.generate_train_batch()
