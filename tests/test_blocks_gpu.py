@@ -490,8 +490,9 @@ def test_clip_adamw_checkpoint_round_trip_and_failure_modes():
     pb, pc = [torch.nn.Parameter(p.detach().clone()) for p in pa], [torch.nn.Parameter(p.detach().clone()) for p in pa]
     ob = TR.ClipAdamW(pb, 5e-4, eps=1e-4, weight_decay=3e-5)
     oc = torch.optim.AdamW(pc, 5e-4, eps=1e-4, weight_decay=3e-5)
-    ob.load_state_dict(sd)
-    oc.load_state_dict(sd)
+    import copy
+    ob.load_state_dict(copy.deepcopy(sd))        # as after torch.save / torch.load: load_state_dict itself keeps same-device
+    oc.load_state_dict(copy.deepcopy(sd))        # tensors by reference, which would alias the three optimizers' moments
     for ps, opt in ((pa, oa), (pb, ob), (pc, oc)):
         for p, gr in zip(ps, grads[2]):
             p.grad = gr.clone()
