@@ -117,15 +117,28 @@ linear_mfma_kernel(const float *__restrict__ X, const float *__restrict__ W, con
         }
     }
     // epilogue: D[row = (r & 3) + 8 * (r >> 2) + 4 * kh][col]; 128-byte row runs per store instruction
+    // Stores must not sit in per-row `if (m < M)` blocks: each exec-masked block gets an `s_waitcnt vmcnt(0)` in front of its
+    // store from the compiler, and the 48 stores of a tile then complete ONE AFTER THE OTHER (a quarter of the kernel's time
+    // at stage 0).  Rows: a uniform test (every shape of the model has M % 128 == 0); columns: one lane mask around the 16
+    // stores of a column block.
+    const bool rows_full = m0 + BM <= g.M;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int n = n0 + 32 * t + col;
-        if (n >= g.N) continue;
-        const float bv = bias ? bias[n] : 0.f;
+        if (n0 + 32 * t >= g.N) break;
+        const float bv = bias ? bias[min(n, g.N - 1)] : 0.f;
+        float *yp = Y + (size_t)(m0 + 32 * wave + 4 * kh) * g.y_stride + n;
+        if (rows_full) {
+            if (n < g.N) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (m < g.M) Y[(size_t)m * g.y_stride + n] = acc[t][r] + bv;
+                for (int r = 0; r < 16; ++r) yp[(size_t)((r & 3) + 8 * (r >> 2)) * g.y_stride] = acc[t][r] + bv;
+            }
+        } else if (n < g.N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (m < g.M) Y[(size_t)m * g.y_stride + n] = acc[t][r] + bv;
+            }
         }
     }
 }

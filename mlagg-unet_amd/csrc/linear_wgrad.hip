@@ -60,16 +60,30 @@ linear_wgrad_kernel(const float *__restrict__ dy, const float *__restrict__ x, f
     constexpr int UNR = 4;
     int m = m_begin;
     // software pipeline: the operands of the NEXT 4 token pairs are in flight while the 36 MFMAs of the
-    // current 4 pairs issue (a wave alone on its SIMD would otherwise wait out every HBM round trip)
+    // current 4 pairs issue (a wave alone on its SIMD would otherwise wait out every HBM round trip).
+    // The pipelined loads are UNCONDITIONAL: columns beyond O / I read a clamped (valid) column and feed accumulator rows /
+    // columns that are never stored.  With `ok ? *p : 0` every load sat in its own exec-masked block, the compiler could not
+    // count them and put `s_waitcnt vmcnt(0)` in front of each consume -- which waits for the NEXT step's loads too.
+    const float *dyb = dy + (size_t)m_begin * g.dy_stride;             // uniform row base; lane part as a 32-bit byte offset
+    const float *xb = x + (size_t)m_begin * g.x_stride;
+    unsigned offa[TO], offb[TI];
+#pragma unroll
+    for (int a = 0; a < TO; ++a) offa[a] = 4u * (unsigned)(kh * g.dy_stride + min(o0 + 32 * a + col, g.O - 1));
+#pragma unroll
+    for (int b = 0; b < TI; ++b) offb[b] = 4u * (unsigned)(kh * g.x_stride + min(i0 + 32 * b + col, g.I - 1));
     float av[2][UNR][TO], bv[2][UNR][TI];
     auto fetch = [&](float (&A)[UNR][TO], float (&Bv)[UNR][TI]) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
+            const char *da = reinterpret_cast<const char *>(dyb + (size_t)(2 * u) * g.dy_stride);
+            const char *db = reinterpret_cast<const char *>(xb + (size_t)(2 * u) * g.x_stride);
 #pragma unroll
-            for (int a = 0; a < TO; ++a) A[u][a] = ld_or_zero(dyp + (size_t)(2 * u) * g.dy_stride + 32 * a, oko[a]);
+            for (int a = 0; a < TO; ++a) A[u][a] = *reinterpret_cast<const float *>(da + (size_t)offa[a]);
 #pragma unroll
-            for (int b = 0; b < TI; ++b) Bv[u][b] = ld_or_zero(xp + (size_t)(2 * u) * g.x_stride + 32 * b, oki[b]);
+            for (int b = 0; b < TI; ++b) Bv[u][b] = *reinterpret_cast<const float *>(db + (size_t)offb[b]);
         }
+        dyb += (size_t)(2 * UNR) * g.dy_stride;
+        xb += (size_t)(2 * UNR) * g.x_stride;
         dyp += (size_t)(2 * UNR) * g.dy_stride;
         xp += (size_t)(2 * UNR) * g.x_stride;
     };
