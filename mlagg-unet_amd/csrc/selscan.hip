@@ -65,6 +65,13 @@ __device__ __forceinline__ float softplus_f(float x)
     return fmaxf(x, 0.f) + (e < 0.01f ? small : big);
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// Keep a prefetched value where it is: a fake read-modify of the register.  Without it the compiler is free to SINK a load
+// of a `const __restrict__` row down to its use (it did, past barriers), which turns "all loads of the chunk up front" back
+// into one exposed round trip per sub-tile.
+__device__ __forceinline__ void pin4(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+// Workgroup barrier for kernels whose waves talk through LDS only: __syncthreads() also releases GLOBAL memory, i.e. waits
+// (vmcnt(0)) for every store of the sub-tile before the next one may start.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ float dpp_quad_xor1(float v)
 {
@@ -181,8 +188,14 @@ __device__ __forceinline__ LaneId lane_id(const ScanGeom &gm)
 // forward pass 1 (FINAL = false): chunk from zero state -> (end state, sum delta')
 // forward pass 3 (FINAL = true) : chunk from its entry state -> y
 // ------------------------------------------------------------------------------------------
-template <bool FINAL, bool LR>
-__global__ void __launch_bounds__(128) selscan_fwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
+// (launch bounds: at least 4 waves per SIMD, i.e. at most 128 VGPRs -- without the cap the branch-free
+// FAST bodies are scheduled with every LDS read of a sub-tile hoisted: 319 / 512 registers, one wave per SIMD.)
+// FAST: L is a multiple of the 64-step chunk, every group a whole number of 32-channel blocks, 128 threads: every lane is
+// active and every access in range, so all loads and stores are UNCONDITIONAL.  In the generic form each guarded access is
+// its own exec-masked block, the compiler cannot count the loads and drains them (`s_waitcnt vmcnt(0)`) at every join: the
+// "12 float4 in flight" of the prologue completed one after the other, and each store waited for the one before it.
+template <bool FINAL, bool LR, bool FAST>
+__global__ void __launch_bounds__(128, 4) selscan_fwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
                                    const float *__restrict__ Wdt, int R,
                                    const float *__restrict__ A, const float *__restrict__ Bm,
                                    const float *__restrict__ Cm, const float *__restrict__ Dv,
@@ -197,7 +210,8 @@ __global__ void __launch_bounds__(128) selscan_fwd_kernel(const float *__restric
     float *sC = sB + ST * BP;
     float *sR = sC + ST * BP;          // LR: two buffers of RMAX x ST rank rows
 
-    const LaneId id = lane_id(gm);
+    LaneId id = lane_id(gm);
+    if (FAST) id.act = true;
     const int tid = threadIdx.x, L = gm.L;
     const bool vec = (L & 3) == 0;
     const float *urow = u + ((size_t)id.b * gm.dim + id.d) * L;
@@ -210,6 +224,9 @@ __global__ void __launch_bounds__(128) selscan_fwd_kernel(const float *__restric
         bcrow = Bm + (((size_t)id.b * gm.G + id.g) * NS + (tid >> 2)) * L;
     else if (FINAL && tid < 128)
         bcrow = Cm + (((size_t)id.b * gm.G + id.g) * NS + ((tid - 64) >> 2)) * L;
+    // FAST: a valid row for every thread (the second wave of pass 1 re-reads B rows and drops them)
+    const float *bcfast = (FINAL && tid >= 64 ? Cm : Bm) + (((size_t)id.b * gm.G + id.g) * NS + ((tid & 63) >> 2)) * L;
+    const float *rkfast = LR ? drow + (size_t)min(tid >> 2, R - 1) * L : drow;     // rank row of this thread (clamped)
     const float bias = (dbias && id.act) ? dbias[id.d] : 0.f;
     const float Dd = (FINAL && Dv && id.act) ? Dv[id.d] : 0.f;
     const size_t srow = ((size_t)id.b * gm.nchunks + id.chunk) * gm.dim + id.d;
@@ -234,6 +251,13 @@ __global__ void __launch_bounds__(128) selscan_fwd_kernel(const float *__restric
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
         const int t0 = tc0 + sub * ST;
+        if (FAST) {
+            pu[sub] = *reinterpret_cast<const float4 *>(urow + t0 + 4 * id.s);
+            pd[sub] = LR ? *reinterpret_cast<const float4 *>(rkfast + t0 + 4 * (tid & 3))
+                         : *reinterpret_cast<const float4 *>(drow + t0 + 4 * id.s);
+            pbc[sub] = *reinterpret_cast<const float4 *>(bcfast + t0 + 4 * (tid & 3));
+            continue;
+        }
         pu[sub] = pd[sub] = pbc[sub] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (LR) pd[sub] = load_rank_rows(drow, R, tid, t0, L, vec);
         if (id.act) {
@@ -241,6 +265,10 @@ __global__ void __launch_bounds__(128) selscan_fwd_kernel(const float *__restric
             if (!LR) pd[sub] = load4(drow, t0 + 4 * id.s, L, vec);
         }
         if (bcrow) pbc[sub] = load4(bcrow, t0 + 4 * (tid & 3), L, vec);
+    }
+    if (FAST) {
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) { pin4(pu[sub]); pin4(pd[sub]); pin4(pbc[sub]); }
     }
     if (LR) stage_rank_rows(sR, R, tid, pd[0]);       // rank rows run one sub-tile ahead of the barriers below
 
@@ -250,23 +278,24 @@ __global__ void __launch_bounds__(128) selscan_fwd_kernel(const float *__restric
         if (FINAL && sub > 0 && id.act)       // state entering 8-step tile 2 * sub: saved so that backward does not re-sweep the chunk
             *reinterpret_cast<float4 *>(csub + ((srow / gm.dim * NT8 + (2 * sub - 1)) * gm.dim + id.d) * NS + 4 * id.s) =
                 make_float4(h[0], h[1], h[2], h[3]);
-        __syncthreads();
+        lds_barrier();
         if (id.act) {
             *reinterpret_cast<float4 *>(su + id.cl * UP + 4 * id.s) = pu[sub];
             *reinterpret_cast<float4 *>(sd + id.cl * UP + 4 * id.s) =
                 activate_delta(LR ? lowrank_delta(sR + (sub & 1) * RMAX * ST, R, id.s, wdt) : pd[sub], bias, softplus,
-                               t0 + 4 * id.s, L);
+                               FAST ? 0 : t0 + 4 * id.s, FAST ? 4 : L);
         }
         if (LR && sub + 1 < NSUB) stage_rank_rows(sR + ((sub + 1) & 1) * RMAX * ST, R, tid, pd[sub + 1]);
         if (bcrow) {
             float *dst = (tid < 64 ? sB : sC) + (4 * (tid & 3)) * BP + ((tid & 63) >> 2);
             dst[0] = pbc[sub].x; dst[BP] = pbc[sub].y; dst[2 * BP] = pbc[sub].z; dst[3 * BP] = pbc[sub].w;
         }
-        __syncthreads();
+        lds_barrier();
         if (id.act) {
             float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads of a 4-step group with the group (register pressure)
                 if (FINAL && q == 2)            // ... and the state entering the odd 8-step tile 2 * sub + 1
                     *reinterpret_cast<float4 *>(csub + ((srow / gm.dim * NT8 + 2 * sub) * gm.dim + id.d) * NS + 4 * id.s) =
                         make_float4(h[0], h[1], h[2], h[3]);
@@ -293,8 +322,15 @@ __global__ void __launch_bounds__(128) selscan_fwd_kernel(const float *__restric
                 }
                 if (FINAL && id.s == q) yv = make_float4(yq[0], yq[1], yq[2], yq[3]);
             }
-            if (FINAL) store4(out + ((size_t)id.b * gm.dim + id.d) * L, t0 + 4 * id.s, L, vec, yv);
+            if (FINAL) {
+                if (FAST) *reinterpret_cast<float4 *>(out + ((size_t)id.b * gm.dim + id.d) * L + t0 + 4 * id.s) = yv;
+                else store4(out + ((size_t)id.b * gm.dim + id.d) * L, t0 + 4 * id.s, L, vec, yv);
+            }
         }
+        // the sub-tile's recurrence is FINISHED here: without this anchor the branch-free pass-1 body has no side effect
+        // between the barriers, and the compiler parks the LDS reads of all four sub-tiles (in scratch) to run the whole
+        // chain after the last barrier
+        if (FAST) asm volatile("" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(dsum));
     }
     if (!FINAL && id.act) {
         *reinterpret_cast<float4 *>(cstate + srow * NS + 4 * id.s) = make_float4(h[0], h[1], h[2], h[3]);
@@ -346,8 +382,8 @@ __global__ void selscan_chunk_prefix(const float *__restrict__ A, float *__restr
 // chunk end; the value at the chunk start is the affine offset of the chunk (slope is the same
 // exp(A * dsum_c) as forward).
 // ------------------------------------------------------------------------------------------
-template <bool LR>
-__global__ void __launch_bounds__(128) selscan_bwd_local_kernel(const float *__restrict__ delta, const float *__restrict__ Wdt, int R,
+template <bool LR, bool FAST>
+__global__ void __launch_bounds__(128, 4) selscan_bwd_local_kernel(const float *__restrict__ delta, const float *__restrict__ Wdt, int R,
                                          const float *__restrict__ A,
                                          const float *__restrict__ Cm, const float *__restrict__ dbias,
                                          const float *__restrict__ dout, float *__restrict__ cq, ScanGeom gm,
@@ -359,7 +395,8 @@ __global__ void __launch_bounds__(128) selscan_bwd_local_kernel(const float *__r
     float *sC = sd + gm.CB * UP;
     float *sR = sC + ST * BP;          // LR: two buffers of RMAX x ST rank rows
 
-    const LaneId id = lane_id(gm);
+    LaneId id = lane_id(gm);
+    if (FAST) id.act = true;                      // see selscan_fwd_kernel
     const int tid = threadIdx.x, L = gm.L;
     const bool vec = (L & 3) == 0;
     const float *grow = dout + ((size_t)id.b * gm.dim + id.d) * L;
@@ -368,6 +405,8 @@ __global__ void __launch_bounds__(128) selscan_bwd_local_kernel(const float *__r
     if (LR && id.act)
         for (int i = 0; i < R; ++i) wdt[i] = Wdt[(size_t)id.d * R + i];
     const float *crow = tid < 64 ? Cm + (((size_t)id.b * gm.G + id.g) * NS + (tid >> 2)) * L : nullptr;
+    const float *cfast = Cm + (((size_t)id.b * gm.G + id.g) * NS + ((tid & 63) >> 2)) * L;
+    const float *rkfast = LR ? drow + (size_t)min(tid >> 2, R - 1) * L : drow;
     const float bias = (dbias && id.act) ? dbias[id.d] : 0.f;
 
     float A2[4], q[4];
@@ -381,6 +420,13 @@ __global__ void __launch_bounds__(128) selscan_bwd_local_kernel(const float *__r
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
         const int t0 = tc0 + sub * ST;
+        if (FAST) {
+            pg[sub] = *reinterpret_cast<const float4 *>(grow + t0 + 4 * id.s);
+            pd[sub] = LR ? *reinterpret_cast<const float4 *>(rkfast + t0 + 4 * (tid & 3))
+                         : *reinterpret_cast<const float4 *>(drow + t0 + 4 * id.s);
+            pc[sub] = *reinterpret_cast<const float4 *>(cfast + t0 + 4 * (tid & 3));
+            continue;
+        }
         pg[sub] = pd[sub] = pc[sub] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (LR) pd[sub] = load_rank_rows(drow, R, tid, t0, L, vec);
         if (id.act) {
@@ -389,26 +435,31 @@ __global__ void __launch_bounds__(128) selscan_bwd_local_kernel(const float *__r
         }
         if (crow) pc[sub] = load4(crow, t0 + 4 * (tid & 3), L, vec);
     }
+    if (FAST) {
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) { pin4(pg[sub]); pin4(pd[sub]); pin4(pc[sub]); }
+    }
     if (LR) stage_rank_rows(sR + ((NSUB - 1) & 1) * RMAX * ST, R, tid, pd[NSUB - 1]);
 #pragma unroll
     for (int sub = NSUB - 1; sub >= 0; --sub) {
         const int t0 = tc0 + sub * ST;
-        __syncthreads();
+        lds_barrier();
         if (id.act) {
             *reinterpret_cast<float4 *>(sg + id.cl * UP + 4 * id.s) = pg[sub];
             *reinterpret_cast<float4 *>(sd + id.cl * UP + 4 * id.s) =
                 activate_delta(LR ? lowrank_delta(sR + (sub & 1) * RMAX * ST, R, id.s, wdt) : pd[sub], bias, softplus,
-                               t0 + 4 * id.s, L);
+                               FAST ? 0 : t0 + 4 * id.s, FAST ? 4 : L);
         }
         if (LR && sub > 0) stage_rank_rows(sR + ((sub - 1) & 1) * RMAX * ST, R, tid, pd[sub - 1]);
         if (crow) {
             float *dst = sC + (4 * (tid & 3)) * BP + (tid >> 2);
             dst[0] = pc[sub].x; dst[BP] = pc[sub].y; dst[2 * BP] = pc[sub].z; dst[3 * BP] = pc[sub].w;
         }
-        __syncthreads();
+        lds_barrier();
         if (id.act) {
 #pragma unroll
             for (int qq = 3; qq >= 0; --qq) {
+                __builtin_amdgcn_sched_barrier(0);      // as in the forward kernel
                 const float4 dv = *reinterpret_cast<const float4 *>(sd + id.cl * UP + 4 * qq);
                 const float4 gv = *reinterpret_cast<const float4 *>(sg + id.cl * UP + 4 * qq);
 #pragma unroll
@@ -423,6 +474,7 @@ __global__ void __launch_bounds__(128) selscan_bwd_local_kernel(const float *__r
                 }
             }
         }
+        if (FAST) asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));      // see selscan_fwd_kernel
     }
     if (id.act) {
         const size_t srow = ((size_t)id.b * gm.nchunks + id.chunk) * gm.dim + id.d;
@@ -1341,12 +1393,20 @@ int scan_forward(const float *u, const float *delta, const float *Wdt, int R, co
     float *csub = cdsum + (size_t)batch * gm.nchunks * dim;
     const dim3 grid(gm.nchunks, G * gm.nblk, batch), block(block_threads(gm));
     const size_t lds = (size_t)(2 * gm.CB * UP + 2 * ST * BP + (LR ? 2 * RMAX * ST : 0)) * sizeof(float);
-    { MLAGG_TIMED(K_SELSCAN_FWD_LOCAL, st); hipLaunchKernelGGL((selscan_fwd_kernel<false, LR>), grid, block, lds, st, u, delta, Wdt, R, A, B, C, D,
-                       delta_bias, out, cstate, cdsum, csub, gm, delta_softplus); }
+    // every lane active, every access in range (see the kernel): the model's shapes at 256^2
+    const bool fast = L % TC == 0 && gm.Hc % gm.CB == 0 && block.x == 128 && 4 * gm.CB == 128 && (!LR || R >= 1);
+    { MLAGG_TIMED(K_SELSCAN_FWD_LOCAL, st);
+      if (fast) hipLaunchKernelGGL((selscan_fwd_kernel<false, LR, true>), grid, block, lds, st, u, delta, Wdt, R, A, B, C, D,
+                                   delta_bias, out, cstate, cdsum, csub, gm, delta_softplus);
+      else hipLaunchKernelGGL((selscan_fwd_kernel<false, LR, false>), grid, block, lds, st, u, delta, Wdt, R, A, B, C, D,
+                              delta_bias, out, cstate, cdsum, csub, gm, delta_softplus); }
     { MLAGG_TIMED(K_SELSCAN_PREFIX, st); hipLaunchKernelGGL(selscan_chunk_prefix, dim3((dim * NS + 255) / 256, batch), dim3(256), 0, st, A, cstate,
                        cdsum, gm, 0); }
-    { MLAGG_TIMED(K_SELSCAN_FWD_FINAL, st); hipLaunchKernelGGL((selscan_fwd_kernel<true, LR>), grid, block, lds, st, u, delta, Wdt, R, A, B, C, D,
-                       delta_bias, out, cstate, cdsum, csub, gm, delta_softplus); }
+    { MLAGG_TIMED(K_SELSCAN_FWD_FINAL, st);
+      if (fast) hipLaunchKernelGGL((selscan_fwd_kernel<true, LR, true>), grid, block, lds, st, u, delta, Wdt, R, A, B, C, D,
+                                   delta_bias, out, cstate, cdsum, csub, gm, delta_softplus);
+      else hipLaunchKernelGGL((selscan_fwd_kernel<true, LR, false>), grid, block, lds, st, u, delta, Wdt, R, A, B, C, D,
+                              delta_bias, out, cstate, cdsum, csub, gm, delta_softplus); }
     return (int)hipGetLastError();
 }
 
@@ -1383,8 +1443,12 @@ int scan_backward(const float *u, const float *delta, const float *Wdt, int R, c
         if (LR) (void)hipMemsetAsync(ddelta, 0, (size_t)batch * G * R * L * sizeof(float), st);
     }
     const size_t lds1 = (size_t)(2 * gm.CB * UP + ST * BP + (LR ? 2 * RMAX * ST : 0)) * sizeof(float);
-    { MLAGG_TIMED(K_SELSCAN_BWD_LOCAL, st); hipLaunchKernelGGL(selscan_bwd_local_kernel<LR>, grid, block, lds1, st, delta, Wdt, R, A, C, delta_bias,
-                       dout, cq, gm, delta_softplus); }
+    const bool fast = L % TC == 0 && gm.Hc % gm.CB == 0 && block.x == 128 && 4 * gm.CB == 128 && (!LR || R >= 1);
+    { MLAGG_TIMED(K_SELSCAN_BWD_LOCAL, st);
+      if (fast) hipLaunchKernelGGL((selscan_bwd_local_kernel<LR, true>), grid, block, lds1, st, delta, Wdt, R, A, C, delta_bias,
+                                   dout, cq, gm, delta_softplus);
+      else hipLaunchKernelGGL((selscan_bwd_local_kernel<LR, false>), grid, block, lds1, st, delta, Wdt, R, A, C, delta_bias,
+                              dout, cq, gm, delta_softplus); }
     { MLAGG_TIMED(K_SELSCAN_PREFIX, st); hipLaunchKernelGGL(selscan_chunk_prefix, dim3((dim * NS + 255) / 256, batch), dim3(256), 0, st, A, cq, cdsum,
                        gm, 1); }
     if (group_form) {
