@@ -29,6 +29,7 @@ constexpr int TS = 16;                 // tile side (tokens)
 constexpr int CH = 32;                 // channels per workgroup
 constexpr int LP = 33;                 // LDS channel pitch
 constexpr int ROWP = TS + 1;           // LDS tile row pitch (tokens): both traversal orders conflict-free
+constexpr int UN = 8;                  // token loads in flight per thread
 
 struct XGeom {
     int B, Lc, nscale;
@@ -73,11 +74,26 @@ cross_scan_kernel(const float *__restrict__ tok_c, float *__restrict__ tok_m, co
         for (int k = 0; k < 4; ++k) {
             if (k == 0 || g.nblk > 1) {                 // (re)load the source block of this direction
                 __syncthreads();
-                for (int e = tid; e < TS * TS * CH; e += 256) {
-                    const int c = e & (CH - 1), t = e >> 5, ly = t >> 4, lx = t & 15;
-                    float v = 0.f;
-                    if (c < nc && y0 + ly < H && x0 + lx < W) v = tok_c[tok_ptr(ly, lx, g.nblk > 1 ? k : 0, c)];
-                    tile[lds_idx(ly, lx, c)] = v;
+                // UN loads in flight per thread, all unconditional (clamped to the tile's first element, value dropped): a
+                // guarded load per iteration is waited for before the next one is issued, i.e. ONE 4-byte load in flight
+                // per lane -- the kernel then runs at the memory latency, not the bandwidth
+                const size_t safe = tok_ptr(0, 0, g.nblk > 1 ? k : 0, 0);
+                for (int e0 = tid; e0 < TS * TS * CH; e0 += 256 * UN) {
+                    float v[UN];
+#pragma unroll
+                    for (int u = 0; u < UN; ++u) {
+                        const int e = e0 + 256 * u;
+                        const int c = e & (CH - 1), t = e >> 5, ly = t >> 4, lx = t & 15;
+                        const bool ok = c < nc && y0 + ly < H && x0 + lx < W;
+                        v[u] = tok_c[ok ? tok_ptr(ly, lx, g.nblk > 1 ? k : 0, c) : safe];
+                    }
+#pragma unroll
+                    for (int u = 0; u < UN; ++u) {
+                        const int e = e0 + 256 * u;
+                        const int c = e & (CH - 1), t = e >> 5, ly = t >> 4, lx = t & 15;
+                        const bool ok = c < nc && y0 + ly < H && x0 + lx < W;
+                        tile[lds_idx(ly, lx, c)] = ok ? v[u] : 0.f;
+                    }
                 }
                 __syncthreads();
             }
@@ -113,22 +129,30 @@ cross_scan_kernel(const float *__restrict__ tok_c, float *__restrict__ tok_m, co
             const bool fresh = (k == 0 || g.nblk > 1);
             __syncthreads();
             if (vec4) {
-                for (int e = tid; e < TS * (TS / 4) * CH; e += 256) {
+                // the 8 float4 of a thread for this direction in flight together (see the scatter branch)
+                constexpr int NV = TS * (TS / 4) * CH / 256;
+                float4 r[NV];
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const int e = tid + 256 * u;
                     const int q = e & 63, c = e >> 6;
                     const int a = q >> 2, f4 = (q & 3) * 4;
                     const int ly0 = (k & 1) ? f4 : a, lx0 = (k & 1) ? a : f4;
-                    float v[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (c < nc && y0 + ly0 < H && x0 + lx0 < W) {
-                        const int pf = (k & 1) ? (x0 + lx0) * H + y0 + ly0 : (y0 + ly0) * W + x0 + lx0;
-                        const float *src = seq_c + ((size_t)b * 4 * g.CB + (size_t)k * g.CB + c0 + c) * g.Lc + off;
-                        if (k & 2) {
-                            const float4 r = *reinterpret_cast<const float4 *>(src + (H * W - 4 - pf));
-                            v[0] = r.w; v[1] = r.z; v[2] = r.y; v[3] = r.x;
-                        } else {
-                            const float4 r = *reinterpret_cast<const float4 *>(src + pf);
-                            v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
-                        }
-                    }
+                    const bool ok = c < nc && y0 + ly0 < H && x0 + lx0 < W;
+                    const int pf = (k & 1) ? (x0 + lx0) * H + y0 + ly0 : (y0 + ly0) * W + x0 + lx0;
+                    const float *src = seq_c + ((size_t)b * 4 * g.CB + (size_t)k * g.CB + c0 + (ok ? c : 0)) * g.Lc + off;
+                    const int pos = ok ? ((k & 2) ? H * W - 4 - pf : pf) : 0;
+                    r[u] = *reinterpret_cast<const float4 *>(src + pos);
+                }
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const int e = tid + 256 * u;
+                    const int q = e & 63, c = e >> 6;
+                    const int a = q >> 2, f4 = (q & 3) * 4;
+                    const int ly0 = (k & 1) ? f4 : a, lx0 = (k & 1) ? a : f4;
+                    const bool ok = c < nc && y0 + ly0 < H && x0 + lx0 < W;
+                    const float v[4] = {ok ? ((k & 2) ? r[u].w : r[u].x) : 0.f, ok ? ((k & 2) ? r[u].z : r[u].y) : 0.f,
+                                        ok ? ((k & 2) ? r[u].y : r[u].z) : 0.f, ok ? ((k & 2) ? r[u].x : r[u].w) : 0.f};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int li = lds_idx((k & 1) ? ly0 + j : ly0, (k & 1) ? lx0 : lx0 + j, c);
