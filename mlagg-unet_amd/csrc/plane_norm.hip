@@ -89,7 +89,10 @@ plane_norm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gam
 }
 
 // g = dy * act'(pre);  dx = rstd * gamma * (g - mean(g) - xhat * mean(g * xhat));  partials: sum g * xhat, sum g
-template <bool VEC>
+// RES as a template flag and 4 float4 groups per loop trip: with `rp ? load : 0` inside a rolled loop every trip had one or
+// two loads in flight per lane and a wait between x / dy and the residual; planes are few (B * C workgroups), so the loop
+// itself has to provide the memory-level parallelism.
+template <bool VEC, bool RES>
 __global__ void __launch_bounds__(256)
 plane_norm_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ gamma,
                       const float *__restrict__ beta, const float *__restrict__ res, const float *__restrict__ stats,
@@ -112,9 +115,28 @@ plane_norm_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy,
         return act == ACT_NONE ? gv : gv * act_bwd(xh * ga + be + rv, act, slope);
     };
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long i = threadIdx.x; i < n4; i += 256) {
+    constexpr int UN = 4;
+    long i0 = threadIdx.x;
+    for (; i0 + 256 * (UN - 1) < n4; i0 += 256 * UN) {
+        float4 a[UN], g4[UN], r[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            a[u] = reinterpret_cast<const float4 *>(xp)[i0 + 256 * u];
+            g4[u] = reinterpret_cast<const float4 *>(gp)[i0 + 256 * u];
+            r[u] = RES ? reinterpret_cast<const float4 *>(rp)[i0 + 256 * u] : z4;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            float xh;
+            float t = term(a[u].x, g4[u].x, r[u].x, xh); s1 += t; s2 += t * xh;
+            t = term(a[u].y, g4[u].y, r[u].y, xh); s1 += t; s2 += t * xh;
+            t = term(a[u].z, g4[u].z, r[u].z, xh); s1 += t; s2 += t * xh;
+            t = term(a[u].w, g4[u].w, r[u].w, xh); s1 += t; s2 += t * xh;
+        }
+    }
+    for (long i = i0; i < n4; i += 256) {
         const float4 a = reinterpret_cast<const float4 *>(xp)[i], g4 = reinterpret_cast<const float4 *>(gp)[i];
-        const float4 r = rp ? reinterpret_cast<const float4 *>(rp)[i] : z4;
+        const float4 r = RES ? reinterpret_cast<const float4 *>(rp)[i] : z4;
         float xh;
         float t = term(a.x, g4.x, r.x, xh); s1 += t; s2 += t * xh;
         t = term(a.y, g4.y, r.y, xh); s1 += t; s2 += t * xh;
@@ -123,14 +145,12 @@ plane_norm_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy,
     }
     for (long i = 4 * n4 + threadIdx.x; i < HW; i += 256) {
         float xh;
-        const float t = term(xp[i], gp[i], rp ? rp[i] : 0.f, xh);
+        const float t = term(xp[i], gp[i], RES ? rp[i] : 0.f, xh);
         s1 += t; s2 += t * xh;
     }
     const float S1 = block_sum(s1, red), S2 = block_sum(s2, red);
     const float m1 = S1 / (float)HW, m2 = S2 / (float)HW, k = rstd * ga;
-    for (long i = threadIdx.x; i < n4; i += 256) {
-        const float4 a = reinterpret_cast<const float4 *>(xp)[i], g4 = reinterpret_cast<const float4 *>(gp)[i];
-        const float4 r = rp ? reinterpret_cast<const float4 *>(rp)[i] : z4;
+    auto finish = [&](long i, const float4 &a, const float4 &g4, const float4 &r) {
         float xh;
         float4 o, tr;
         float t = term(a.x, g4.x, r.x, xh); o.x = k * (t - m1 - xh * m2); tr.x = t;
@@ -138,13 +158,28 @@ plane_norm_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy,
         t = term(a.z, g4.z, r.z, xh); o.z = k * (t - m1 - xh * m2); tr.z = t;
         t = term(a.w, g4.w, r.w, xh); o.w = k * (t - m1 - xh * m2); tr.w = t;
         reinterpret_cast<float4 *>(dp)[i] = o;
-        if (drp) reinterpret_cast<float4 *>(drp)[i] = tr;          // gradient of the residual input
+        if (RES && drp) reinterpret_cast<float4 *>(drp)[i] = tr;   // gradient of the residual input (optional)
+    };
+    i0 = threadIdx.x;
+    for (; i0 + 256 * (UN - 1) < n4; i0 += 256 * UN) {
+        float4 a[UN], g4[UN], r[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            a[u] = reinterpret_cast<const float4 *>(xp)[i0 + 256 * u];
+            g4[u] = reinterpret_cast<const float4 *>(gp)[i0 + 256 * u];
+            r[u] = RES ? reinterpret_cast<const float4 *>(rp)[i0 + 256 * u] : z4;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) finish(i0 + 256 * u, a[u], g4[u], r[u]);
     }
+    for (long i = i0; i < n4; i += 256)
+        finish(i, reinterpret_cast<const float4 *>(xp)[i], reinterpret_cast<const float4 *>(gp)[i],
+               RES ? reinterpret_cast<const float4 *>(rp)[i] : z4);
     for (long i = 4 * n4 + threadIdx.x; i < HW; i += 256) {
         float xh;
-        const float t = term(xp[i], gp[i], rp ? rp[i] : 0.f, xh);
+        const float t = term(xp[i], gp[i], RES ? rp[i] : 0.f, xh);
         dp[i] = k * (t - m1 - xh * m2);
-        if (drp) drp[i] = t;
+        if (RES && drp) drp[i] = t;
     }
     if (threadIdx.x == 0 && part) { part[2 * plane] = S2; part[2 * plane + 1] = S1; }     // d(gamma), d(beta) of this plane
 }
@@ -249,8 +284,14 @@ extern "C" int mlagg_plane_norm_bwd(const float *x, const float *dy, const float
     float *part = (dgamma || dbeta) ? workspace : nullptr;
     {
         MLAGG_TIMED(K_PLANE_NORM_BWD, st);
-        if (vec) hipLaunchKernelGGL(plane_norm_bwd_kernel<true>, dim3(B * C), dim3(256), 0, st, x, dy, gamma, beta, res, stats, dx, dres, part, C, HW, act, slope);
-        else hipLaunchKernelGGL(plane_norm_bwd_kernel<false>, dim3(B * C), dim3(256), 0, st, x, dy, gamma, beta, res, stats, dx, dres, part, C, HW, act, slope);
+#define MLAGG_PN_BWD(VEC, RES) hipLaunchKernelGGL((plane_norm_bwd_kernel<VEC, RES>), dim3(B * C), dim3(256), 0, st, x, dy, gamma, beta, res, stats, dx, \
+                                                  dres, part, C, HW, act, slope)
+        const bool with_res = res != nullptr;
+        if (vec && with_res) MLAGG_PN_BWD(true, true);
+        else if (vec) MLAGG_PN_BWD(true, false);
+        else if (with_res) MLAGG_PN_BWD(false, true);
+        else MLAGG_PN_BWD(false, false);
+#undef MLAGG_PN_BWD
     }
     if (part)           // partials are a (B) x (2C) matrix [c][dgamma | dbeta] interleaved: columns 2c, 2c+1
         hipLaunchKernelGGL(mlagg_internal::column_sum_interleaved_kernel<0>, dim3((2 * C + 63) / 64), dim3(1024), 0, st, part, B,
