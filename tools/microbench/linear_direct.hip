@@ -72,18 +72,26 @@ linear_direct_kernel(const float *__restrict__ X, const float *__restrict__ W, c
         mma(a1, b1);
     }
     if (k < K) mma(a0, b0);                 // odd number of k8 steps
+    const bool full = m0 + 32 * TM <= M && n0 + 32 * TN <= N;      // uniform: unconditional stores (see K5's epilogue)
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int n = n0 + 32 * b + col;
-        if (n >= N) continue;
-        const float bv = bias ? bias[n] : 0.f;
+        if (n0 + 32 * b >= N) break;
+        const float bv = bias ? bias[min(n, N - 1)] : 0.f;
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+        for (int a = 0; a < TM; ++a) {
+            if (full) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (m < M) Y[(size_t)m * ys + n] = acc[a][b][r] + bv;
+                for (int r = 0; r < 16; ++r)
+                    Y[(size_t)(m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh) * ys + n] = acc[a][b][r] + bv;
+            } else if (n < N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (m < M) Y[(size_t)m * ys + n] = acc[a][b][r] + bv;
+                }
             }
+        }
     }
 }
 
@@ -154,18 +162,26 @@ linear_persistent_kernel(const float *__restrict__ X, const float *__restrict__ 
             else if (t + nw < ntiles) { point(t + nw); load(a0, b0, 0); }
             mma(a1, b1);
         }
+        const bool full = m0 + 32 * TM <= M && n0 + 32 * TN <= N;
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int n = n0 + 32 * b + col;
-            if (n >= N) continue;
-            const float bv = bias ? bias[n] : 0.f;
+            if (n0 + 32 * b >= N) break;
+            const float bv = bias ? bias[min(n, N - 1)] : 0.f;
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
+            for (int a = 0; a < TM; ++a) {
+                if (full) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    if (m < M) Y[(size_t)m * ys + n] = acc[a][b][r] + bv;
+                    for (int r = 0; r < 16; ++r)
+                        Y[(size_t)(m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh) * ys + n] = acc[a][b][r] + bv;
+                } else if (n < N) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        if (m < M) Y[(size_t)m * ys + n] = acc[a][b][r] + bv;
+                    }
                 }
+            }
         }
     }
 }
@@ -182,6 +198,94 @@ float run_persistent(const float *X, const float *W, const float *b, float *Y, i
     CHECK(hipEventRecord(e0));
     for (int i = 0; i < iters; ++i)
         hipLaunchKernelGGL((linear_persistent_kernel<TM, TN, WAVES, OCC, MFMA_ONLY>), grid, dim3(64 * WAVES), 0, 0, X, W, b, Y, M, N, K, K, K, N);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters * 1e3f;
+}
+
+// Column blocks one after the other: the wave owns (32 TM) rows x (32 TN) columns but computes ONE 32-column block at a
+// time (TM accumulators), so the stores of block b drain while the MFMAs of block b + 1 run -- the store burst of a tile is
+// TN times shorter and overlaps compute inside the wave (x is re-read TN times, from L1 / L2).
+template <int TM, int TN, int OCC>
+__global__ void __launch_bounds__(64, OCC)
+linear_seq_kernel(const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias,
+                  float *__restrict__ Y, int M, int N, int K, int xs, int ws, int ys)
+{
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 31, kh = lane >> 5;
+    const int m0 = blockIdx.x * 32 * TM, n0 = blockIdx.y * 32 * TN;
+    if (m0 >= M) return;
+    const float *ap[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) ap[a] = X + (size_t)min(m0 + 32 * a + col, M - 1) * xs + 4 * kh;
+    const bool full = m0 + 32 * TM <= M && n0 + 32 * TN <= N;
+#pragma unroll 1
+    for (int b = 0; b < TN; ++b) {
+        if (n0 + 32 * b >= N) break;
+        const int n = n0 + 32 * b + col;
+        const float *bp = W + (size_t)min(n, N - 1) * ws + 4 * kh;
+        f32x16 acc[TM];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+        float4 a0[TM], a1[TM], b0, b1;
+        auto load = [&](float4 (&ra)[TM], float4 &rb, int k) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) ra[a] = *reinterpret_cast<const float4 *>(ap[a] + k);
+            rb = *reinterpret_cast<const float4 *>(bp + k);
+        };
+        auto mma = [&](const float4 (&ra)[TM], const float4 &rb) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const float av = j == 0 ? ra[a].x : (j == 1 ? ra[a].y : (j == 2 ? ra[a].z : ra[a].w));
+                    const float bv = j == 0 ? rb.x : (j == 1 ? rb.y : (j == 2 ? rb.z : rb.w));
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a], 0, 0, 0);
+                }
+        };
+        load(a0, b0, 0);
+        int k = 0;
+        for (; k + 16 <= K; k += 16) {
+            load(a1, b1, k + 8);
+            mma(a0, b0);
+            if (k + 16 < K) load(a0, b0, k + 16);
+            mma(a1, b1);
+        }
+        if (k < K) mma(a0, b0);
+        const float bv = bias ? bias[min(n, N - 1)] : 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            if (full) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Y[(size_t)(m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh) * ys + n] = acc[a][r] + bv;
+            } else if (n < N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (m < M) Y[(size_t)m * ys + n] = acc[a][r] + bv;
+                }
+            }
+        }
+    }
+}
+
+template <int TM, int TN, int OCC>
+float run_seq(const float *X, const float *W, const float *b, float *Y, int M, int N, int K, int iters)
+{
+    const dim3 grid((M + 32 * TM - 1) / (32 * TM), (N + 32 * TN - 1) / (32 * TN));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i)
+        hipLaunchKernelGGL((linear_seq_kernel<TM, TN, OCC>), grid, dim3(64), 0, 0, X, W, b, Y, M, N, K, K, K, N);
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i)
+        hipLaunchKernelGGL((linear_seq_kernel<TM, TN, OCC>), grid, dim3(64), 0, 0, X, W, b, Y, M, N, K, K, K, N);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms;
@@ -251,6 +355,17 @@ int main()
         t[3] = run<1, 3, 4, 4>(X, W, b, Y, M, N, K, 20);
         t[4] = run<2, 2, 4, 3>(X, W, b, Y, M, N, K, 20);
         t[5] = run<4, 3, 2, 1>(X, W, b, Y, M, N, K, 20);
+        {
+            const float q0 = run_seq<4, 3, 2>(X, W, b, Y, M, N, K, 20);
+            CHECK(hipMemcpy(y.data(), Y, y.size() * 4, hipMemcpyDeviceToHost));
+            double md3 = 0;
+            for (size_t i = 0; i < y.size(); i += 97) md3 = fmax(md3, fabs((double)y[i] - yr[i]));
+            const float q1 = run_seq<4, 3, 3>(X, W, b, Y, M, N, K, 20);
+            const float q2 = run_seq<2, 3, 4>(X, W, b, Y, M, N, K, 20);
+            const float q3 = run_seq<4, 6, 2>(X, W, b, Y, M, N, K, 20);
+            const float q4 = run_seq<2, 6, 4>(X, W, b, Y, M, N, K, 20);
+            printf("   column-sequential 4x3 occ2 %6.1f us (maxdiff %.2e) | 4x3 occ3 %6.1f | 2x3 occ4 %6.1f | 4x6 occ2 %6.1f | 2x6 occ4 %6.1f\n", q0, md3, q1, q2, q3, q4);
+        }
         if (K % 16 == 0) {
             const float p0 = run_persistent<2, 3, 1, 2, false>(X, W, b, Y, M, N, K, 20);
             CHECK(hipMemcpy(y.data(), Y, y.size() * 4, hipMemcpyDeviceToHost));
