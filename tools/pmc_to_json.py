@@ -22,13 +22,27 @@ LIB_NAMES = {"selscan_fwd_kernel<false, true>": "selscan_fwd_kernel<false>", "se
              "selscan_bwd_group_kernel": "selscan_bwd_kernel"}     # round 2: the group-per-wave form serves the same entry point
 
 
+def lib_name(base, targs):
+    """rocprof's kernel name -> the library's profile name (bench.py's keys): the scan kernels keep only the template
+    argument that distinguishes passes (forward: FINAL), every other template argument is a shape specialisation."""
+    args = [a.strip() for a in targs.strip("<>").split(",")] if targs else []
+    if base == "selscan_fwd_kernel":
+        return f"selscan_fwd_kernel<{args[0]}>" if args else base
+    if base in ("selscan_bwd_local_kernel", "selscan_bwd_kernel"):
+        return base
+    if base == "selscan_bwd_group_kernel":
+        return "selscan_bwd_kernel"                       # round 2: the group-per-wave form serves the same entry point
+    name = base + (targs or "")
+    return LIB_NAMES.get(name, name)
+
+
 def load(d):
     out = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            m = re.search(r"([a-z_0-9]+_kernel(?:<(?:true|false|\d+)(?:, ?(?:true|false|\d+))?>)?|selscan_[a-z_]+)", r["Kernel_Name"])
+            m = re.search(r"([a-z_0-9]+_kernel)(<[^>]*>)?|(selscan_[a-z_]+)", r["Kernel_Name"])
             if m:
-                out[LIB_NAMES.get(m.group(1), m.group(1))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                out[lib_name(m.group(1) or m.group(3), m.group(2) or "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return out
 
 
