@@ -16,6 +16,8 @@
 // Roofline: HBM-bound, algorithmic bytes 4 * M * (O + I) per launch (dy and x read once).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "mlagg_hip.h"
 #include "prof.h"
 
@@ -192,8 +194,12 @@ int make_geom(WGeom &g, int M, int O, int I, int dys, int xs)
     g.M = M; g.O = O; g.I = I; g.dy_stride = dys; g.x_stride = xs;
     g.ogroups = (O + TMAX * 32 - 1) / (TMAX * 32);
     g.igroups = (I + TMAX * 32 - 1) / (TMAX * 32);
-    // ~2 waves per SIMD (1024 SIMDs); slabs of an even number of tokens, at least 64
-    int slab = (int)(((long long)M * g.ogroups * g.igroups + 2047) / 2048);
+    // slabs of an even number of tokens, at least 64
+    // token slabs: ONE wave per SIMD (1024).  Round 1 ran ~2 per SIMD to hide the operand latency; with the pipelined loads
+    // really in flight (see the kernel) one wave does, and half as many partial blocks are written and reduced: 1207 -> 1098 us
+    // over the 15 shapes of tools/bench_linear.py (512: 1603, 1536: 1345 -- uneven -- 4096: 1522).  MLAGG_K5W_WAVES overrides.
+    static const int target = [] { const char *e = getenv("MLAGG_K5W_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+    int slab = (int)(((long long)M * g.ogroups * g.igroups + target - 1) / target);
     slab = ((slab + 7) / 8) * 8;
     if (slab < 64) slab = 64;
     g.slab = slab;
