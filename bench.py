@@ -149,7 +149,12 @@ def main():
 
     _lib.lib()                                              # fail loudly if the HIP library is missing
     # The reference sets cudnn.benchmark=True (run_training.py:123-125); here: the committed result of that search
-    miopen_db = miopen_tuning.use_tuned_convolutions(enabled=args.config == 2 and cfg["precision"] == "fp32")
+    # the committed find-db covers the fp32 convolutions of config 2; the other configurations run MIOpen's immediate-mode
+    # choice.  MLAGG_BENCH_MIOPEN=find lets MIOpen search at first use instead -- measured on config 3: more than 7 minutes of
+    # solver compilation before the first step finishes, so it is not the default; =off forces immediate mode everywhere
+    mode = os.environ.get("MLAGG_BENCH_MIOPEN", "auto")
+    miopen_db = miopen_tuning.use_tuned_convolutions(
+        enabled=(mode == "find") or (mode == "auto" and args.config == 2 and cfg["precision"] == "fp32"))
     torch.manual_seed(0)
     net = model.build_network_architecture(IMG, cfg["in_ch"], N_CLASSES, True, cfg["variant"], cfg["precision"]).to(dev).train()
     use_graph = args.graph and not ddp and not args.no_graph and cfg["precision"] == "fp32"
