@@ -45,12 +45,13 @@ def lp(t, dtype):
     return t if (t is None or dtype == torch.float32) else t.to(dtype)
 
 
-# Library convolutions in 16-bit mode.  Off by default: the maps are fp32 in HBM, so a 16-bit MIOpen convolution needs a
-# cast kernel on its input and another on its output (and again in backward); measured at 224 x 224, batch 10, bf16:
-# convolutions 8.9 ms + 3.5 ms of casts against ~10.4 ms for the fp32 convolutions.  MLAGG_LP_CONV=1 (or setting this
-# flag) rounds the convolution operands too, i.e. the literal operand rounding of the reference's autocast step.
+# Library convolutions in 16-bit mode: ON by default -- the literal operand rounding of the reference's autocast step.  The
+# maps are fp32 in HBM, so a 16-bit MIOpen convolution costs a cast kernel on its input and another on its output (and again
+# in backward), but the 16-bit convolutions themselves are so much faster that the step gains: config 3 (224 x 224, bf16)
+# 42.2 -> 34.7 ms, config 5 (512 x 640, fp16) 98.0 -> 82.9 ms.  (Early in round 2, before the fused conv epilogues, the casts
+# still outweighed the gain.)  MLAGG_LP_CONV=0 keeps the convolutions in fp32.
 import os as _os
-LP_CONV = _os.environ.get("MLAGG_LP_CONV", "0") == "1"
+LP_CONV = _os.environ.get("MLAGG_LP_CONV", "1") == "1"
 
 
 def conv_dtype():

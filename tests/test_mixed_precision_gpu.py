@@ -79,16 +79,23 @@ def _compare(out, loss, norms, g, logit_tol, loss_tol, grad_rtol):
     return worst_logit
 
 
-def test_bf16_config_matches_reference_fp32_and_autocast_goldens():
-    """BASELINE configs[2] shape (224 x 224, 4 classes, variant B) in bf16 mode."""
+@pytest.mark.parametrize("lp_conv", [True, False], ids=["conv16", "conv32"])
+def test_bf16_config_matches_reference_fp32_and_autocast_goldens(lp_conv, monkeypatch):
+    """BASELINE configs[2] shape (224 x 224, 4 classes, variant B) in bf16 mode; library convolutions on 16-bit operands (the
+    default, what autocast does) and in fp32."""
+    from mlagg_unet_amd import ops
+    monkeypatch.setattr(ops, "LP_CONV", lp_conv)
     out, loss, norms = _run("224_variantB", "bf16")
     a = _compare(out, loss, norms, np.load(os.path.join(GOLD, "full_model_224_variantB.npz")), 0.8, 5e-3, 0.05)
     b = _compare(out, loss, norms, np.load(os.path.join(GOLD, "full_model_224_variantB_bf16.npz")), 1.3, 5e-3, 0.10)
     print("bf16 224: max |logit - fp32 reference|", a, " max |logit - bf16-autocast reference|", b)
 
 
-def test_fp16_flash_config_matches_reference_goldens():
+@pytest.mark.parametrize("lp_conv", [True, False], ids=["conv16", "conv32"])
+def test_fp16_flash_config_matches_reference_goldens(lp_conv, monkeypatch):
     """BASELINE configs[4] shape (512 x 640 RGB, 8 classes, variant A = the shipped flash scaling) in fp16 mode."""
+    from mlagg_unet_amd import ops
+    monkeypatch.setattr(ops, "LP_CONV", lp_conv)
     out, loss, norms = _run("512x640_variantA", "fp16")
     a = _compare(out, loss, norms, np.load(os.path.join(GOLD, "full_model_512x640_variantA.npz")), 0.085, 2e-3, 0.05)
     b = _compare(out, loss, norms, np.load(os.path.join(GOLD, "full_model_512x640_variantA_fp16.npz")), 0.14, 0.08, 0.10)
@@ -98,7 +105,7 @@ def test_fp16_flash_config_matches_reference_goldens():
 @pytest.mark.parametrize("precision,lp_conv", [("bf16", False), ("fp16", False), ("bf16", True), ("fp16", True)])
 def test_mixed_precision_train_steps_fit_a_batch(precision, lp_conv, monkeypatch):
     """Five optimisation steps on one batch (fp16: through the GradScaler branch of the reference step, B:853-858), with
-    the library convolutions in fp32 (default) and with their operands rounded to 16 bits too (ops.LP_CONV)."""
+    the library convolutions on 16-bit operands (default, ops.LP_CONV) and in fp32."""
     from mlagg_unet_amd import model as PM, ops, trainer as TR
     monkeypatch.setattr(ops, "LP_CONV", lp_conv)
     torch.manual_seed(0)
