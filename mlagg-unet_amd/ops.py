@@ -363,6 +363,8 @@ def pooled_diff_attn(q, k_pool, v_pool, lam, subln_w, nh, scale):
 
 
 WGRAD_MIN_ROWS = 8192      # below this many tokens the library GEMM is no longer the split-K corner case
+K5_MIN_ROWS = int(_os.environ.get("MLAGG_K5_MIN_ROWS", "16384"))     # fp32 forward / dx: K5 from this many tokens on (at 10240 tokens the
+#                            library's split-K kernels win: 80-320 K5 workgroups do not fill 256 CUs evenly; A/B on the step: +0.9 %)
 
 
 def _rows2d(t, name):
@@ -395,7 +397,7 @@ class LinearFn(torch.autograd.Function):
         ctx.cdt = cdt = compute_dtype()
         O, I = weight.shape
         M = x.numel() // I
-        if M >= WGRAD_MIN_ROWS and I % 4 == 0 and x.is_cuda:
+        if M >= (K5_MIN_ROWS if cdt == torch.float32 else WGRAD_MIN_ROWS) and I % 4 == 0 and x.is_cuda:
             x2, xs = _mfma_rows(x, "x")
             w = _require(weight.contiguous(), "weight")
             y = torch.empty(x.shape[:-1] + (O,), device=x.device, dtype=torch.float32)
@@ -421,7 +423,7 @@ class LinearFn(torch.autograd.Function):
         big = M >= WGRAD_MIN_ROWS
         lib = _lib.lib()
         if ctx.needs_input_grad[0]:
-            if big and O % 4 == 0 and I % 4 == 0:
+            if big and (M >= K5_MIN_ROWS or cdt != torch.float32) and O % 4 == 0 and I % 4 == 0:
                 w = _require(weight.contiguous(), "weight")
                 dx = torch.empty(x.shape, device=dy.device, dtype=torch.float32)
                 if cdt == torch.float32:
