@@ -190,8 +190,8 @@ __device__ __forceinline__ LaneId lane_id(const ScanGeom &gm)
 // ------------------------------------------------------------------------------------------
 // (launch bounds: at least 4 waves per SIMD, i.e. at most 128 VGPRs -- without the cap the branch-free
 // FAST bodies are scheduled with every LDS read of a sub-tile hoisted: 319 / 512 registers, one wave per SIMD.)
-// FAST: L is a multiple of the 64-step chunk, every group a whole number of 32-channel blocks, 128 threads: every lane is
-// active and every access in range, so all loads and stores are UNCONDITIONAL.  In the generic form each guarded access is
+// FAST: L % 4 == 0, every group a whole number of 32-channel blocks, 128 threads: every lane is active and -- in every chunk
+// but a ragged last one -- every access in range, so all loads and stores are UNCONDITIONAL.  In the generic form each guarded access is
 // its own exec-masked block, the compiler cannot count the loads and drains them (`s_waitcnt vmcnt(0)`) at every join: the
 // "12 float4 in flight" of the prologue completed one after the other, and each store waited for the one before it.
 template <bool FINAL, bool LR, bool FAST>
@@ -214,6 +214,9 @@ __global__ void __launch_bounds__(128, 4) selscan_fwd_kernel(const float *__rest
     if (FAST) id.act = true;
     const int tid = threadIdx.x, L = gm.L;
     const bool vec = (L & 3) == 0;
+    // FAST kernels serve every L % 4 == 0: the (at most one) ragged chunk at the end of the sequence takes the guarded
+    // forms below, decided per workgroup (uniform)
+    const bool whole = FAST && (int)(blockIdx.x + 1) * TC <= L;
     const float *urow = u + ((size_t)id.b * gm.dim + id.d) * L;
     const float *drow = LR ? delta + (((size_t)id.b * gm.G + id.g) * R) * L : delta + ((size_t)id.b * gm.dim + id.d) * L;
     float wdt[RMAX] = {0.f, 0.f, 0.f, 0.f};
@@ -251,7 +254,7 @@ __global__ void __launch_bounds__(128, 4) selscan_fwd_kernel(const float *__rest
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
         const int t0 = tc0 + sub * ST;
-        if (FAST) {
+        if (whole) {
             pu[sub] = *reinterpret_cast<const float4 *>(urow + t0 + 4 * id.s);
             pd[sub] = LR ? *reinterpret_cast<const float4 *>(rkfast + t0 + 4 * (tid & 3))
                          : *reinterpret_cast<const float4 *>(drow + t0 + 4 * id.s);
@@ -283,7 +286,7 @@ __global__ void __launch_bounds__(128, 4) selscan_fwd_kernel(const float *__rest
             *reinterpret_cast<float4 *>(su + id.cl * UP + 4 * id.s) = pu[sub];
             *reinterpret_cast<float4 *>(sd + id.cl * UP + 4 * id.s) =
                 activate_delta(LR ? lowrank_delta(sR + (sub & 1) * RMAX * ST, R, id.s, wdt) : pd[sub], bias, softplus,
-                               FAST ? 0 : t0 + 4 * id.s, FAST ? 4 : L);
+                               whole ? 0 : t0 + 4 * id.s, whole ? 4 : L);
         }
         if (LR && sub + 1 < NSUB) stage_rank_rows(sR + ((sub + 1) & 1) * RMAX * ST, R, tid, pd[sub + 1]);
         if (bcrow) {
@@ -323,7 +326,7 @@ __global__ void __launch_bounds__(128, 4) selscan_fwd_kernel(const float *__rest
                 if (FINAL && id.s == q) yv = make_float4(yq[0], yq[1], yq[2], yq[3]);
             }
             if (FINAL) {
-                if (FAST) *reinterpret_cast<float4 *>(out + ((size_t)id.b * gm.dim + id.d) * L + t0 + 4 * id.s) = yv;
+                if (whole) *reinterpret_cast<float4 *>(out + ((size_t)id.b * gm.dim + id.d) * L + t0 + 4 * id.s) = yv;
                 else store4(out + ((size_t)id.b * gm.dim + id.d) * L, t0 + 4 * id.s, L, vec, yv);
             }
         }
@@ -399,6 +402,7 @@ __global__ void __launch_bounds__(128, 4) selscan_bwd_local_kernel(const float *
     if (FAST) id.act = true;                      // see selscan_fwd_kernel
     const int tid = threadIdx.x, L = gm.L;
     const bool vec = (L & 3) == 0;
+    const bool whole = FAST && (int)(blockIdx.x + 1) * TC <= L;
     const float *grow = dout + ((size_t)id.b * gm.dim + id.d) * L;
     const float *drow = LR ? delta + (((size_t)id.b * gm.G + id.g) * R) * L : delta + ((size_t)id.b * gm.dim + id.d) * L;
     float wdt[RMAX] = {0.f, 0.f, 0.f, 0.f};
@@ -420,7 +424,7 @@ __global__ void __launch_bounds__(128, 4) selscan_bwd_local_kernel(const float *
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
         const int t0 = tc0 + sub * ST;
-        if (FAST) {
+        if (whole) {
             pg[sub] = *reinterpret_cast<const float4 *>(grow + t0 + 4 * id.s);
             pd[sub] = LR ? *reinterpret_cast<const float4 *>(rkfast + t0 + 4 * (tid & 3))
                          : *reinterpret_cast<const float4 *>(drow + t0 + 4 * id.s);
@@ -448,7 +452,7 @@ __global__ void __launch_bounds__(128, 4) selscan_bwd_local_kernel(const float *
             *reinterpret_cast<float4 *>(sg + id.cl * UP + 4 * id.s) = pg[sub];
             *reinterpret_cast<float4 *>(sd + id.cl * UP + 4 * id.s) =
                 activate_delta(LR ? lowrank_delta(sR + (sub & 1) * RMAX * ST, R, id.s, wdt) : pd[sub], bias, softplus,
-                               FAST ? 0 : t0 + 4 * id.s, FAST ? 4 : L);
+                               whole ? 0 : t0 + 4 * id.s, whole ? 4 : L);
         }
         if (LR && sub > 0) stage_rank_rows(sR + ((sub - 1) & 1) * RMAX * ST, R, tid, pd[sub - 1]);
         if (crow) {
@@ -1394,7 +1398,7 @@ int scan_forward(const float *u, const float *delta, const float *Wdt, int R, co
     const dim3 grid(gm.nchunks, G * gm.nblk, batch), block(block_threads(gm));
     const size_t lds = (size_t)(2 * gm.CB * UP + 2 * ST * BP + (LR ? 2 * RMAX * ST : 0)) * sizeof(float);
     // every lane active, every access in range (see the kernel): the model's shapes at 256^2
-    const bool fast = L % TC == 0 && gm.Hc % gm.CB == 0 && block.x == 128 && 4 * gm.CB == 128 && (!LR || R >= 1);
+    const bool fast = (L & 3) == 0 && gm.Hc % gm.CB == 0 && block.x == 128 && 4 * gm.CB == 128 && (!LR || R >= 1);
     { MLAGG_TIMED(K_SELSCAN_FWD_LOCAL, st);
       if (fast) hipLaunchKernelGGL((selscan_fwd_kernel<false, LR, true>), grid, block, lds, st, u, delta, Wdt, R, A, B, C, D,
                                    delta_bias, out, cstate, cdsum, csub, gm, delta_softplus);
@@ -1443,7 +1447,7 @@ int scan_backward(const float *u, const float *delta, const float *Wdt, int R, c
         if (LR) (void)hipMemsetAsync(ddelta, 0, (size_t)batch * G * R * L * sizeof(float), st);
     }
     const size_t lds1 = (size_t)(2 * gm.CB * UP + ST * BP + (LR ? 2 * RMAX * ST : 0)) * sizeof(float);
-    const bool fast = L % TC == 0 && gm.Hc % gm.CB == 0 && block.x == 128 && 4 * gm.CB == 128 && (!LR || R >= 1);
+    const bool fast = (L & 3) == 0 && gm.Hc % gm.CB == 0 && block.x == 128 && 4 * gm.CB == 128 && (!LR || R >= 1);
     { MLAGG_TIMED(K_SELSCAN_BWD_LOCAL, st);
       if (fast) hipLaunchKernelGGL((selscan_bwd_local_kernel<LR, true>), grid, block, lds1, st, delta, Wdt, R, A, C, delta_bias,
                                    dout, cq, gm, delta_softplus);
