@@ -28,7 +28,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 LAMBDA_INIT = 0.8  # T:638
-SCAN_LITERAL_INDEXING = False   # tools/cpu_baseline_literal.py: time the scan loop exactly as selective_scan_ref writes it
+SCAN_LITERAL_INDEXING = False   # tests/perf/cpu_baseline_literal.py: time the scan loop exactly as selective_scan_ref writes it
 
 
 # --------------------------------------------------------------------------------------

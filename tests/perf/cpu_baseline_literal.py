@@ -1,7 +1,8 @@
 """BASELINE.md section 4, figure (a): one CPU train step of BASELINE configs[0] (batch 2, 128x128, 14 classes, variant B)
 with the scan loop written exactly as mamba-ssm's selective_scan_ref writes it (`deltaA[:, :, i]` indexing, O(L^2)
 backward), beside figure (b), the `unbind` loop the bench's cpu_baseline uses.  CPU only; takes ~10-20 minutes.
-    python tools/cpu_baseline_literal.py [--threads 8] > profiles/roundN_cpu_literal.json.log
+    python tests/perf/cpu_baseline_literal.py [--threads 8] > profiles/roundN_cpu_literal.json.log
+(under tests/: oracle code is test infrastructure and is only run from there, from smoke() and from bench.py's cpu_baseline)
 """
 import argparse
 import json
@@ -11,7 +12,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import mlagg_oracle as O  # noqa: E402
 
 

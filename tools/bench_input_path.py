@@ -1,5 +1,6 @@
 """Throughput of the real-data input path at the headline shape (batch 10, loader patch 301x301 -> 256x256):
-the device augmentation chain (augmentation.GpuAugmenter) beside its scipy oracle on the host cores.
+the device augmentation chain (augmentation.GpuAugmenter).  The CPU figure beside it (the scipy restatement of the reference's
+batchgenerators chain, one core) is tests/perf/augmentation_cpu_baseline.py: oracle code is only run from tests/.
     python tools/bench_input_path.py [--batches 50]
 Prints one JSON line."""
 import argparse
@@ -20,7 +21,6 @@ from mlagg_unet_amd import dataloading as DL  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batches", type=int, default=50)
-    ap.add_argument("--cpu-batches", type=int, default=3)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     aug = AUG.GpuAugmenter((256, 256), dev, seed=0, labels=[0, 1, 2, 3])
@@ -36,15 +36,8 @@ def main():
         DL.to_device({"data": data, "seg": seg}, dev, augmenter=aug)
     torch.cuda.synchronize()
     gpu = (time.perf_counter() - t0) / a.batches
-    from oracle import augmentation_oracle as AO              # the checker, timed as the CPU baseline of this tool only
-    t0 = time.perf_counter()
-    for i in range(a.cpu_batches):
-        p = AUG.draw_params(np.random.RandomState(i), 10, 1, aug.rotation)
-        AO.apply(data.numpy().copy(), seg.numpy().copy(), (256, 256), p, rng.randn(10, 1, 256, 256).astype(np.float32))
-    cpu = (time.perf_counter() - t0) / a.cpu_batches
     print(json.dumps({"workload": "augmentation chain B:666-701, batch 10, 301x301 -> 256x256, H2D included",
-                      "gpu_ms_per_batch": round(gpu * 1e3, 3), "gpu_img_per_s": round(10 / gpu, 1),
-                      "cpu_oracle_ms_per_batch": round(cpu * 1e3, 1), "cpu_img_per_s_one_core": round(10 / cpu, 1)}))
+                      "gpu_ms_per_batch": round(gpu * 1e3, 3), "gpu_img_per_s": round(10 / gpu, 1)}))
 
 
 if __name__ == "__main__":
