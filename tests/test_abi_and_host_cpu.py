@@ -104,3 +104,32 @@ def test_product_loss_equals_oracle_loss_on_cpu():
         gb = torch.autograd.grad(b, outs)
         for x, y in zip(ga, gb):
             assert torch.allclose(x, y, atol=1e-7)
+
+
+def test_product_and_tools_never_import_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it
+    (the product path must not route through a CPU restatement)."""
+    import ast
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    offenders = []
+    for path in glob.glob(os.path.join(root, "mlagg-unet_amd", "**", "*.py"), recursive=True) + \
+            glob.glob(os.path.join(root, "tools", "**", "*.py"), recursive=True) + [os.path.join(root, "mlagg_unet_amd.py")]:
+        tree = ast.parse(open(path).read())
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                offenders.append(os.path.relpath(path, root))
+    assert not offenders, offenders
+    # bench.py and __graft_entry__.py: the import sits inside cpu_baseline's helper / smoke() only
+    for name, allowed in (("bench.py", {"_oracle_step_seconds"}), ("__graft_entry__.py", {"smoke"})):
+        tree = ast.parse(open(os.path.join(root, name)).read())
+        for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+            uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(fn))
+            assert not uses or fn.name in allowed, (name, fn.name)
+        top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+        assert not any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in top), name
