@@ -8,6 +8,7 @@ import torch
 
 import mlagg_unet_amd  # noqa: F401
 from mlagg_unet_amd import model, trainer
+from _trajectory import assert_same_trajectory
 
 pytestmark = pytest.mark.gpu
 
@@ -27,5 +28,4 @@ def test_graph_replay_follows_the_eager_trajectory():
         got = float(graphed(data, target))
         want = float(trainer.train_step(twin, opt_t, data, target))
         assert abs(got - want) < 2e-4 * max(1.0, abs(want)), (got, want)
-    for (k, a), b in zip(net.state_dict().items(), twin.state_dict().values()):
-        assert torch.allclose(a, b, rtol=0, atol=1e-4), (k, float((a - b).abs().max()))
+    assert_same_trajectory(net, twin, steps=6, lr=5e-4)

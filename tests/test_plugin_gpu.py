@@ -7,6 +7,7 @@ import pytest
 import torch
 
 import fake_nnunet as FK
+from _trajectory import assert_same_trajectory
 
 pytestmark = pytest.mark.gpu
 IMG, NCLS, BATCH = (64, 64), 14, 2
@@ -32,21 +33,6 @@ def _batches(n):
     return out
 
 
-def _assert_same_trajectory(net_a, net_b, steps, lr):
-    """Two runs of the same steps: the losses agree to rounding (checked by the callers); the parameters agree up to the
-    run-to-run wobble of float-atomic weight gradients (MIOpen's split-K weight-gradient kernels) seen through AdamW's
-    m / sqrt(v) normalisation: a gradient that is ~0 relative to that noise can move its weight by up to lr per step in
-    either direction.  So: no element further apart than the AdamW bound, and all but a sliver within 5 % of one step."""
-    worst, n_far, n_all = 0.0, 0, 0
-    for (k, a), b in zip(net_a.state_dict().items(), net_b.state_dict().values()):
-        d = (a.float() - b.float()).abs()
-        worst = max(worst, float(d.max()))
-        n_far += int((d > 0.05 * lr).sum())
-        n_all += d.numel()
-    assert worst <= 2.0 * lr * steps * 1.01, worst
-    assert n_far <= 1e-4 * n_all, (n_far, n_all, worst)
-
-
 def test_plugin_train_step_equals_trainer_train_step():
     from mlagg_unet_amd import model, trainer
     tr = _trainer()
@@ -62,7 +48,7 @@ def test_plugin_train_step_equals_trainer_train_step():
         assert isinstance(got["loss"], np.ndarray) and abs(float(got["loss"]) - float(want)) < 2e-5
     assert tr.base_calls["train_step"] == 0 and tr.base_calls["_build_loss"] == 0
     # the losses above agree to rounding (the first one bit for bit); the parameters: see _assert_same_trajectory
-    _assert_same_trajectory(tr.network, twin, steps=2, lr=tr.initial_lr)
+    assert_same_trajectory(tr.network, twin, steps=2, lr=tr.initial_lr)
 
 
 def test_reference_amp_step_also_runs_on_the_product_network():
@@ -82,4 +68,4 @@ def test_reference_amp_step_also_runs_on_the_product_network():
         want = trainer.train_step(twin, twin_opt, b["data"].cuda(), [t.cuda() for t in b["target"]], batch_dice=True)
         assert np.isfinite(got["loss"]) and abs(float(got["loss"]) - float(want)) < 1e-5
     assert tr.base_calls["train_step"] == 2
-    _assert_same_trajectory(tr.network, twin, steps=2, lr=tr.initial_lr)
+    assert_same_trajectory(tr.network, twin, steps=2, lr=tr.initial_lr)
