@@ -136,3 +136,47 @@ def test_selscan_lowrank_rejects_rank_above_4():
         selective_scan_lowrank_fn(u, torch.zeros(1, 1, 5, 16, device=dev), torch.zeros(8, 5, device=dev),
                                   -torch.ones(8, 16, device=dev), torch.zeros(1, 1, 16, 16, device=dev),
                                   torch.zeros(1, 1, 16, 16, device=dev))
+
+
+@gpu
+def test_selscan_full_size_properties():
+    """BASELINE config-2 scan shape (D = 384, G = 4, R = 3, L_cat = 21760; batch 2 of 10), where the oracle is too slow to
+    be the checker: properties that hold at any size.  (i) the scan is LINEAR in u for fixed delta / A / B / C / D;
+    (ii) it is CAUSAL: y[..., :t] does not depend on u[..., t:], bit for bit; (iii) every gradient is linear in dout."""
+    from mlagg_unet_amd.ops import selective_scan_lowrank_fn
+    b, G, Hc, L, R, N = 2, 4, 96, 21760, 3, 16
+    d = G * Hc
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(7)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)                      # noqa: E731
+    u1, u2 = rn(b, d, L), rn(b, d, L)
+    dtr, Wdt = rn(b, G, R, L), rn(d, R) * 0.4
+    A = -torch.exp(rn(d, N) * 0.3 + 1.0)
+    Bm, Cm, Dv, bias = rn(b, G, N, L), rn(b, G, N, L), rn(d), rn(d) - 3.0
+
+    def run(u, dout=None):
+        leaves = [t.clone().requires_grad_(True) for t in (u, dtr, Wdt, A, Bm, Cm, Dv, bias)]
+        y = selective_scan_lowrank_fn(*leaves[:6], leaves[6], leaves[7], True)
+        if dout is None:
+            return y.detach()
+        y.backward(dout)
+        return y.detach(), [t.grad for t in leaves]
+
+    y1, y2 = run(u1), run(u2)
+    y12 = run(0.7 * u1 - 1.3 * u2)
+    scale = float(y1.abs().max())
+    assert float((y12 - (0.7 * y1 - 1.3 * y2)).abs().max()) < 2e-5 * scale * 10          # (i): fp32 sums of ~1e2 terms
+    t0 = 12345                                                                            # inside a chunk, inside a tile
+    u3 = u1.clone()
+    u3[..., t0:] = rn(b, d, L - t0)
+    y3 = run(u3)
+    assert torch.equal(y3[..., :t0], y1[..., :t0])                                        # (ii)
+    assert float((y3[..., t0:] - y1[..., t0:]).abs().max()) > 1e-3 * scale
+    d1, d2 = rn(b, d, L), rn(b, d, L)
+    _, ga = run(u1, d1)
+    _, gb = run(u1, d2)
+    _, gab = run(u1, d1 + 0.5 * d2)
+    for name, a_, b_, ab in zip(("du", "ddtr", "dWdt", "dA", "dB", "dC", "dD", "dbias"), ga, gb, gab):
+        want = a_ + 0.5 * b_
+        s = float(want.abs().max())
+        assert float((ab - want).abs().max()) < 2e-4 * s, name                            # (iii)
