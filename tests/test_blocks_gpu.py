@@ -549,3 +549,40 @@ def test_channel_epilogue_matches_torch(act, B, C, H, W, with_res, with_bias):
         _close(rg.grad, rr.grad.float(), 1e-5, 1e-5, "epilogue dres")
     if with_bias:
         _close(bg.grad, br.grad.float(), 2e-4, 1e-4, "epilogue dbias")
+
+
+@gpu
+def test_full_size_round_trips_of_the_data_movement_and_attention_ops():
+    """Headline shapes (batch 10, 256 x 256 -> four MSMM scales, L_cat = 21760) through properties that need no oracle:
+    cross_merge(cross_scan(x)) = 4 x bit for bit (each direction is a permutation, the merge a sum of four equal values);
+    direction 0 of scale 0 is the plain row-major map; the pooled attention does not depend on the order of the pooled
+    keys (softmax-sum invariance); the token-major projection is linear."""
+    from mlagg_unet_amd import ops
+    HW = [(128, 128), (64, 64), (32, 32), (16, 16)]
+    Lc = sum(h * w for h, w in HW)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x = torch.randn(10, Lc, 96, device=DEV, generator=g)
+    seq = ops.cross_scan(x, HW, 96, 1)
+    assert seq.shape == (10, 4 * 96, Lc)
+    assert torch.equal(seq[:, :96, :128 * 128].transpose(1, 2), x[:, :128 * 128])                  # k = 0, scale 0: identity order
+    assert torch.equal(seq[:, 2 * 96:3 * 96, :128 * 128].flip(-1), seq[:, :96, :128 * 128])        # k = 2 = reversed k = 0
+    back = ops.cross_merge(seq, HW, 96)
+    assert torch.equal(back, 4.0 * x)
+    # K4: key order invariance at stage-0 size (N = 16384 tokens, P = 64 pooled keys, one head pair, d = 48)
+    N, P, nh, d = 128 * 128, 64, 1, 48
+    q = torch.randn(10, N, d, device=DEV, generator=g)
+    k = torch.randn(10, P, d, device=DEV, generator=g)
+    v = torch.randn(10, P, d, device=DEV, generator=g)
+    lam = torch.tensor([0.3], device=DEV)
+    w = torch.ones(48, device=DEV)
+    o1 = ops.pooled_diff_attn(q, k, v, lam, w, nh, 24 ** -0.5)
+    perm = torch.randperm(P, device=DEV, generator=g)
+    o2 = ops.pooled_diff_attn(q, k[:, perm].contiguous(), v[:, perm].contiguous(), lam, w, nh, 24 ** -0.5)
+    assert float((o1 - o2).abs().max()) < 1e-5 * max(1.0, float(o1.abs().max()))
+    # K5: linearity of the 163840-token projection
+    W_ = torch.randn(192, 96, device=DEV, generator=g) * 0.1
+    b_ = torch.randn(192, device=DEV, generator=g)
+    xa, xb = x[:, :16384].contiguous(), torch.randn(10, 16384, 96, device=DEV, generator=g)
+    ya, yb = ops.linear(xa, W_, b_), ops.linear(xb, W_, b_)
+    yab = ops.linear(2.0 * xa - xb, W_, b_)
+    assert float((yab - (2.0 * ya - yb)).abs().max()) < 1e-4 * float(ya.abs().max())      # W(2a - b) + c = 2(Wa + c) - (Wb + c)
