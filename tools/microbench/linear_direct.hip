@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -293,6 +294,135 @@ float run_seq(const float *X, const float *W, const float *b, float *Y, int M, i
     return ms / iters * 1e3f;
 }
 
+// Epilogue software-pipelined into the NEXT tile's k-loop: a persistent wave keeps two accumulator sets; while the MFMAs of
+// tile i + 1 run, the 96 stores of tile i are issued 16 at a time behind the first NP k16-steps.  One wave per SIMD
+// (~250 registers), operands double-buffered at a distance of one k16-step (48 MFMAs).
+template <int TM, int TN, int NP>
+__global__ void __launch_bounds__(64, 1)
+linear_overlap_kernel(const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias,
+                      float *__restrict__ Y, int M, int N, int K, int xs, int ws, int ys)
+{
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 31, kh = lane >> 5;
+    const int nct = N / (32 * TN), nrt = M / (32 * TM);              // full tiles only in this experiment
+    const int ntiles = nct * nrt, nw = gridDim.x;
+    constexpr int NST = TM * TN * 16, SPS = (NST + NP - 1) / NP;      // stores per pipelined step
+    float4 a0[2][TM], b0[2][TN], a1[2][TM], b1[2][TN];
+    const float *ap[TM], *bp[TN];
+    auto point = [&](int t) {
+        const int m0 = (t / nct) * 32 * TM, n0 = (t % nct) * 32 * TN;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) ap[a] = X + (size_t)(m0 + 32 * a + col) * xs + 4 * kh;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bp[b] = W + (size_t)(n0 + 32 * b + col) * ws + 4 * kh;
+    };
+    auto load = [&](float4 (&ra)[2][TM], float4 (&rb)[2][TN], int k) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) ra[h][a] = *reinterpret_cast<const float4 *>(ap[a] + k + 8 * h);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) rb[h][b] = *reinterpret_cast<const float4 *>(bp[b] + k + 8 * h);
+        }
+    };
+    auto mma = [&](f32x16 (&acc)[TM][TN], const float4 (&ra)[2][TM], const float4 (&rb)[2][TN]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        const float av = j == 0 ? ra[h][a].x : (j == 1 ? ra[h][a].y : (j == 2 ? ra[h][a].z : ra[h][a].w));
+                        const float bv = j == 0 ? rb[h][b].x : (j == 1 ? rb[h][b].y : (j == 2 ? rb[h][b].z : rb[h][b].w));
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
+                    }
+    };
+    // stores [lo, hi) of a finished tile (flattened index (a * TN + b) * 16 + r), all compile-time
+    auto store_range = [&](const f32x16 (&acc)[TM][TN], int t, const float (&bv)[TN], auto lo_c, auto hi_c) {
+        constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
+        const int m0 = (t / nct) * 32 * TM, n0 = (t % nct) * 32 * TN;
+#pragma unroll
+        for (int i = lo; i < hi; ++i) {
+            if (i >= NST) break;
+            const int a = i / (TN * 16), b = (i / 16) % TN, r = i % 16;
+            Y[(size_t)(m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh) * ys + n0 + 32 * b + col] = acc[a][b][r] + bv[b];
+        }
+    };
+    f32x16 accA[TM][TN], accB[TM][TN];
+    float bvA[TN], bvB[TN];
+    // one tile: zero `cur`, run its k-loop; behind the first NP steps issue SPS stores of `prev` (tile tp) each
+    auto tile = [&](f32x16 (&cur)[TM][TN], float (&bcur)[TN], int t, const f32x16 (&prev)[TM][TN], const float (&bprev)[TN], int tp,
+                    bool have_prev, int tnext) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cur[a][b][r] = 0.f;
+        const int n0 = (t % nct) * 32 * TN;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bcur[b] = bias ? bias[n0 + 32 * b + col] : 0.f;
+        // operands of step 0 are already in a0 / b0 (requested by the previous tile or the prologue)
+        int k = 0;
+#define MLAGG_STEP(S, CURBUF_A, CURBUF_B, NXT_A, NXT_B)                                                        \
+        {                                                                                                      \
+            if (k + 16 < K) load(NXT_A, NXT_B, k + 16);                                                        \
+            else if (tnext < ntiles) { point(tnext); load(NXT_A, NXT_B, 0); }                                  \
+            mma(cur, CURBUF_A, CURBUF_B);                                                                      \
+            if (have_prev) store_range(prev, tp, bprev, std::integral_constant<int, (S) * SPS>(),              \
+                                       std::integral_constant<int, ((S) + 1) * SPS>());                       \
+            k += 16;                                                                                           \
+        }
+        // NP (even) pipelined steps, buffers alternate 0 / 1
+        if (NP >= 2) { MLAGG_STEP(0, a0, b0, a1, b1) MLAGG_STEP(1, a1, b1, a0, b0) }
+        if (NP >= 4) { MLAGG_STEP(2, a0, b0, a1, b1) MLAGG_STEP(3, a1, b1, a0, b0) }
+        if (NP >= 6) { MLAGG_STEP(4, a0, b0, a1, b1) MLAGG_STEP(5, a1, b1, a0, b0) }
+#undef MLAGG_STEP
+        for (; k < K; k += 32) {                    // the rest of K (multiples of 32 beyond 16 NP), no stores left
+            if (k + 16 < K) load(a1, b1, k + 16);
+            mma(cur, a0, b0);
+            if (k + 32 < K) load(a0, b0, k + 32);
+            else if (tnext < ntiles) { point(tnext); load(a0, b0, 0); }
+            mma(cur, a1, b1);
+        }
+    };
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    point(t);
+    load(a0, b0, 0);
+    tile(accA, bvA, t, accB, bvB, 0, false, t + nw);
+    while (true) {
+        const int t2 = t + nw;
+        if (t2 >= ntiles) { store_range(accA, t, bvA, std::integral_constant<int, 0>(), std::integral_constant<int, NST>()); break; }
+        tile(accB, bvB, t2, accA, bvA, t, true, t2 + nw);
+        const int t3 = t2 + nw;
+        if (t3 >= ntiles) { store_range(accB, t2, bvB, std::integral_constant<int, 0>(), std::integral_constant<int, NST>()); break; }
+        tile(accA, bvA, t3, accB, bvB, t2, true, t3 + nw);
+        t = t3;
+    }
+}
+
+template <int TM, int TN, int NP>
+float run_overlap(const float *X, const float *W, const float *b, float *Y, int M, int N, int K, int iters)
+{
+    const dim3 grid(1024);
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i)
+        hipLaunchKernelGGL((linear_overlap_kernel<TM, TN, NP>), grid, dim3(64), 0, 0, X, W, b, Y, M, N, K, K, K, N);
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i)
+        hipLaunchKernelGGL((linear_overlap_kernel<TM, TN, NP>), grid, dim3(64), 0, 0, X, W, b, Y, M, N, K, K, K, N);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters * 1e3f;
+}
+
 __global__ void reference_kernel(const float *X, const float *W, const float *bias, float *Y, int M, int N, int K)
 {
     const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
@@ -355,6 +485,13 @@ int main()
         t[3] = run<1, 3, 4, 4>(X, W, b, Y, M, N, K, 20);
         t[4] = run<2, 2, 4, 3>(X, W, b, Y, M, N, K, 20);
         t[5] = run<4, 3, 2, 1>(X, W, b, Y, M, N, K, 20);
+        if (K >= 96 && (K - 96) % 32 == 0 && N % 96 == 0 && M % 64 == 0) {
+            const float o0 = run_overlap<2, 3, 6>(X, W, b, Y, M, N, K, 20);
+            CHECK(hipMemcpy(y.data(), Y, y.size() * 4, hipMemcpyDeviceToHost));
+            double md4 = 0;
+            for (size_t i = 0; i < y.size(); i += 97) md4 = fmax(md4, fabs((double)y[i] - yr[i]));
+            printf("   epilogue overlapped into the next tile, 2x3, 1 wave / SIMD: %6.1f us  %5.1f TF (maxdiff %.2e)\n", o0, fl / o0 / 1e6, md4);
+        }
         {
             const float q0 = run_seq<4, 3, 2>(X, W, b, Y, M, N, K, 20);
             CHECK(hipMemcpy(y.data(), Y, y.size() * 4, hipMemcpyDeviceToHost));
