@@ -209,6 +209,20 @@ int mlagg_layernorm_bwd(const float *x, int x_stride, const float *dy, int dy_st
                         int rows, int C, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K2v: depthwise 3x3x3 convolution (zero padding 1, stride 1) + bias (+ SiLU when `silu`) on token-major volumes:
+ * x, y (batch, D*H*W, C) with row strides in floats (multiples of 4, C % 4 == 0); w (C, 27) = Conv3d weight (C, 1, 3, 3, 3)
+ * flattened, tap index kd * 9 + kh * 3 + kw.  Replaces the depthwise nn.Conv3d + SiLU of SS3D
+ * (variants/mamba/UMambaEnc_SS3D.py:166-174, 331-333).  pre: (batch, D*H*W, C) contiguous pre-activation saved for
+ * backward when silu (NULL otherwise / inference).  Backward writes dx, dw (C, 27) and dbias (C, may be NULL).
+ * ------------------------------------------------------------------------------------------ */
+int mlagg_dwconv3d_fwd(const float *x, int x_stride, const float *w, const float *bias, float *y, int y_stride,
+                       float *pre, int batch, int D, int H, int W, int C, int silu, void *stream);
+size_t mlagg_dwconv3d_bwd_workspace_floats(int batch, int D, int H, int W, int C);
+int mlagg_dwconv3d_bwd(const float *x, int x_stride, const float *w, const float *dy, int dy_stride, const float *pre,
+                       float *dx, int dx_stride, float *dw, float *dbias, float *workspace, int batch, int D, int H,
+                       int W, int C, int silu, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * K2n: depthwise 3x3 convolution on NCHW maps (zero padding 1, stride 1 or 2) + bias.  x (B, C, H, W),
  * y (B, C, Ho, Wo), w (C, 9).  Replaces nn.Conv2d(groups=C) of MedNeXtBlock.conv1 / MedNeXtDownBlock.conv1
  * (nnUNetTrainer_MLAgg_2D_dt_MS.py:256-263, 310, 349-356).  Backward overwrites dx, dw (C, 9), dbias (C or NULL).

@@ -227,6 +227,46 @@ def dwconv3x3_nlc(x, weight, bias, H, W, silu=False):
     return DWConv3x3Fn.apply(x, weight, bias, H, W, silu)
 
 
+class DWConv3dFn(torch.autograd.Function):
+    """K2v: depthwise 3x3x3 convolution (+ SiLU) on token-major volumes (B, D*H*W, C); weight (C, 1, 3, 3, 3)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, dims, silu):
+        D, H, W = dims
+        x, xs = _rows(x, "x")
+        B, L, C = x.shape
+        if L != D * H * W or weight.numel() != C * 27:
+            raise RuntimeError(f"dwconv3d: bad shapes x {tuple(x.shape)} weight {tuple(weight.shape)} dims {dims}")
+        w = _require(weight.reshape(C, 27).contiguous(), "weight")
+        bias = None if bias is None else _require(bias.contiguous(), "bias", (C,))
+        y = torch.empty(B, L, C, device=x.device, dtype=torch.float32)
+        pre = torch.empty_like(y) if silu else None
+        _lib.check(_lib.lib().mlagg_dwconv3d_fwd(_ptr(x), xs, _ptr(w), _ptr(bias), _ptr(y), C, _ptr(pre), B, D, H, W, C,
+                                                 int(silu), _stream()), "mlagg_dwconv3d_fwd")
+        ctx.save_for_backward(x, w, pre)
+        ctx.geom = (D, H, W, bool(silu), bias is not None, weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, pre = ctx.saved_tensors
+        D, H, W, silu, has_bias, wshape = ctx.geom
+        B, L, C = x.shape
+        dy, dys = _rows(dy, "dy")
+        dx = torch.empty(B, L, C, device=x.device, dtype=torch.float32)
+        dw = torch.empty(C, 27, device=x.device, dtype=torch.float32)
+        db = torch.empty(C, device=x.device, dtype=torch.float32) if has_bias else None
+        lib = _lib.lib()
+        ws = torch.empty(lib.mlagg_dwconv3d_bwd_workspace_floats(B, D, H, W, C), device=x.device, dtype=torch.float32)
+        _lib.check(lib.mlagg_dwconv3d_bwd(_ptr(x), x.stride(1), _ptr(w), _ptr(dy), dys, _ptr(pre), _ptr(dx), C, _ptr(dw), _ptr(db),
+                                          _ptr(ws), B, D, H, W, C, int(silu), _stream()), "mlagg_dwconv3d_bwd")
+        return dx, dw.reshape(wshape), db, None, None
+
+
+def dwconv3d_nlc(x, weight, bias, dims, silu=False):
+    return DWConv3dFn.apply(x, weight, bias, dims, silu)
+
+
 class LocalDiffAttnFn(torch.autograd.Function):
     """K3: fused 3x3-window differential attention + RMSNorm + LePE (AggregatedAttention local branch)."""
 

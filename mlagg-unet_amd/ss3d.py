@@ -79,7 +79,14 @@ class SS3D(nn.Module):
         """x (B, D, H, W, d_model) -> same shape (reference SS3D.forward, UMambaEnc_SS3D.py:326-352)."""
         B, D, H, W, _ = x.shape
         h = self.in_proj(x.reshape(B, D * H * W, -1))
-        vol = F.silu(self.conv3d(h.transpose(1, 2).reshape(B, self.d_inner, D, H, W)))
-        tok = vol.reshape(B, self.d_inner, -1).transpose(1, 2).contiguous()
+        if h.is_cuda:
+            # K2v: the depthwise 3x3x3 convolution + SiLU on the token-major volume itself -- no transpose on either side (handed
+            # the strided view `h.transpose(1, 2)`, PyTorch takes the volume for channels_last_3d and MIOpen runs a far slower
+            # path still: the block took 19.0 ms per forward + backward at 2 x 24 x 40 x 40 tokens; with real transposes
+            # around MIOpen's naive depthwise kernels 6.8 ms)
+            tok = ops.dwconv3d_nlc(h, self.conv3d.weight, self.conv3d.bias, (D, H, W), silu=True)
+        else:
+            vol = F.silu(self.conv3d(h.transpose(1, 2).reshape(B, self.d_inner, D, H, W)))
+            tok = vol.reshape(B, self.d_inner, -1).transpose(1, 2).contiguous()
         y = self.core(tok, (D, H, W))
         return self.out_proj(self.out_norm(y)).view(B, D, H, W, -1)

@@ -66,3 +66,38 @@ def test_ss3d_at_a_btcv_like_stage_shape():
     idx = ss3d.scan_orders_3d(24, 40, 40, DEV)
     ones = torch.ones(1, 12 * 8, 38400, device=DEV)
     assert torch.equal(ops.index_merge(ones, idx, 8), torch.full((1, 38400, 8), 12.0, device=DEV))
+
+
+@pytest.mark.parametrize("B,D,H,W,C,silu,bias", [(2, 5, 7, 6, 40, True, True), (1, 1, 3, 9, 96, False, True), (2, 4, 4, 4, 8, True, False),
+                                                 (1, 9, 10, 11, 96, True, True)])
+def test_dwconv3d_matches_torch_conv3d(B, D, H, W, C, silu, bias):
+    """K2v (token-major depthwise 3x3x3 + SiLU) against F.conv3d(groups=C) in double precision: forward and all gradients;
+    volumes thinner than the kernel (D = 1), odd extents, channel counts that leave a partial 64-channel block."""
+    import torch.nn.functional as F
+    from mlagg_unet_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + D + C)
+    L = D * H * W
+    x = torch.randn(B, L, C, generator=g)
+    w = torch.randn(C, 1, 3, 3, 3, generator=g) * 0.3
+    b = torch.randn(C, generator=g) if bias else None
+    gy = torch.randn(B, L, C, generator=g)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if bias else None
+    vol = F.conv3d(xr.transpose(1, 2).reshape(B, C, D, H, W), wr, br, padding=1, groups=C)
+    yr = (F.silu(vol) if silu else vol).reshape(B, C, L).transpose(1, 2)
+    yr.backward(gy.double())
+    xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    bg = b.to(DEV).requires_grad_(True) if bias else None
+    y = ops.dwconv3d_nlc(xg, wg, bg, (D, H, W), silu=silu)
+    y.backward(gy.to(DEV))
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < 2e-5
+    assert float((xg.grad.cpu().double() - xr.grad).abs().max()) < 2e-5
+    s = max(1.0, float(wr.grad.abs().max()))
+    assert float((wg.grad.cpu().double() - wr.grad).abs().max()) < 2e-5 * s * 5
+    if bias:
+        assert float((bg.grad.cpu().double() - br.grad).abs().max()) < 1e-4 * max(1.0, float(br.grad.abs().max()))
+    # a strided input (channel block of a wider row, as after a stacked projection) is taken without a copy
+    wide = torch.randn(B, L, C + 8, generator=g).to(DEV)
+    y2 = ops.dwconv3d_nlc(wide[..., 4:4 + C], wg.detach(), bg.detach() if bias else None, (D, H, W), silu=silu)
+    y3 = ops.dwconv3d_nlc(wide[..., 4:4 + C].contiguous(), wg.detach(), bg.detach() if bias else None, (D, H, W), silu=silu)
+    assert torch.equal(y2, y3)
