@@ -20,6 +20,7 @@
 namespace {
 
 constexpr int TL = 64;                 // scan steps per tile
+constexpr int UN = 8;                  // loads in flight per thread
 
 template <bool MERGE>
 __global__ void __launch_bounds__(256)
@@ -35,9 +36,22 @@ index_scan_kernel(float *__restrict__ tok, long tok_stride, int blk_stride, cons
     float *tb = tok + (size_t)b * L * tok_stride + (size_t)k * blk_stride;
     if (!MERGE) {
         __syncthreads();
-        for (int e = threadIdx.x; e < n * CB; e += 256) {
-            const int i = e / CB, c = e - i * CB;
-            sT[c * (TL + 1) + i] = tb[(size_t)sI[i] * tok_stride + c];
+        // UN gathers in flight per thread, unconditional (elements past the tile read its first element and are dropped): one
+        // guarded load per trip is waited for before the next is issued ("Guarded memory operations")
+        for (int e0 = threadIdx.x; e0 < n * CB; e0 += 256 * UN) {
+            float v[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int e = e0 + 256 * u;
+                const bool ok = e < n * CB;
+                const int i = ok ? e / CB : 0, c = ok ? e - i * CB : 0;
+                v[u] = tb[(size_t)sI[i] * tok_stride + c];
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int e = e0 + 256 * u;
+                if (e < n * CB) { const int i = e / CB, c = e - i * CB; sT[c * (TL + 1) + i] = v[u]; }
+            }
         }
         __syncthreads();
         for (int e = threadIdx.x; e < CB * TL; e += 256) {
@@ -45,9 +59,20 @@ index_scan_kernel(float *__restrict__ tok, long tok_stride, int blk_stride, cons
             if (i < n) srow[(size_t)c * L + l0 + i] = sT[c * (TL + 1) + i];
         }
     } else {
-        for (int e = threadIdx.x; e < CB * TL; e += 256) {
-            const int c = e / TL, i = e - c * TL;
-            if (i < n) sT[c * (TL + 1) + i] = srow[(size_t)c * L + l0 + i];
+        for (int e0 = threadIdx.x; e0 < CB * TL; e0 += 256 * UN) {
+            float v[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int e = e0 + 256 * u;
+                const int c = min(e / TL, CB - 1), i = e % TL;
+                v[u] = srow[(size_t)c * L + l0 + (i < n ? i : 0)];
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int e = e0 + 256 * u;
+                const int c = e / TL, i = e - c * TL;
+                if (e < CB * TL && i < n) sT[c * (TL + 1) + i] = v[u];
+            }
         }
         __syncthreads();
         for (int e = threadIdx.x; e < n * CB; e += 256) {
