@@ -47,14 +47,27 @@ dwconv_tiled_kernel(const float *__restrict__ x, const float *__restrict__ w, co
     const int N = g.H * g.W;
     const int c4 = threadIdx.x & 7, c = c0 + 4 * c4;
     const bool cok = c < g.C;
-    // halo: 180 tokens x 8 float4
-    for (int i = threadIdx.x; i < HY * HX * 8; i += 256) {
-        const int hl = i >> 3, hy = hl / HX, hx = hl - hy * HX;
-        const int yy = y0 + hy - 1, xx = x0 + hx - 1;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (cok && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W)
-            v = *reinterpret_cast<const float4 *>(x + ((size_t)b * N + (size_t)yy * g.W + xx) * g.x_stride + c);
-        tile[hl * 8 + c4] = v;
+    // halo: 180 tokens x 8 float4 = 1440 float4, 6 per thread, ALL requested before the first LDS write and unconditional
+    // (clamped token / channel, value dropped): a guarded load per trip is waited for before the next one is issued
+    constexpr int NH = (HY * HX * 8 + 255) / 256;
+    float4 hv[NH];
+    const int cs = cok ? c : 0;
+#pragma unroll
+    for (int u = 0; u < NH; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        const int hl = min(i >> 3, HY * HX - 1), hy = hl / HX, hx = hl - hy * HX;
+        const int yy = min(max(y0 + hy - 1, 0), g.H - 1), xx = min(max(x0 + hx - 1, 0), g.W - 1);
+        hv[u] = *reinterpret_cast<const float4 *>(x + ((size_t)b * N + (size_t)yy * g.W + xx) * g.x_stride + cs);
+    }
+#pragma unroll
+    for (int u = 0; u < NH; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        if (i < HY * HX * 8) {
+            const int hl = i >> 3, hy = hl / HX, hx = hl - hy * HX;
+            const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+            const bool ok = cok && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+            tile[hl * 8 + c4] = ok ? hv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     float wr[4][9];
 #pragma unroll
