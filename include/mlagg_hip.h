@@ -296,6 +296,9 @@ int mlagg_index_scan(const float *tok, long tok_stride, int blk_stride, const in
                      void *stream);
 int mlagg_index_merge(const float *seq, const int *idx, float *tok, long tok_stride, int blk_stride, int B, int L, int K, int CB,
                       void *stream);
+/* out (rows, CB) = sum of the K column blocks of wide (rows, K * CB), in a fixed order (CB % 4 == 0): with
+ * mlagg_index_merge(blk_stride = CB) the deterministic form of the summed merge (torch.sum(y, dim=1), UMambaEnc_SS3D.py:338). */
+int mlagg_block_sum(const float *wide, float *out, long rows, int K, int CB, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K13: epilogue of the library convolutions on NCHW maps (B, C, HW): y = act(x + bias[c] + res), act 0 = none (in place on

@@ -84,6 +84,7 @@ SIGNATURES = {
     "mlagg_channel_gelu_bwd": (_I, [_F, _F, _F, _F, _F, _I, _I, ctypes.c_long, _S]),
     "mlagg_index_scan": (_I, [_F, ctypes.c_long, _I, _F, _F, _I, _I, _I, _I, _S]),
     "mlagg_index_merge": (_I, [_F, _F, _F, ctypes.c_long, _I, _I, _I, _I, _I, _S]),
+    "mlagg_block_sum": (_I, [_F, _F, ctypes.c_long, _I, _I, _S]),
 }
 
 _lib = None

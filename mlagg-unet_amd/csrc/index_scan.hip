@@ -84,6 +84,31 @@ index_scan_kernel(float *__restrict__ tok, long tok_stride, int blk_stride, cons
     }
 }
 
+// out[row][c] = sum_k wide[row][k * CB + c]: the K column blocks of the direction-separated merge, summed in a FIXED order
+// (the atomic form of the summed merge is order-dependent and paid 12 read-modify-writes per output in L2)
+__global__ void __launch_bounds__(256)
+block_sum_kernel(const float *__restrict__ wide, float *__restrict__ out, long rows, int K, int CB)
+{
+    const int q4 = CB >> 2;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * q4) return;
+    const long row = i / q4;
+    const int c = 4 * (int)(i - row * q4);
+    const float *p = wide + row * (long)K * CB + c;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    int k = 0;
+    for (; k + 1 < K; k += 2) {
+        const float4 a = *reinterpret_cast<const float4 *>(p + (long)k * CB), b = *reinterpret_cast<const float4 *>(p + (long)(k + 1) * CB);
+        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+    }
+    if (k < K) {
+        const float4 a = *reinterpret_cast<const float4 *>(p + (long)k * CB);
+        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+    }
+    *reinterpret_cast<float4 *>(out + row * CB + c) = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+}
+
 int check(int B, int L, int K, int CB, long tok_stride, int blk_stride)
 {
     if (B <= 0 || L <= 0 || K <= 0 || CB <= 0 || B > 65535 || K > 65535) return MLAGG_E_UNSUPPORTED;
@@ -130,5 +155,17 @@ extern "C" int mlagg_index_merge(const float *seq, const int *idx, float *tok, l
     MLAGG_TIMED(K_CROSS_MERGE, st);
     hipLaunchKernelGGL(index_scan_kernel<true>, dim3((L + TL - 1) / TL, K, B), dim3(256), lds, st, tok, tok_stride, blk_stride, idx,
                        const_cast<float *>(seq), L, K, CB, atomic);
+    return (int)hipGetLastError();
+}
+
+// (rows, K * CB) -> (rows, CB): sum of the K column blocks (CB % 4 == 0), deterministic
+extern "C" int mlagg_block_sum(const float *wide, float *out, long rows, int K, int CB, void *stream)
+{
+    if (!wide || !out) return MLAGG_E_NULLPTR;
+    if (rows <= 0 || K <= 0 || CB <= 0 || (CB & 3) || rows * (CB >> 2) > 2147483647L * 256) return MLAGG_E_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MLAGG_TIMED(K_CROSS_MERGE, st);
+    const long n = rows * (CB >> 2);
+    hipLaunchKernelGGL(block_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wide, out, rows, K, CB);
     return (int)hipGetLastError();
 }

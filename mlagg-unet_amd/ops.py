@@ -733,7 +733,15 @@ class IndexMergeFn(torch.autograd.Function):
         if rows != K * CB or tuple(idx.shape) != (K, L) or idx.dtype != torch.int32:
             raise RuntimeError(f"index_merge: bad shapes seq {tuple(seq.shape)} idx {tuple(idx.shape)}")
         tok = torch.empty(B, L, CB, device=seq.device, dtype=torch.float32)
-        _lib.check(_lib.lib().mlagg_index_merge(_ptr(seq), _ptr(idx), _ptr(tok), CB, 0, B, L, K, CB, _stream()), "mlagg_index_merge")
+        if K > 1 and CB % 4 == 0:
+            # every direction into its own column block (plain stores), then the K blocks summed in a fixed order: deterministic,
+            # and faster than K float-atomic read-modify-writes per output
+            wide = torch.empty(B, L, K * CB, device=seq.device, dtype=torch.float32)
+            _lib.check(_lib.lib().mlagg_index_merge(_ptr(seq), _ptr(idx), _ptr(wide), K * CB, CB, B, L, K, CB, _stream()),
+                       "mlagg_index_merge")
+            _lib.check(_lib.lib().mlagg_block_sum(_ptr(wide), _ptr(tok), B * L, K, CB, _stream()), "mlagg_block_sum")
+        else:
+            _lib.check(_lib.lib().mlagg_index_merge(_ptr(seq), _ptr(idx), _ptr(tok), CB, 0, B, L, K, CB, _stream()), "mlagg_index_merge")
         ctx.save_for_backward(idx)
         ctx.CB = CB
         return tok

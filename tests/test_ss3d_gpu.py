@@ -28,7 +28,8 @@ def test_index_scan_and_merge_are_transposes():
     ref = torch.zeros(B, L, C, dtype=torch.float64)
     for k in range(12):
         ref[:, idx[k].cpu().long(), :] += y[:, k * C:(k + 1) * C].transpose(1, 2).double()
-    assert float((merged.cpu().double() - ref).abs().max()) < 1e-5     # 12-way float sum, order not fixed
+    assert float((merged.cpu().double() - ref).abs().max()) < 1e-5     # 12-way float sum
+    assert torch.equal(merged, ops.index_merge(y.to(DEV), idx, C))      # ... in a fixed order: bit-reproducible
     # column-block form: direction k reads its own columns of a wide row (the x_proj output)
     wide = torch.randn(B, L, 12 * 9, generator=g)
     rows = ops.index_scan(wide.to(DEV), idx, 4, 9, 3)
