@@ -322,12 +322,14 @@ int mlagg_channel_gelu_bwd(const float *pre, const float *dy, float *dpre, float
  * stats_g[b][c] = sum_p [y == c], ce_sum[0] = sum_{b,p} -log softmax_y.
  * grad: dlogits = d(loss)/d(logits) for upstream gradients g_ip (B, 2, C) of stats_ip and g_ce[0] of ce_sum (device scalars:
  * no host synchronisation).
+ * ignore_label >= 0: pixels carrying that label take no part in any sum and get a zero gradient -- the loss mask of
+ * DC_and_CE_loss(ignore_label=...) (loss/compound_losses.py:38-50; the number of valid pixels is sum_{b,c} stats_g); -1: none.
  * ------------------------------------------------------------------------------------------ */
 int mlagg_dice_ce_max_classes(void);
 int mlagg_dice_ce_stats(const float *logits, const float *target, float *stats_ip, float *stats_g, float *ce_sum, int B, int C,
-                        long HW, void *stream);
+                        long HW, int ignore_label, void *stream);
 int mlagg_dice_ce_grad(const float *logits, const float *target, const float *g_ip, const float *g_ce, float *dlogits, int B,
-                       int C, long HW, void *stream);
+                       int C, long HW, int ignore_label, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K10: per-plane normalisation of an NCHW map fused with the activation that follows it:

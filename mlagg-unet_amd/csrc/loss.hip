@@ -31,6 +31,7 @@ constexpr int TPB = 256;
 struct LossGeom {
     int B, C;
     long HW;
+    int ignore;                   // label value whose pixels take no part in the loss (DC_and_CE_loss(ignore_label=...)); -1: none
 };
 
 __device__ __forceinline__ float wave_sum(float v)
@@ -76,15 +77,16 @@ dice_ce_stats_kernel(const float *__restrict__ logits, const float *__restrict__
             s += z[c];
         }
         const float inv = 1.f / s;
+        const bool valid = y != g.ignore;                  // the loss mask of the reference (compound_losses.py:38-46)
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             const float pc = z[c] * inv;
-            const bool hit = c == y;
-            aP[c] += pc;
+            const bool hit = valid && c == y;
+            aP[c] += valid ? pc : 0.f;
             aI[c] += hit ? pc : 0.f;
             aG[c] += hit ? 1.f : 0.f;
         }
-        ace += logf(s) - zy;                               // -log softmax(z)_y
+        ace += valid ? logf(s) - zy : 0.f;                 // -log softmax(z)_y (CrossEntropyLoss(ignore_index))
     }
     // block reduction: wave butterflies, then LDS adds, then one global add per value
 #pragma unroll
@@ -150,11 +152,13 @@ dice_ce_grad_kernel(const float *__restrict__ logits, const float *__restrict__ 
             z[c] *= inv;                                               // p_c
             dot += z[c] * (gP[c] + (c == y ? gI[c] : 0.f));
         }
+        const bool valid = y != g.ignore;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             if (c < C) {
                 const float hit = c == y ? 1.f : 0.f;
-                db[(size_t)c * g.HW + p] = z[c] * (gP[c] + hit * gI[c] - dot) + gce * (z[c] - hit);
+                const float dz = z[c] * (gP[c] + hit * gI[c] - dot) + gce * (z[c] - hit);
+                db[(size_t)c * g.HW + p] = valid ? dz : 0.f;
             }
         }
     }
@@ -171,12 +175,12 @@ int check(int B, int C, long HW)
 extern "C" int mlagg_dice_ce_max_classes(void) { return MAXC; }
 
 extern "C" int mlagg_dice_ce_stats(const float *logits, const float *target, float *stats_ip, float *stats_g, float *ce_sum,
-                                   int B, int C, long HW, void *stream)
+                                   int B, int C, long HW, int ignore_label, void *stream)
 {
     if (!logits || !target || !stats_ip || !stats_g || !ce_sum) return MLAGG_E_NULLPTR;
     if (int rc = check(B, C, HW)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    LossGeom g{B, C, HW};
+    LossGeom g{B, C, HW, ignore_label};
     MLAGG_TIMED(K_LOSS_STATS, st);
     hipLaunchKernelGGL(dice_ce_stats_kernel, dim3((unsigned)((HW + TPB * PPT - 1) / (TPB * PPT)), B), dim3(TPB), 0, st, logits,
                        target, stats_ip, stats_g, ce_sum, g);
@@ -184,12 +188,12 @@ extern "C" int mlagg_dice_ce_stats(const float *logits, const float *target, flo
 }
 
 extern "C" int mlagg_dice_ce_grad(const float *logits, const float *target, const float *g_ip, const float *g_ce,
-                                  float *dlogits, int B, int C, long HW, void *stream)
+                                  float *dlogits, int B, int C, long HW, int ignore_label, void *stream)
 {
     if (!logits || !target || !g_ip || !g_ce || !dlogits) return MLAGG_E_NULLPTR;
     if (int rc = check(B, C, HW)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    LossGeom g{B, C, HW};
+    LossGeom g{B, C, HW, ignore_label};
     MLAGG_TIMED(K_LOSS_GRAD, st);
     hipLaunchKernelGGL(dice_ce_grad_kernel, dim3((unsigned)((HW + TPB * PPT - 1) / (TPB * PPT)), B), dim3(TPB), 0, st, logits,
                        target, g_ip, g_ce, dlogits, g);

@@ -17,7 +17,8 @@ What the class overrides, and why the inherited method cannot stay (B = nnUNetTr
   * ``initialize``  B:193-215 wraps with a plain ``DDP(...)``; here ``trainer.wrap_ddp`` (bucket views, no buffer
                     broadcast) and the loss is rebuilt so that it knows about DDP.
   * ``_build_loss`` T:106-129: the fused Dice + CE deep-supervision loss (K9) with the batch-dice exchange as one
-                    all-reduce; region / ignore-label datasets keep the reference's own loss classes.
+                    all-reduce; the ignore label of partially annotated datasets is handled in K9; region datasets keep the
+                    reference's own loss classes.
 """
 import torch
 
@@ -77,16 +78,18 @@ def make_trainer_class(nnUNetTrainer, variant="B", precision="fp32"):
 
         def _build_loss(self):                                                      # reference T:106-129
             lm = self.label_manager
-            if getattr(lm, "has_regions", False) or getattr(lm, "ignore_label", None) is not None:
-                # DC_and_BCE_loss / ignore-label masking (T:107-116): not on the MLAgg-UNet benchmark path; the
-                # reference's own torch loss classes run unchanged on the device logits
+            if getattr(lm, "has_regions", False):
+                # DC_and_BCE_loss on region targets (T:107-112): not on the MLAgg-UNet benchmark path; the reference's own
+                # torch loss classes run unchanged on the device logits
                 return super()._build_loss()
             batch_dice, ddp = bool(self.configuration_manager.batch_dice), bool(self.is_ddp)
+            ignore = getattr(lm, "ignore_label", None)                              # T:116: partially annotated datasets
 
             def loss(output, target):
                 if not isinstance(output, (list, tuple)):                           # deep supervision off (validation of
                     output, target = [output], [target if torch.is_tensor(target) else target[0]]   # a no-DS network)
-                return trainer.deep_supervision_loss(list(output), list(target[:len(output)]), batch_dice, ddp)
+                return trainer.deep_supervision_loss(list(output), list(target[:len(output)]), batch_dice, ddp,
+                                                     ignore_label=ignore)
 
             return loss
 

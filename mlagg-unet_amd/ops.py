@@ -885,12 +885,14 @@ def scaled_residual(skip, branch, scale):
 class DiceCEStatsFn(torch.autograd.Function):
     """K9: per-level Dice / cross-entropy statistics of ALL deep-supervision levels (one kernel per level each way).
 
-    ``DiceCEStatsFn.apply(n_levels, *logits, *targets)`` -> (ip (L, B, 2, C): intersect and sum_pred per sample and class,
-    gt (L, B, C): label counts, ce (L,): summed -log softmax of the label); gradients flow to the logits from ip and ce."""
+    ``DiceCEStatsFn.apply(n_levels, ignore_label, *logits, *targets)`` -> (ip (L, B, 2, C): intersect and sum_pred per sample and
+    class, gt (L, B, C): label counts, ce (L,): summed -log softmax of the label); gradients flow to the logits from ip and ce.
+    ``ignore_label`` (int, -1: none): pixels with that label are left out of every sum and get no gradient."""
 
     @staticmethod
-    def forward(ctx, n, *tensors):
+    def forward(ctx, n, ignore_label, *tensors):
         logits, targets = tensors[:n], tensors[n:]
+        ctx.ignore = int(ignore_label)
         B, C = logits[0].shape[:2]
         dev = logits[0].device
         lib = _lib.lib()
@@ -908,7 +910,7 @@ class DiceCEStatsFn(torch.autograd.Function):
                 raise RuntimeError("dice_ce_stats: logits / target shapes of a level do not match")
             hw = z.numel() // (B * C)
             _lib.check(lib.mlagg_dice_ce_stats(_ptr(z), _ptr(t), _ptr(ip[i]), _ptr(gt[i]), ce.data_ptr() + 4 * i, B, C, hw,
-                                               _stream()), "mlagg_dice_ce_stats")
+                                               ctx.ignore, _stream()), "mlagg_dice_ce_stats")
             saved += [z, t]
         ctx.save_for_backward(*saved)
         ctx.n = n
@@ -928,13 +930,13 @@ class DiceCEStatsFn(torch.autograd.Function):
             z, t = saved[2 * i], saved[2 * i + 1]
             dz = torch.empty_like(z)
             _lib.check(lib.mlagg_dice_ce_grad(_ptr(z), _ptr(t), _ptr(g_ip[i]), g_ce.data_ptr() + 4 * i, _ptr(dz), B, C,
-                                              z.numel() // (B * C), _stream()), "mlagg_dice_ce_grad")
+                                              z.numel() // (B * C), ctx.ignore, _stream()), "mlagg_dice_ce_grad")
             grads.append(dz)
-        return (None, *grads, *([None] * n))
+        return (None, None, *grads, *([None] * n))
 
 
-def dice_ce_stats(logits, targets):
-    return DiceCEStatsFn.apply(len(logits), *logits, *targets)
+def dice_ce_stats(logits, targets, ignore_label=None):
+    return DiceCEStatsFn.apply(len(logits), -1 if ignore_label is None else int(ignore_label), *logits, *targets)
 
 
 def transpose_2d(src):

@@ -43,16 +43,19 @@ class _AllGatherSum(torch.autograd.Function):
         return g
 
 
-def soft_dice_loss(logits, target, batch_dice=True, smooth=1e-5, ddp=False):
+def soft_dice_loss(logits, target, batch_dice=True, smooth=1e-5, ddp=False, mask=None):
+    """MemoryEfficientSoftDiceLoss (loss/dice.py:73-117), do_bg False; `mask` (B, 1, ...) bool: the loss mask of an ignore label."""
     probs = logits.softmax(1)[:, 1:]
     axes = tuple(range(2, logits.ndim))
     with torch.no_grad():
         onehot = torch.zeros(logits.shape, dtype=torch.bool, device=logits.device)
         onehot.scatter_(1, target.long(), 1)
         onehot = onehot[:, 1:]
+        if mask is not None:
+            onehot = onehot & mask
         sum_gt = onehot.sum(axes).to(probs.dtype)
     intersect = (probs * onehot).sum(axes)
-    sum_pred = probs.sum(axes)
+    sum_pred = (probs if mask is None else probs * mask).sum(axes)
     if batch_dice:
         stats = torch.stack([intersect.sum(0), sum_pred.sum(0), sum_gt.sum(0)])
         if ddp:
@@ -62,8 +65,16 @@ def soft_dice_loss(logits, target, batch_dice=True, smooth=1e-5, ddp=False):
     return -dc.mean()
 
 
-def dc_and_ce_loss(logits, target, batch_dice=True, ddp=False):
-    return F.cross_entropy(logits, target[:, 0].long()) + soft_dice_loss(logits, target, batch_dice, ddp=ddp)
+def dc_and_ce_loss(logits, target, batch_dice=True, ddp=False, ignore_label=None):
+    """DC_and_CE_loss.forward (loss/compound_losses.py:31-57) incl. its ignore-label branch (:38-50)."""
+    if ignore_label is None:
+        return F.cross_entropy(logits, target[:, 0].long()) + soft_dice_loss(logits, target, batch_dice, ddp=ddp)
+    mask = target != ignore_label
+    target_dice = torch.where(mask, target, torch.zeros_like(target))
+    dc = soft_dice_loss(logits, target_dice, batch_dice, ddp=ddp, mask=mask)
+    if int(mask.sum()) == 0:                            # the reference skips the cross-entropy of a fully ignored batch
+        return dc
+    return F.cross_entropy(logits, target[:, 0].long(), ignore_index=int(ignore_label)) + dc
 
 
 def deep_supervision_weights(n=5):
@@ -72,12 +83,12 @@ def deep_supervision_weights(n=5):
     return [v / s for v in w]
 
 
-def deep_supervision_loss_eager(outputs, targets, batch_dice=True, ddp=False):
+def deep_supervision_loss_eager(outputs, targets, batch_dice=True, ddp=False, ignore_label=None):
     """The loss as the reference composes it, level by level in torch ops (host tensors / CPU tests)."""
     ws = deep_supervision_weights(len(outputs))
-    total = ws[0] * dc_and_ce_loss(outputs[0], targets[0], batch_dice, ddp)
+    total = ws[0] * dc_and_ce_loss(outputs[0], targets[0], batch_dice, ddp, ignore_label)
     for w, o, t in zip(ws[1:], outputs[1:], targets[1:]):
-        total = total + w * dc_and_ce_loss(o, t, batch_dice, ddp)
+        total = total + w * dc_and_ce_loss(o, t, batch_dice, ddp, ignore_label)
     return total
 
 
@@ -94,15 +105,15 @@ def _level_constants(npix, device):
     return _LEVEL_CONSTANTS[key]
 
 
-def deep_supervision_loss(outputs, targets, batch_dice=True, ddp=False, smooth=1e-5):
+def deep_supervision_loss(outputs, targets, batch_dice=True, ddp=False, smooth=1e-5, ignore_label=None):
     """DeepSupervisionWrapper(DC_and_CE_loss) of reference T:106-129.  On the MI355X: K9 reads every logit map once
     for the statistics and once for the gradient (2 x 5 kernels instead of ~310 launches, 2.5 -> 0.3 ms at config 2);
     the (levels, classes)-sized algebra below is torch, vectorised over the levels, and the batch-dice statistics of
     all levels cross the ranks in ONE all-reduce each way."""
     if not outputs[0].is_cuda:
-        return deep_supervision_loss_eager(outputs, targets, batch_dice, ddp)
+        return deep_supervision_loss_eager(outputs, targets, batch_dice, ddp, ignore_label)
     from . import ops
-    ip, gt, ce = ops.dice_ce_stats(list(outputs), list(targets))            # (L, B, 2, C), (L, B, C), (L,)
+    ip, gt, ce = ops.dice_ce_stats(list(outputs), list(targets), ignore_label)   # (L, B, 2, C), (L, B, C), (L,)
     inter, pred, gts = ip[:, :, 0, 1:], ip[:, :, 1, 1:], gt[:, :, 1:]        # background dropped (do_bg=False)
     if batch_dice:
         stats = torch.stack([inter.sum(1), pred.sum(1), gts.sum(1)])        # (3, L, C-1)
@@ -112,6 +123,11 @@ def deep_supervision_loss(outputs, targets, batch_dice=True, ddp=False, smooth=1
     dc = (2 * inter + smooth) / torch.clip(gts + pred + smooth, 1e-8)
     dice = -dc.flatten(1).mean(1)                                           # (L,)
     w_ce, w_dice = _level_constants(tuple(o.numel() // o.shape[1] for o in outputs), ce.device)
+    if ignore_label is not None:
+        # cross-entropy mean over the pixels that are NOT ignored (CrossEntropyLoss(ignore_index), local to the rank as in the
+        # reference); every valid pixel hits exactly one class, so their number is the sum of the label counts.  A fully ignored
+        # level has ce = 0 and contributes nothing, like the reference's `num_fg > 0` test
+        w_ce = w_dice / gt.sum((1, 2)).clamp(min=1.0)
     return (w_ce * ce + w_dice * dice).sum()
 
 

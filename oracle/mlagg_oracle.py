@@ -623,24 +623,35 @@ def build_reference_config_model(img_size, in_channels=1, num_classes=14, deep_s
 # loss (L/deep_supervision.py:17-34, L/compound_losses.py:31-57, L/dice.py:73-117,
 #       L/robust_ce_loss.py:12-16) -- single-process form (no AllGatherGrad)
 # --------------------------------------------------------------------------------------
-def soft_dice_loss(logits, target, batch_dice=True, smooth=1e-5):
+def soft_dice_loss(logits, target, batch_dice=True, smooth=1e-5, loss_mask=None):
+    """MemoryEfficientSoftDiceLoss.forward (L/dice.py:73-117), do_bg False; loss_mask (B, 1, ...) as in :97-107."""
     probs = logits.softmax(1)[:, 1:]
     axes = tuple(range(2, logits.ndim))
     with torch.no_grad():
         onehot = torch.zeros(logits.shape, dtype=torch.bool, device=logits.device)
         onehot.scatter_(1, target.long(), 1)
         onehot = onehot[:, 1:]
-        sum_gt = onehot.sum(axes)
-    intersect = (probs * onehot).sum(axes)
-    sum_pred = probs.sum(axes)
+        sum_gt = onehot.sum(axes) if loss_mask is None else (onehot * loss_mask).sum(axes)
+    intersect = (probs * onehot).sum(axes) if loss_mask is None else (probs * onehot * loss_mask).sum(axes)
+    sum_pred = probs.sum(axes) if loss_mask is None else (probs * loss_mask).sum(axes)
     if batch_dice:
         intersect, sum_pred, sum_gt = intersect.sum(0), sum_pred.sum(0), sum_gt.sum(0)
     dc = (2 * intersect + smooth) / torch.clip(sum_gt + sum_pred + smooth, 1e-8)
     return -dc.mean()
 
 
-def dc_and_ce_loss(logits, target, batch_dice=True):
-    return F.cross_entropy(logits, target[:, 0].long()) + soft_dice_loss(logits, target, batch_dice)
+def dc_and_ce_loss(logits, target, batch_dice=True, ignore_label=None):
+    """DC_and_CE_loss.forward (L/compound_losses.py:31-57): with an ignore label (:38-46) the ignored pixels are masked out of
+    the dice sums (their label replaced by 0) and skipped by the cross-entropy (ignore_index: mean over the others); a batch
+    without a single annotated pixel has no cross-entropy term (:50-51)."""
+    if ignore_label is None:
+        return F.cross_entropy(logits, target[:, 0].long()) + soft_dice_loss(logits, target, batch_dice)
+    mask = (target != ignore_label).bool()
+    target_dice = torch.clone(target)
+    target_dice[target == ignore_label] = 0
+    dc = soft_dice_loss(logits, target_dice, batch_dice, loss_mask=mask)
+    ce = F.cross_entropy(logits, target[:, 0].long(), ignore_index=int(ignore_label)) if mask.sum() > 0 else 0
+    return ce + dc
 
 
 def deep_supervision_weights(n=5):  # T:118-126
@@ -648,11 +659,11 @@ def deep_supervision_weights(n=5):  # T:118-126
     return (w / w.sum()).tolist()
 
 
-def deep_supervision_loss(outputs, targets, batch_dice=True):
+def deep_supervision_loss(outputs, targets, batch_dice=True, ignore_label=None):
     ws = deep_supervision_weights(len(outputs))
-    total = ws[0] * dc_and_ce_loss(outputs[0], targets[0], batch_dice)
+    total = ws[0] * dc_and_ce_loss(outputs[0], targets[0], batch_dice, ignore_label)
     for w, o, t in zip(ws[1:], outputs[1:], targets[1:]):
-        total = total + w * dc_and_ce_loss(o, t, batch_dice)
+        total = total + w * dc_and_ce_loss(o, t, batch_dice, ignore_label)
     return total
 
 

@@ -326,6 +326,44 @@ def golden_loss():
     print("loss", vals)
 
 
+def loss_ignore_case():
+    """Inputs of the ignore-label loss golden (shared with the tests): 5 deep-supervision levels, 5 classes + ignore label 5;
+    level 3 of sample 0 and ALL of the coarsest level are fully ignored (the latter exercises the skipped cross-entropy)."""
+    g = torch.Generator().manual_seed(23)
+    outs = [torch.randn(3, 5, 32 >> s, 32 >> s, generator=g) for s in range(5)]
+    tg = []
+    for s in range(5):
+        t = torch.round(torch.rand(3, 1, 32 >> s, 32 >> s, generator=g) * 4)
+        t[torch.rand(t.shape, generator=g) < 0.3] = 5.0
+        tg.append(t)
+    tg[3][0] = 5.0
+    tg[4][:] = 5.0
+    return outs, tg
+
+
+def golden_loss_ignore():
+    """DeepSupervisionWrapper(DC_and_CE_loss(ignore_label=5)) of the reference (T:106-129 with a label manager that has an
+    ignore label; L/compound_losses.py:38-51): value and gradient w.r.t. every level's logits."""
+    from nnunetv2.training.loss.compound_losses import DC_and_CE_loss
+    from nnunetv2.training.loss.deep_supervision import DeepSupervisionWrapper
+    from nnunetv2.training.loss.dice import MemoryEfficientSoftDiceLoss
+    vals = {}
+    for bd in (True, False):
+        base = DC_and_CE_loss({'batch_dice': bd, 'smooth': 1e-5, 'do_bg': False, 'ddp': False}, {}, weight_ce=1,
+                              weight_dice=1, ignore_label=5, dice_class=MemoryEfficientSoftDiceLoss)
+        w = np.array([1 / (2 ** i) for i in range(5)])
+        wrap = DeepSupervisionWrapper(base, w / w.sum())
+        outs, tg = loss_ignore_case()
+        outs = [o.requires_grad_(True) for o in outs]
+        loss = wrap(outs, tg)
+        loss.backward()
+        vals[f"loss_batch_dice_{int(bd)}"] = float(loss)
+        for s, o in enumerate(outs):
+            vals[f"grad{s}_batch_dice_{int(bd)}"] = o.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "loss_ignore.npz"), seed=23, **vals)
+    print("loss (ignore label)", {k: v for k, v in vals.items() if k.startswith("loss")})
+
+
 def golden_sliding_window():
     """Reference predict_sliding_window_return_logits (sliding_window_prediction.py:118-210) on its CPU branch, with
     acvl_utils.pad_nd_image (third-party, absent) replaced by the oracle's restatement."""
@@ -448,6 +486,10 @@ if __name__ == "__main__":
     if "--only-ss3d" in sys.argv:
         golden_ss3d()
         sys.exit(0)
+    if "--only-loss" in sys.argv:
+        golden_loss()
+        golden_loss_ignore()
+        sys.exit(0)
     if "--only-256" in sys.argv:
         golden_full_model_256(T)
         sys.exit(0)
@@ -460,6 +502,7 @@ if __name__ == "__main__":
     golden_evaluation()
     golden_dataloader()
     golden_loss()
+    golden_loss_ignore()
     golden_msmm(M)
     for v in ("B", "A"):
         golden_mllablock(T, v)

@@ -586,3 +586,32 @@ def test_full_size_round_trips_of_the_data_movement_and_attention_ops():
     ya, yb = ops.linear(xa, W_, b_), ops.linear(xb, W_, b_)
     yab = ops.linear(2.0 * xa - xb, W_, b_)
     assert float((yab - (2.0 * ya - yb)).abs().max()) < 1e-4 * float(ya.abs().max())      # W(2a - b) + c = 2(Wa + c) - (Wb + c)
+
+
+@gpu
+@pytest.mark.parametrize("batch_dice", [True, False])
+def test_fused_loss_with_ignore_label_matches_reference_golden(batch_dice):
+    """K9 with the ignore label of partially annotated datasets: pixels carrying it are left out of the dice sums and of the
+    cross-entropy mean and get no gradient (reference DC_and_CE_loss(ignore_label=5), tests/golden/loss_ignore.npz)."""
+    import os
+    import numpy as np
+    from mlagg_unet_amd import trainer as TR
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_ignore.npz"))
+    g = torch.Generator().manual_seed(23)
+    outs = [torch.randn(3, 5, 32 >> s, 32 >> s, generator=g) for s in range(5)]
+    tg = []
+    for s in range(5):
+        t_ = torch.round(torch.rand(3, 1, 32 >> s, 32 >> s, generator=g) * 4)
+        t_[torch.rand(t_.shape, generator=g) < 0.3] = 5.0
+        tg.append(t_)
+    tg[3][0] = 5.0
+    tg[4][:] = 5.0
+    zs = [o.to(DEV).requires_grad_(True) for o in outs]
+    loss = TR.deep_supervision_loss(zs, [t_.to(DEV) for t_ in tg], batch_dice=batch_dice, ignore_label=5)
+    assert abs(float(loss.detach()) - float(G[f"loss_batch_dice_{int(batch_dice)}"])) < 2e-6
+    loss.backward()
+    for s, z in enumerate(zs):
+        want = torch.from_numpy(G[f"grad{s}_batch_dice_{int(batch_dice)}"])
+        assert float((z.grad.cpu() - want).abs().max()) < 1e-7
+    assert float(zs[4].grad.abs().max()) == 0.0                    # the fully ignored level: no gradient at all
+    assert float(zs[0].grad.cpu()[(tg[0] == 5).expand(-1, 5, -1, -1)].abs().max()) == 0.0

@@ -96,6 +96,36 @@ def test_msmm_matches_reference(golden_dir):
         np.testing.assert_allclose(p.grad.numpy(), g[key], atol=1e-4, rtol=2e-3, err_msg=key)
 
 
+def _loss_ignore_case():
+    """tests/golden/make_golden.py: loss_ignore_case (same seeded inputs)."""
+    g = torch.Generator().manual_seed(23)
+    outs = [torch.randn(3, 5, 32 >> s, 32 >> s, generator=g) for s in range(5)]
+    tg = []
+    for s in range(5):
+        t = torch.round(torch.rand(3, 1, 32 >> s, 32 >> s, generator=g) * 4)
+        t[torch.rand(t.shape, generator=g) < 0.3] = 5.0
+        tg.append(t)
+    tg[3][0] = 5.0
+    tg[4][:] = 5.0
+    return outs, tg
+
+
+def test_ignore_label_loss_matches_reference(golden_dir):
+    """DC_and_CE_loss(ignore_label=5) of the reference (L/compound_losses.py:38-51): value and logit gradients of every level,
+    for the oracle and for the product's host path; one level is fully ignored (no cross-entropy term there)."""
+    from mlagg_unet_amd import trainer
+    g = _load(golden_dir, "loss_ignore.npz")
+    for fn in (O.deep_supervision_loss, trainer.deep_supervision_loss):
+        for bd in (True, False):
+            outs, tg = _loss_ignore_case()
+            outs = [o.requires_grad_(True) for o in outs]
+            loss = fn(outs, tg, batch_dice=bd, ignore_label=5)
+            assert abs(float(loss.detach()) - float(g[f"loss_batch_dice_{int(bd)}"])) < 1e-6
+            for s_, gr in enumerate(torch.autograd.grad(loss, outs)):
+                assert float((gr - torch.from_numpy(g[f"grad{s_}_batch_dice_{int(bd)}"])).abs().max()) < 1e-7
+            assert float(torch.autograd.grad(fn(outs, tg, batch_dice=bd, ignore_label=5), outs)[4].abs().max()) == 0.0
+
+
 def test_loss_matches_reference(golden_dir):
     g = _load(golden_dir, "loss.npz")
     gen = torch.Generator()

@@ -96,13 +96,28 @@ def test_plugin_drops_the_grad_scaler_of_a_gpu_trainer(plugin):
     assert tr.device == torch.device("cuda", 0) and tr.grad_scaler is None
 
 
-def test_region_or_ignore_label_datasets_keep_the_reference_loss(plugin):
+def test_ignore_label_dataset_uses_the_product_loss_and_regions_keep_the_reference_classes(plugin):
+    """T:106-116: a dataset with an ignore label gets the product loss with that label masked out (value checked against the
+    oracle's restatement of DC_and_CE_loss(ignore_label=...)); region targets fall back to the maintainer's DC_and_BCE_loss."""
+    from oracle import mlagg_oracle as O
     cls, _ = plugin
     dj = FK.make_dataset_json(5)
     dj["ignore_label"] = 5
     tr = cls(FK.make_plans((32, 32), 3), "2d_bs10", 0, dj, device=torch.device("cpu"))
     tr.initialize()
-    assert tr.base_calls["_build_loss"] == 1 and tr.loss == "reference-loss-classes"
+    assert tr.base_calls["_build_loss"] == 0 and callable(tr.loss)
+    g = torch.Generator().manual_seed(4)
+    outs = [torch.randn(2, 5, 32 >> s, 32 >> s, generator=g) for s in range(5)]
+    tg = [torch.round(torch.rand(2, 1, 32 >> s, 32 >> s, generator=g) * 5) for s in range(5)]        # label 5 = ignore
+    want = O.deep_supervision_loss(outs, tg, batch_dice=tr.configuration_manager.batch_dice, ignore_label=5)
+    assert abs(float(tr.loss(outs, tg)) - float(want)) < 1e-6
+    plain = O.deep_supervision_loss(outs, [t.clamp(max=4) for t in tg], batch_dice=tr.configuration_manager.batch_dice)
+    assert abs(float(want) - float(plain)) > 1e-3                   # ... and the mask matters
+    dj2 = FK.make_dataset_json(5)
+    dj2["regions"] = True
+    tr2 = cls(FK.make_plans((32, 32), 3), "2d_bs10", 0, dj2, device=torch.device("cpu"))
+    tr2.initialize()
+    assert tr2.base_calls["_build_loss"] == 1 and tr2.loss == "reference-loss-classes"
 
 
 def test_unknown_precision_is_refused():
