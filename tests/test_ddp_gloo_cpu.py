@@ -61,6 +61,36 @@ def test_ddp_batch_dice_equals_global_batch_dice():
         assert gerr < 1e-7                     # and, after DDP's 1/world averaging, the global gradient
 
 
+def _dice_ignore_case(rank, world):
+    """Batch dice with an ignore label over two ranks: the masked statistics cross the ranks (one all-reduce each way) and
+    equal the masked global-batch dice of one process."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import mlagg_unet_amd  # noqa: F401
+    from mlagg_unet_amd import trainer
+    g = torch.Generator().manual_seed(19)
+    logits = torch.randn(4, 5, 16, 16, generator=g)
+    target = torch.round(torch.rand(4, 1, 16, 16, generator=g) * 5)          # label 5 = ignore
+    target[3] = 5.0                                                          # a fully ignored sample (on rank 1)
+    mask = target != 5
+    tdice = torch.where(mask, target, torch.zeros_like(target))
+    mine = logits[2 * rank:2 * rank + 2].clone().requires_grad_(True)
+    sl = slice(2 * rank, 2 * rank + 2)
+    loss = trainer.soft_dice_loss(mine, tdice[sl], batch_dice=True, ddp=True, mask=mask[sl])
+    loss.backward()
+    full = logits.clone().requires_grad_(True)
+    ref = trainer.soft_dice_loss(full, tdice, batch_dice=True, ddp=False, mask=mask)
+    ref.backward()
+    return (float(loss.detach()), float(ref.detach()), float((mine.grad / world - full.grad[sl]).abs().max()),
+            float(mine.grad[mask[sl].expand(-1, 5, -1, -1) == 0].abs().max()))
+
+
+def test_ddp_batch_dice_with_ignore_label_equals_global_batch_dice():
+    for loss, ref, gerr, gmasked in _run(_dice_ignore_case):
+        assert abs(loss - ref) < 1e-6 and gerr < 1e-7
+        assert gmasked == 0.0                  # ignored pixels receive no dice gradient on any rank
+
+
 class _Tiny(torch.nn.Module):
     def __init__(self):
         super().__init__()
