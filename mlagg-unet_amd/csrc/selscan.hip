@@ -848,7 +848,7 @@ selscan_bwd_kernel(const float *__restrict__ u, const float *__restrict__ delta,
 //   * per (tile, channel): lane (cl, s) loads / activates delta for its steps, parks delta', delta' u, u, dy rows in LDS
 //     (quad-private rows, b128 broadcast reads), runs its 4 states (forward 8 steps keeping a_k, h_{k-1}; reverse 8 steps),
 //     quad-reduces the per-step sums and finishes du / d(delta) for steps 2s, 2s + 1.
-// ~22 KB of LDS per wave: 7 waves per CU.
+// 18.9 KB of LDS per wave: 8 waves per CU (2 per SIMD, which is also what its ~234 VGPRs allow).
 // ------------------------------------------------------------------------------------------
 constexpr int T8 = 8;            // steps per tile of the group kernel
 constexpr int SP8 = 8;           // pitch of the 8-step dy rows (b128 reads of one 16-lane group still hit 16 distinct banks)
@@ -982,7 +982,7 @@ selscan_bwd_group_kernel(const float *__restrict__ u, const float *__restrict__ 
     __shared__ float sY[16 * SP8];                      // dy of the current 8 steps
     __shared__ float4 sQ[JMAX * 64], sA[JMAX * 64];     // per (channel slot, lane): reverse carry q[4], dA[4]
     __shared__ float2 sE[JMAX * 16 * 3];                // per channel: {dD, d(bias)}, {dW0, dW1}, {dW2, dW3}
-    // 18.4 KB in all: 8 waves per CU (2 per SIMD, what ~240 VGPRs allow)
+    // 18.9 KB in all: 8 waves per CU (2 per SIMD, what ~240 VGPRs allow)
 
     constexpr bool LR = RT > 0;
     constexpr bool RDYN = RT == RMAX;                   // rank rows beyond the run-time R are skipped one by one
