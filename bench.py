@@ -145,7 +145,7 @@ def main():
             dist.init_process_group(backend)
 
     import mlagg_unet_amd  # noqa: F401
-    from mlagg_unet_amd import _lib, miopen_tuning, model, profiling, trainer
+    from mlagg_unet_amd import _lib, gemm_tuning, miopen_tuning, model, profiling, trainer
 
     _lib.lib()                                              # fail loudly if the HIP library is missing
     # The reference sets cudnn.benchmark=True (run_training.py:123-125); here: the committed result of that search
@@ -155,6 +155,8 @@ def main():
     mode = os.environ.get("MLAGG_BENCH_MIOPEN", "auto")
     miopen_db = miopen_tuning.use_tuned_convolutions(
         enabled=(mode == "find") or (mode == "auto" and args.config == 2 and cfg["precision"] == "fp32"))
+    # ... and of the same kind of search over the library GEMM algorithms (PyTorch TunableOp table, tuning off at run time)
+    gemm_db = gemm_tuning.use_tuned_gemms(enabled=mode == "auto" and args.precision is None and args.config == 2)
     torch.manual_seed(0)
     net = model.build_network_architecture(IMG, cfg["in_ch"], N_CLASSES, True, cfg["variant"], cfg["precision"]).to(dev).train()
     use_graph = args.graph and not ddp and not args.no_graph and cfg["precision"] == "fp32"
@@ -250,7 +252,8 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "final_loss": round(float(loss), 5),
                        "launch": "hipGraph replay of the whole step" if use_graph else "eager",
-                       "miopen": "tuned find-db (mlagg-unet_amd/miopen_db)" if miopen_db else "immediate mode"},
+                       "miopen": "tuned find-db (mlagg-unet_amd/miopen_db)" if miopen_db else "immediate mode",
+                       "library_gemm": "TunableOp table (mlagg-unet_amd/gemm_db), tuning off" if gemm_db else "library default"},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline and args.config == 2:

@@ -133,3 +133,20 @@ def test_product_and_tools_never_import_the_oracle():
             assert not uses or fn.name in allowed, (name, fn.name)
         top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
         assert not any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in top), name
+
+
+def test_committed_tuning_tables_are_well_formed():
+    """The MIOpen find-db and the TunableOp GEMM table that bench.py loads: present, parseable, made for gfx950."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gemm = glob.glob(os.path.join(root, "mlagg-unet_amd", "gemm_db", "*.csv"))
+    assert len(gemm) == 1
+    lines = open(gemm[0]).read().strip().split("\n")
+    assert any(ln.startswith("Validator,GCN_ARCH_NAME,gfx950") for ln in lines)
+    rows = [ln.split(",") for ln in lines if not ln.startswith("Validator")]
+    assert len(rows) >= 30 and all(len(r) == 4 and float(r[3]) > 0 for r in rows)
+    ufdb = glob.glob(os.path.join(root, "mlagg-unet_amd", "miopen_db", "*.ufdb.txt"))
+    assert len(ufdb) == 1 and "gfx950" in os.path.basename(ufdb[0])
+    assert all("=" in ln for ln in open(ufdb[0]).read().strip().split("\n"))
+    from mlagg_unet_amd import gemm_tuning
+    assert gemm_tuning.use_tuned_gemms(enabled=False) is None
