@@ -28,7 +28,7 @@ constexpr int E = 24;                  // head_dim of every MLAgg-UNet stage (re
 constexpr int TOK = 256;               // tokens per workgroup (forward, backward-1)
 constexpr int CH2 = 512;               // tokens per workgroup chunk (backward-2)
 constexpr int TT = 32;                 // tokens per LDS tile (backward-2)
-constexpr int TW = 2 * E + 2;          // floats per staged token: q[24], dout[24], lse, D
+constexpr int TW = 2 * E + 4;          // floats per staged token: q[24], dout[24], lse, D, 2 of padding: rows stay 16-byte aligned for the float4 reads
 
 struct FGeom {
     int B, N, P, nh;
@@ -196,7 +196,7 @@ flash_bwd_kv_kernel(const unsigned short *__restrict__ q, const unsigned short *
                     const unsigned short *__restrict__ dout, const float *__restrict__ lse, const float *__restrict__ Dws,
                     float *__restrict__ dkv, FGeom g)
 {
-    __shared__ float sT[TT * TW];
+    __shared__ __attribute__((aligned(16))) float sT[TT * TW];
     const int h = blockIdx.y, b = blockIdx.z;
     const int p = threadIdx.x;
     const bool act = p < g.P;

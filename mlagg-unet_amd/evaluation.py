@@ -31,22 +31,33 @@ def confusion_matrix(pred_labels, target_labels, num_classes):
     return torch.bincount(t * num_classes + p, minlength=num_classes * num_classes).view(num_classes, num_classes)
 
 
-def hard_tp_fp_fn(logits, target):
-    """Foreground tp / fp / fn of argmax(logits) against a label map (reference :899-940, background dropped)."""
+def hard_tp_fp_fn(logits, target, ignore_label=None):
+    """Foreground tp / fp / fn of argmax(logits) against a label map (reference :899-940, background dropped).  Pixels that
+    carry ``ignore_label`` are left out of all three counts (reference B:917-929: ``mask = target != ignore``, the target is
+    zeroed there and ``get_tp_fp_fn_tn(..., mask=mask)`` multiplies every count by the mask)."""
     C = logits.shape[1]
-    cm = confusion_matrix(logits.argmax(1), target, C)
+    pred, tgt = logits.argmax(1).reshape(-1), target.reshape(-1).long()
+    if ignore_label is not None:
+        keep = tgt != int(ignore_label)
+        pred, tgt = pred[keep], tgt[keep]
+    cm = confusion_matrix(pred, tgt, C)
     tp = cm.diagonal()
     return tp[1:], (cm.sum(0) - tp)[1:], (cm.sum(1) - tp)[1:]
 
 
 @torch.no_grad()
-def validation_step(network, data, target, batch_dice=True, ddp=False):
-    """reference validation_step: {'loss', 'tp_hard', 'fp_hard', 'fn_hard'} (device tensors, no host sync)."""
+def validation_step(network, data, target, batch_dice=True, ddp=False, ignore_label=None, loss_fn=None):
+    """reference validation_step: {'loss', 'tp_hard', 'fp_hard', 'fn_hard'} (device tensors, no host sync).  ``loss_fn``:
+    the trainer's own loss (B:897 ``self.loss(output, target)``); default: the fused Dice + CE deep-supervision loss with
+    ``ignore_label`` masked inside K9."""
     output = network(data)
     if not isinstance(output, (list, tuple)):
         output, target = [output], target if isinstance(target, (list, tuple)) else [target]
-    loss = trainer.deep_supervision_loss(output, target, batch_dice=batch_dice, ddp=ddp)
-    tp, fp, fn = hard_tp_fp_fn(output[0], target[0])
+    if loss_fn is not None:
+        loss = loss_fn(output, target)
+    else:
+        loss = trainer.deep_supervision_loss(output, target, batch_dice=batch_dice, ddp=ddp, ignore_label=ignore_label)
+    tp, fp, fn = hard_tp_fp_fn(output[0], target[0], ignore_label)
     return {"loss": loss.detach(), "tp_hard": tp, "fp_hard": fp, "fn_hard": fn}
 
 

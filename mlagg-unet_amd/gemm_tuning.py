@@ -8,6 +8,7 @@ search at run time.  Worth 0.8 % of the step (228.9 -> 230.8 images/s, same box)
 was made with; PyTorch ignores it when they differ.  Regenerate with
     PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1 PYTORCH_TUNABLEOP_FILENAME=out.csv python bench.py
 """
+import atexit
 import glob
 import os
 import shutil
@@ -26,11 +27,17 @@ def use_tuned_gemms(enabled=True):
         return None
     if not torch.cuda.is_available():
         return None
-    private = os.path.join(tempfile.mkdtemp(prefix="mlagg_gemm_db_"), os.path.basename(files[0]))
-    shutil.copy(files[0], private)                    # TunableOp rewrites its file at exit: never the committed one
+    tmp = tempfile.mkdtemp(prefix="mlagg_gemm_db_")
+    atexit.register(shutil.rmtree, tmp, ignore_errors=True)
+    private = os.path.join(tmp, os.path.basename(files[0]))
+    shutil.copy(files[0], private)                    # never hand TunableOp the committed file
     tn = torch.cuda.tunable
     tn.enable(True)
     tn.tuning_enable(False)
+    tn.write_file_on_exit(False)                      # nothing is tuned here, so there is nothing to write back
     tn.set_filename(private)
-    tn.read_file(private)
+    ok = tn.read_file(private)                        # False when the Validator rows (library versions) do not match
+    if not ok or not tn.get_results():
+        tn.enable(False)
+        return None
     return private

@@ -8,6 +8,7 @@ kept next to this file; ``use_tuned_convolutions`` points MIOpen at a private co
 problems in the database get their measured-best solver, anything else falls back to MIOpen's immediate-mode
 heuristic instead of a search.  Worth 2.6 % of the step at config 2 (55.9 -> 54.5 ms).
 """
+import atexit
 import glob
 import os
 import shutil
@@ -16,6 +17,13 @@ import tempfile
 import torch
 
 DB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_db")
+TUNED_PATCH = (256, 256)          # the committed records: fp32 convolutions of the 256 x 256, batch-10 train step
+_PRIVATE = []
+
+
+def _cleanup():
+    for d in _PRIVATE:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def use_tuned_convolutions(enabled=True):
@@ -35,6 +43,9 @@ def use_tuned_convolutions(enabled=True):
         torch.backends.cudnn.benchmark = False
         return None
     private = tempfile.mkdtemp(prefix="mlagg_miopen_db_")  # per process: MIOpen rewrites the files it opens
+    if not _PRIVATE:
+        atexit.register(_cleanup)
+    _PRIVATE.append(private)
     for f in files:
         if f.endswith(".ufdb.txt"):
             # MIOpen re-validates a find-db record against its KERNEL cache, which is empty on a fresh box: the first

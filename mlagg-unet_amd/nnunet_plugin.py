@@ -48,8 +48,12 @@ def make_trainer_class(nnUNetTrainer, variant="B", precision="fp32"):
             if precision != "fp16":
                 self.grad_scaler = None
             self.mlagg_precision = precision
-            # run_training.py:123-125 sets cudnn.benchmark (MIOpen's exhaustive find); here: the committed find-db
-            miopen_tuning.use_tuned_convolutions()
+            # run_training.py:123-125 sets cudnn.benchmark (MIOpen's exhaustive find); here: the committed find-db, which
+            # holds the fp32 convolutions of the 256 x 256 step only.  Any other patch size or precision takes MIOpen's
+            # immediate-mode choice (no find, naive fallback solvers left available): a find-db miss in FAST mode with the
+            # naive solvers switched off can stall or end in "no solver found"
+            patch = tuple(int(v) for v in self.configuration_manager.patch_size)
+            miopen_tuning.use_tuned_convolutions(enabled=(precision == "fp32" and patch == miopen_tuning.TUNED_PATCH))
 
         @staticmethod
         def build_network_architecture(plans_manager, dataset_json, configuration_manager, num_input_channels,
@@ -112,9 +116,12 @@ def make_trainer_class(nnUNetTrainer, variant="B", precision="fp32"):
             return {"loss": loss.cpu().numpy()}                                     # the reference's per-step host copy
 
         def validation_step(self, batch):                                           # reference B:880-942
+            if getattr(self.label_manager, "has_regions", False):
+                return super().validation_step(batch)        # sigmoid regions (B:899-905): the reference's own body
             data, target = self._to_device(batch)
+            # B:897 evaluates self.loss; B:917-929 masks the ignore label out of tp / fp / fn
             return evaluation.validation_step(self.network, data, target, self.configuration_manager.batch_dice,
-                                              self.is_ddp)
+                                              self.is_ddp, getattr(self.label_manager, "ignore_label", None), self.loss)
 
         def on_validation_epoch_end(self, val_outputs):                             # reference B:944-978
             res = evaluation.validation_epoch_end(val_outputs)

@@ -16,7 +16,17 @@ from . import _lib
 # ------------------------------------------------------------------------------------------------
 PRECISIONS = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
 _LP_CODE = {torch.bfloat16: 1, torch.float16: 2}            # MLAGG_DTYPE_* of include/mlagg_hip.h
-_COMPUTE = [torch.float32]
+import threading as _threading
+
+
+class _ComputeStack(_threading.local):
+    """Per-thread stack (autograd's backward thread and data-loader threads never see another thread's block)."""
+
+    def __init__(self):
+        self.stack = [torch.float32]
+
+
+_COMPUTE = _ComputeStack()
 
 
 class compute_precision:
@@ -28,16 +38,16 @@ class compute_precision:
         self.dtype = PRECISIONS[precision]
 
     def __enter__(self):
-        _COMPUTE.append(self.dtype)
+        _COMPUTE.stack.append(self.dtype)
         return self
 
     def __exit__(self, *exc):
-        _COMPUTE.pop()
+        _COMPUTE.stack.pop()
         return False
 
 
 def compute_dtype():
-    return _COMPUTE[-1]
+    return _COMPUTE.stack[-1]
 
 
 def lp(t, dtype):
@@ -993,6 +1003,10 @@ class ChannelEpilogueFn(torch.autograd.Function):
         res = None if res is None else _require(res.contiguous(), "res", x.shape)
         B, C = x.shape[:2]
         hw = x.numel() // (B * C)
+        if act == EPI_GELU and x._version != 0:
+            # the GELU form overwrites x with the pre-activation WITHOUT telling autograd: only a map nothing else has
+            # written or saved in a modified state (a fresh convolution output) may be handed in
+            raise RuntimeError("channel_epilogue(GELU): x must be the fresh output of the producing call")
         y = torch.empty_like(x) if act == EPI_GELU else None
         _lib.check(_lib.lib().mlagg_channel_epilogue_fwd(_ptr(x), _ptr(bias), _ptr(res), _ptr(y), B, C, hw, int(act), _stream()),
                    "mlagg_channel_epilogue_fwd")

@@ -125,3 +125,68 @@ def test_unknown_precision_is_refused():
     from mlagg_unet_amd import nnunet_plugin
     with pytest.raises(RuntimeError):
         nnunet_plugin.make_trainer_class(FK.nnUNetTrainer, precision="int8")
+
+
+def _reference_hard_counts(logits, target, ignore_label):
+    """B:899-940 written out: one-hot of the argmax, the ignore mask applied to prediction and target, sums over batch + space."""
+    C = logits.shape[1]
+    seg = logits.argmax(1)[:, None]
+    pred = torch.zeros(logits.shape, dtype=torch.float32).scatter_(1, seg, 1)
+    tgt = target.clone()
+    if ignore_label is not None:
+        mask = (tgt != ignore_label).float()
+        tgt[tgt == ignore_label] = 0
+    else:
+        mask = torch.ones_like(tgt)
+    onehot = torch.zeros(logits.shape, dtype=torch.float32).scatter_(1, tgt.long(), 1)
+    tp = (pred * onehot * mask).sum((0, 2, 3))
+    fp = (pred * (1 - onehot) * mask).sum((0, 2, 3))
+    fn = ((1 - pred) * onehot * mask).sum((0, 2, 3))
+    return tp[1:], fp[1:], fn[1:]
+
+
+def test_validation_step_masks_the_ignore_label(plugin):
+    """B:880-942 on a partially annotated dataset: the ignore label (== number of classes) must neither crash the confusion
+    matrix nor count in tp / fp / fn, and the validation loss is the trainer's own (masked) loss."""
+    from oracle import mlagg_oracle as O
+    cls, _ = plugin
+    dj = FK.make_dataset_json(5)
+    dj["ignore_label"] = 5
+    tr = cls(FK.make_plans((32, 32), 3), "2d_bs10", 0, dj, device=torch.device("cpu"))
+    tr.initialize()
+    g = torch.Generator().manual_seed(9)
+    batch = {"data": torch.rand(3, 1, 32, 32, generator=g),
+             "target": [torch.round(torch.rand(3, 1, 32 >> s, 32 >> s, generator=g) * 5) for s in range(5)]}
+    assert (batch["target"][0] == 5).any()
+    out = tr.validation_step(batch)
+    with torch.no_grad():
+        logits = tr.network(batch["data"])
+    tp, fp, fn = _reference_hard_counts(logits[0], batch["target"][0], 5)
+    assert torch.equal(out["tp_hard"].float(), tp) and torch.equal(out["fp_hard"].float(), fp)
+    assert torch.equal(out["fn_hard"].float(), fn)
+    want = O.deep_supervision_loss(logits, batch["target"], batch_dice=tr.configuration_manager.batch_dice, ignore_label=5)
+    assert abs(float(out["loss"]) - float(want)) < 1e-6
+    # without an ignore label the counts are the plain ones
+    tr2 = cls(FK.make_plans((32, 32), 3), "2d_bs10", 0, FK.make_dataset_json(5), device=torch.device("cpu"))
+    tr2.initialize()
+    b2 = _batch(3)
+    out2 = tr2.validation_step(b2)
+    with torch.no_grad():
+        tp2, fp2, fn2 = _reference_hard_counts(tr2.network(b2["data"])[0], b2["target"][0], None)
+    assert torch.equal(out2["tp_hard"].float(), tp2) and torch.equal(out2["fn_hard"].float(), fn2)
+    assert torch.equal(out2["fp_hard"].float(), fp2)
+
+
+def test_tuned_convolution_database_is_used_only_for_the_shapes_it_holds(monkeypatch):
+    """The committed MIOpen find-db covers the fp32 256 x 256 step: any other patch size / precision must not switch to FAST
+    find mode with the naive fallback solvers off."""
+    import mlagg_unet_amd  # noqa: F401
+    from mlagg_unet_amd import miopen_tuning, model, nnunet_plugin
+    calls = []
+    monkeypatch.setattr(miopen_tuning, "use_tuned_convolutions", lambda enabled=True: calls.append(enabled))
+    monkeypatch.setattr(model, "build_network_architecture", lambda *a, **k: StubNet(1, 5))
+    for precision, patch, want in (("fp32", (256, 256), True), ("fp32", (224, 224), False), ("bf16", (256, 256), False),
+                                   ("fp16", (512, 640), False)):
+        cls = nnunet_plugin.make_trainer_class(FK.nnUNetTrainer, precision=precision)
+        cls(FK.make_plans(patch, 3), "2d_bs10", 0, FK.make_dataset_json(5), device=torch.device("cpu"))
+        assert calls[-1] is want, (precision, patch)
