@@ -279,20 +279,82 @@ def golden_msmm(M):
     print("msmm", [float(y.abs().mean()) for y in ys])
 
 
+def import_ss3d_module():
+    """The reference's UMambaEnc_SS3D.py with stand-ins for the names it imports from absent third-party packages:
+    dynamic_network_architectures' helper functions (restated: they map a dimension to torch classes), its ``BasicBlockD`` and
+    MONAI's ``MLPBlock`` (arithmetic restated in oracle/umamba3d_oracle.py -- unpinned third-party boundaries)."""
+    from oracle import umamba3d_oracle as U
+
+    class BasicBlockD(U.BasicBlockD):
+        def __init__(self, conv_op, input_channels, output_channels, kernel_size, stride, conv_bias, norm_op, norm_op_kwargs,
+                     nonlin, nonlin_kwargs):
+            assert conv_op is nn.Conv3d and input_channels == output_channels and stride == 1 and conv_bias
+            assert norm_op is nn.InstanceNorm3d and norm_op_kwargs == {"eps": 1e-5, "affine": True} and nonlin is nn.LeakyReLU
+            super().__init__(input_channels, list(kernel_size))
+
+    class MLPBlock(U.MLPBlock):
+        def __init__(self, hidden_size, mlp_dim, act, dropout_rate, dropout_mode):
+            assert act == "GELU" and dropout_rate == 0.0 and dropout_mode == "swin"
+            super().__init__(hidden_size, mlp_dim)
+
+    def scalar_to_list(conv_op, scalar):
+        return list(scalar) if isinstance(scalar, (tuple, list, np.ndarray)) else [scalar] * 3
+
+    _mod("dynamic_network_architectures.building_blocks")
+    _mod("dynamic_network_architectures.building_blocks.helper", get_matching_convtransp=lambda conv_op: nn.ConvTranspose3d,
+         convert_conv_op_to_dim=lambda conv_op: 3, get_matching_instancenorm=lambda conv_op: nn.InstanceNorm3d,
+         convert_dim_to_conv_op=lambda dim: {2: nn.Conv2d, 3: nn.Conv3d}[dim], maybe_convert_scalar_to_list=scalar_to_list,
+         get_matching_pool_op=None)
+    _mod("dynamic_network_architectures.building_blocks.residual", BasicBlockD=BasicBlockD)
+    sys.modules["monai.networks.blocks"].MLPBlock = MLPBlock
+    return importlib.import_module("nnunetv2.training.nnUNetTrainer.variants.mamba.UMambaEnc_SS3D")
+
+
+UMAMBA3D_SMALL = dict(size=(8, 64, 64), in_ch=1, n_cls=5, batch=2,
+                      strides=[[1, 1, 1], [2, 2, 2], [2, 2, 2], [2, 2, 2], [1, 2, 2], [1, 2, 2]])
+
+
+def golden_umamba3d():
+    """The reference's 3-D network (UMambaEnc of UMambaEnc_SS3D.py:815-888, built with the keyword arguments of
+    get_umamba_enc_3d_from_plans :890-942: 6 stages, features min(32 * 2^i, 320), 3x3x3 kernels, InstanceNorm3d(affine),
+    LeakyReLU, conv bias, deep supervision) on a small volume: the 5 logit maps, the base trainer's loss
+    (nnUNetTrainer.py:330-352: DC_and_CE_loss, batch_dice False as in 3d_fullres plans, weights 1/2^i normalised) and every
+    gradient norm."""
+    from oracle import umamba3d_oracle as U
+    S = import_ss3d_module()
+    c = UMAMBA3D_SMALL
+    n = len(c["strides"])
+    net = S.UMambaEnc(input_size=c["size"], input_channels=c["in_ch"], n_stages=n, features_per_stage=U.features_for(n),
+                      conv_op=nn.Conv3d, kernel_sizes=[[3, 3, 3]] * n, strides=c["strides"], n_conv_per_stage=[2] * n,
+                      num_classes=c["n_cls"], n_conv_per_stage_decoder=[2] * (n - 1), conv_bias=True, norm_op=nn.InstanceNorm3d,
+                      norm_op_kwargs={"eps": 1e-5, "affine": True}, dropout_op=None, dropout_op_kwargs=None,
+                      nonlin=nn.LeakyReLU, nonlin_kwargs={"inplace": True}, deep_supervision=True).eval()
+    O.deterministic_fill_(net.state_dict(), seed=21)
+    data, target = U.synthetic_batch_3d(c["batch"], c["in_ch"], c["size"], c["strides"], c["n_cls"], seed=77)
+    out = net(data)
+    from nnunetv2.training.loss.compound_losses import DC_and_CE_loss
+    from nnunetv2.training.loss.deep_supervision import DeepSupervisionWrapper
+    from nnunetv2.training.loss.dice import MemoryEfficientSoftDiceLoss
+    base = DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False, 'ddp': False}, {}, weight_ce=1,
+                          weight_dice=1, ignore_label=None, dice_class=MemoryEfficientSoftDiceLoss)
+    w = np.array([1 / (2 ** i) for i in range(len(out))])
+    loss = DeepSupervisionWrapper(base, w / w.sum())(out, target)
+    loss.backward()
+    names, norms = grad_summary(net)
+    keep = ("encoder.mamba_layers.0.blocks.0.self_attention.", "encoder.mamba_layers.3.blocks.0.self_attention.dt_projs",
+            "decoder.seg_layers.", "encoder.stem.0.conv1.")
+    small = {"grad/" + k: p.grad.numpy() for k, p in net.named_parameters()
+             if p.grad is not None and k.startswith(keep) and p.numel() <= 70000}
+    np.savez_compressed(os.path.join(HERE, "umamba3d_small.npz"), loss=float(loss), grad_names=np.asarray(names),
+                        grad_norms=norms, state_keys=np.asarray(sorted(net.state_dict().keys())),
+                        **{f"out{i}": o.detach().numpy() for i, o in enumerate(out)}, **small)
+    print("umamba3d", float(loss), [tuple(o.shape) for o in out], len(names), "gradients", len(net.state_dict()), "keys")
+
+
 def golden_ss3d():
     """The reference's 3-D selective-scan block SS3D (variants/mamba/UMambaEnc_SS3D.py:126-357) on a small volume: block output,
-    input gradient and every parameter gradient.  Extra stand-ins: the dynamic_network_architectures / MONAI / nnunetv2 names
-    that file imports at module level and never uses inside SS3D."""
-    class _Any:
-        def __init__(self, *a, **k):
-            pass
-    _mod("dynamic_network_architectures.building_blocks")
-    _mod("dynamic_network_architectures.building_blocks.helper", get_matching_convtransp=None, convert_conv_op_to_dim=None,
-         get_matching_instancenorm=None, convert_dim_to_conv_op=None, maybe_convert_scalar_to_list=None, get_matching_pool_op=None)
-    _mod("dynamic_network_architectures.building_blocks.residual", BasicBlockD=_Any)
-    sys.modules["monai.networks.blocks"].MLPBlock = _Any
-    _mod("nnunetv2.utilities.network_initialization", InitWeights_He=None)
-    S = importlib.import_module("nnunetv2.training.nnUNetTrainer.variants.mamba.UMambaEnc_SS3D")
+    input gradient and every parameter gradient."""
+    S = import_ss3d_module()
     blk = S.SS3D(d_model=16).eval()                            # d_inner 32, dt_rank 1, d_state 16, K = 12
     O.deterministic_fill_(blk.state_dict(), seed=12)
     g = torch.Generator().manual_seed(33)
@@ -486,6 +548,9 @@ if __name__ == "__main__":
     if "--only-ss3d" in sys.argv:
         golden_ss3d()
         sys.exit(0)
+    if "--only-umamba3d" in sys.argv:
+        golden_umamba3d()
+        sys.exit(0)
     if "--only-loss" in sys.argv:
         golden_loss()
         golden_loss_ignore()
@@ -511,3 +576,4 @@ if __name__ == "__main__":
     for tag in CONFIG_GOLDENS:
         golden_full_model_config(T, tag)
     golden_ss3d()
+    golden_umamba3d()

@@ -1,0 +1,50 @@
+"""CPU: the 3-D network oracle (oracle/umamba3d_oracle.py) against the reference's own UMambaEnc
+(variants/mamba/UMambaEnc_SS3D.py:815-888; fixture tests/golden/umamba3d_small.npz made by tests/golden/make_golden.py with the
+reference classes), and the host logic of the product's 3-D model (state_dict keys = the reference's, duplicates included)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import mlagg_oracle as O
+from oracle import umamba3d_oracle as U
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "umamba3d_small.npz")
+CFG = dict(size=(8, 64, 64), in_ch=1, n_cls=5, batch=2,
+           strides=[[1, 1, 1], [2, 2, 2], [2, 2, 2], [2, 2, 2], [1, 2, 2], [1, 2, 2]])          # make_golden.UMAMBA3D_SMALL
+
+
+def _oracle_net():
+    n = len(CFG["strides"])
+    net = U.build_reference_3d_model(CFG["in_ch"], CFG["n_cls"], U.features_for(n), CFG["strides"]).eval()
+    O.deterministic_fill_(net.state_dict(), seed=21)
+    return net
+
+
+def test_oracle_network_matches_the_reference_golden():
+    gold = np.load(GOLD)
+    net = _oracle_net()
+    assert sorted(net.state_dict().keys()) == [str(k) for k in gold["state_keys"]]          # 614 keys incl. decoder.encoder.*
+    data, target = U.synthetic_batch_3d(CFG["batch"], CFG["in_ch"], CFG["size"], CFG["strides"], CFG["n_cls"], seed=77)
+    out = net(data)
+    for i, o in enumerate(out):
+        assert float((o.detach() - torch.from_numpy(gold[f"out{i}"])).abs().max()) < 1e-4, i
+    loss = O.deep_supervision_loss(out, target, batch_dice=False)
+    assert abs(float(loss.detach()) - float(gold["loss"])) < 1e-5
+    loss.backward()
+    grads = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+    assert sorted(grads) == [str(n) for n in gold["grad_names"]]
+    for n, want in zip(gold["grad_names"], gold["grad_norms"]):
+        got = float(grads[str(n)].double().norm())
+        assert abs(got - want) <= 1e-3 * want + 2e-6, (str(n), got, want)     # conv biases in front of an InstanceNorm: exact gradient 0, rounding noise ~4e-7
+    for k in gold.files:
+        if k.startswith("grad/"):
+            g = grads[k[5:]]
+            assert float((g - torch.from_numpy(gold[k])).abs().max()) <= 1e-3 * float(np.abs(gold[k]).max()) + 1e-8, k
+
+
+def test_deep_supervision_scales_and_targets_follow_the_pooling_strides():
+    sc = U.deep_supervision_scales(CFG["strides"])
+    assert len(sc) == 5 and sc[0] == [1.0, 1.0, 1.0] and sc[4] == [1 / 8, 1 / 16, 1 / 16]
+    _, target = U.synthetic_batch_3d(1, 1, CFG["size"], CFG["strides"], 5)
+    assert [tuple(t.shape[2:]) for t in target] == [(8, 64, 64), (4, 32, 32), (2, 16, 16), (1, 8, 8), (1, 4, 4)]
