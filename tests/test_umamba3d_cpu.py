@@ -40,7 +40,7 @@ def test_oracle_network_matches_the_reference_golden():
     for k in gold.files:
         if k.startswith("grad/"):
             g = grads[k[5:]]
-            assert float((g - torch.from_numpy(gold[k])).abs().max()) <= 1e-3 * float(np.abs(gold[k]).max()) + 1e-8, k
+            assert float((g - torch.from_numpy(gold[k])).abs().max()) <= 1e-3 * float(np.abs(gold[k]).max()) + 2e-6, k
 
 
 def test_deep_supervision_scales_and_targets_follow_the_pooling_strides():
