@@ -301,6 +301,34 @@ int mlagg_index_merge(const float *seq, const int *idx, float *tok, long tok_str
 int mlagg_block_sum(const float *wide, float *out, long rows, int K, int CB, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K1s: selective scan with ONE state per channel on token-major volumes, scan orders applied inside the kernels.
+ * Replaces, for the reference's 3-D network (variants/mamba/UMambaEnc_SS3D.py: `SS3D` built with d_state = 1 at :640-655),
+ * everything of `SS3D.forward_corev0` (:244-296) behind x_proj: the copies that build the K = 12 scan sequences of u
+ * (:251-259), the dt einsum (:264), `selective_scan_fn(xs, dts, As, Bs, Cs, Ds, z=None, delta_bias, delta_softplus=True)`
+ * (:277-283) and the inverse permutations (:285-296); the caller finishes `torch.sum(y, dim=1)` (:338) with mlagg_block_sum.
+ *   tok   (B, L, C) conv output u in natural (d, h, w) token order, rows of tok_stride floats; C % 64 == 0
+ *   idx   (K, L) int32: token visited at step l of direction k
+ *   dtr   (B, K, R, L), Bs, Cs (B, K, L): x_proj's output in scan order (mlagg_index_scan); R in {1, 2, 3, 4, 8, 16, 20}
+ *   Wdt   (K*C, R) dt_projs_weight; A (K*C) = -exp(A_logs); D (K*C); bias (K*C) dt_projs_bias
+ *   yk    (B, L, K, C): y of direction k at the natural position of its token
+ *   state saved for backward, mlagg_selscan1_state_floats() floats: chunk-entry states, chunk sums of delta, states entering
+ *         every 16-step tile
+ * Backward: dout (B, L, C) (rows of dout_stride floats) = gradient of the K-way sum; writes duk (B, L, K, C) (the caller sums the
+ * K blocks), ddtr / dBs / dCs in scan order, and dparams (K*C, 3 + R) = [dA | dD | dbias | dWdt] per channel.
+ * mlagg_selscan1_chunk: the chunk length the kernels cut L into (diagnostics).
+ * ------------------------------------------------------------------------------------------ */
+int mlagg_selscan1_chunk(int B, int L, int K);
+size_t mlagg_selscan1_state_floats(int B, int L, int C, int K);
+int mlagg_selscan1_fwd(const float *tok, long tok_stride, const int *idx, const float *dtr, const float *Bs, const float *Cs,
+                       const float *Wdt, int R, const float *A, const float *D, const float *bias, float *yk, float *state,
+                       int B, int L, int C, int K, void *stream);
+size_t mlagg_selscan1_bwd_workspace_floats(int B, int L, int C, int K, int R);
+int mlagg_selscan1_bwd(const float *tok, long tok_stride, const int *idx, const float *dtr, const float *Bs, const float *Cs,
+                       const float *Wdt, int R, const float *A, const float *D, const float *bias, const float *dout,
+                       long dout_stride, const float *state, float *duk, float *ddtr, float *dBs, float *dCs, float *dparams,
+                       float *workspace, int B, int L, int C, int K, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * K13: epilogue of the library convolutions on NCHW maps (B, C, HW): y = act(x + bias[c] + res), act 0 = none (in place on
  * x, y ignored), 1 = GELU (erf form; x is overwritten with the pre-activation, y receives the result).  Replaces the
  * bias add / GELU / residual add chain behind the convolutions of MedNeXtBlock, MedNeXtDownBlock, PatchExpand and project

@@ -85,6 +85,11 @@ SIGNATURES = {
     "mlagg_index_scan": (_I, [_F, ctypes.c_long, _I, _F, _F, _I, _I, _I, _I, _S]),
     "mlagg_index_merge": (_I, [_F, _F, _F, ctypes.c_long, _I, _I, _I, _I, _I, _S]),
     "mlagg_block_sum": (_I, [_F, _F, ctypes.c_long, _I, _I, _S]),
+    "mlagg_selscan1_chunk": (_I, [_I, _I, _I]),
+    "mlagg_selscan1_state_floats": (_SZ, [_I, _I, _I, _I]),
+    "mlagg_selscan1_fwd": (_I, [_F, ctypes.c_long] + [_F] * 5 + [_I] + [_F] * 5 + [_I] * 4 + [_S]),
+    "mlagg_selscan1_bwd_workspace_floats": (_SZ, [_I, _I, _I, _I, _I]),
+    "mlagg_selscan1_bwd": (_I, [_F, ctypes.c_long] + [_F] * 5 + [_I] + [_F] * 4 + [ctypes.c_long] + [_F] * 7 + [_I] * 4 + [_S]),
 }
 
 _lib = None

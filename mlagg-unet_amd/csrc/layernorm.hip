@@ -19,7 +19,6 @@
 
 namespace {
 
-constexpr int F4 = 3;               // float4 per lane and row
 constexpr int BLOCK = 256;
 
 template <int LPR>
@@ -30,7 +29,7 @@ __device__ __forceinline__ float group_sum(float v)
     return v;
 }
 
-template <int LPR>
+template <int LPR, int F4>
 __global__ void __launch_bounds__(BLOCK)
 layernorm_fwd_kernel(const float *__restrict__ x, int x_stride, const float *__restrict__ gamma,
                      const float *__restrict__ beta, float *__restrict__ y, float *__restrict__ stats, int rows,
@@ -72,7 +71,7 @@ layernorm_fwd_kernel(const float *__restrict__ x, int x_stride, const float *__r
     }
 }
 
-template <int LPR>
+template <int LPR, int F4>
 __global__ void __launch_bounds__(BLOCK)
 layernorm_bwd_kernel(const float *__restrict__ x, int x_stride, const float *__restrict__ dy, int dy_stride,
                      const float *__restrict__ gamma, const float *__restrict__ stats, float *__restrict__ dx,
@@ -128,19 +127,52 @@ layernorm_bwd_kernel(const float *__restrict__ x, int x_stride, const float *__r
     }
 }
 
-inline int lanes_per_row(int C)
+// C -> (lanes per row, float4 per lane): a row is owned by a power-of-two lane group.  C = 12 * lanes (48 .. 768: the 2-D MLAgg
+// network), the power-of-two and 5 * 64-multiples of the 3-D network (32 .. 640: UMambaEnc_SS3D.py features and 2x expansions)
+struct RowShape { int lpr, f4; };
+inline RowShape row_shape(int C)
 {
-    if (C % 12) return 0;
-    const int l = C / 12;
-    return (l == 4 || l == 8 || l == 16 || l == 32 || l == 64) ? l : 0;
+    switch (C) {
+    case 48: return {4, 3};
+    case 96: return {8, 3};
+    case 192: return {16, 3};
+    case 384: return {32, 3};
+    case 768: return {64, 3};
+    case 32: return {8, 1};
+    case 64: return {16, 1};
+    case 128: return {32, 1};
+    case 256: return {64, 1};
+    case 512: return {64, 2};
+    case 320: return {16, 5};
+    case 640: return {32, 5};
+    default: return {0, 0};
+    }
 }
+inline int lanes_per_row(int C) { return row_shape(C).lpr; }
 
-inline int grid_blocks(int rows, int lpr)
+inline int grid_blocks(long rows, int lpr)
 {
     const int rpb = BLOCK / lpr;
-    long need = ((long)rows + rpb - 1) / rpb;
+    long need = (rows + rpb - 1) / rpb;
     return (int)(need < 1024 ? need : 1024);       // grid-stride beyond 4 workgroups per CU
 }
+
+#define MLAGG_LN_DISPATCH(C, MACRO)                                                                                   \
+    switch (C) {                                                                                                      \
+    case 48: MACRO(4, 3); break;                                                                                      \
+    case 96: MACRO(8, 3); break;                                                                                      \
+    case 192: MACRO(16, 3); break;                                                                                    \
+    case 384: MACRO(32, 3); break;                                                                                    \
+    case 768: MACRO(64, 3); break;                                                                                    \
+    case 32: MACRO(8, 1); break;                                                                                      \
+    case 64: MACRO(16, 1); break;                                                                                     \
+    case 128: MACRO(32, 1); break;                                                                                    \
+    case 256: MACRO(64, 1); break;                                                                                    \
+    case 512: MACRO(64, 2); break;                                                                                    \
+    case 320: MACRO(16, 5); break;                                                                                    \
+    case 640: MACRO(32, 5); break;                                                                                    \
+    default: return MLAGG_E_UNSUPPORTED;                                                                              \
+    }
 
 }  // namespace
 
@@ -161,13 +193,9 @@ extern "C" int mlagg_layernorm_fwd(const float *x, int x_stride, const float *ga
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(grid_blocks(rows, lpr)), block(BLOCK);
     MLAGG_TIMED(K_LAYERNORM_FWD, st);
-    switch (lpr) {
-    case 4: hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, block, 0, st, x, x_stride, gamma, beta, y, stats, rows, eps); break;
-    case 8: hipLaunchKernelGGL(layernorm_fwd_kernel<8>, grid, block, 0, st, x, x_stride, gamma, beta, y, stats, rows, eps); break;
-    case 16: hipLaunchKernelGGL(layernorm_fwd_kernel<16>, grid, block, 0, st, x, x_stride, gamma, beta, y, stats, rows, eps); break;
-    case 32: hipLaunchKernelGGL(layernorm_fwd_kernel<32>, grid, block, 0, st, x, x_stride, gamma, beta, y, stats, rows, eps); break;
-    default: hipLaunchKernelGGL(layernorm_fwd_kernel<64>, grid, block, 0, st, x, x_stride, gamma, beta, y, stats, rows, eps); break;
-    }
+#define MLAGG_LN_FWD(LPR, F4) hipLaunchKernelGGL((layernorm_fwd_kernel<LPR, F4>), grid, block, 0, st, x, x_stride, gamma, beta, y, stats, rows, eps)
+    MLAGG_LN_DISPATCH(C, MLAGG_LN_FWD)
+#undef MLAGG_LN_FWD
     return (int)hipGetLastError();
 }
 
@@ -184,13 +212,9 @@ extern "C" int mlagg_layernorm_bwd(const float *x, int x_stride, const float *dy
     const dim3 grid(nb), block(BLOCK);
     {
         MLAGG_TIMED(K_LAYERNORM_BWD, st);
-        switch (lpr) {
-        case 4: hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, st, x, x_stride, dy, dy_stride, gamma, stats, dx, workspace, rows); break;
-        case 8: hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, block, 0, st, x, x_stride, dy, dy_stride, gamma, stats, dx, workspace, rows); break;
-        case 16: hipLaunchKernelGGL(layernorm_bwd_kernel<16>, grid, block, 0, st, x, x_stride, dy, dy_stride, gamma, stats, dx, workspace, rows); break;
-        case 32: hipLaunchKernelGGL(layernorm_bwd_kernel<32>, grid, block, 0, st, x, x_stride, dy, dy_stride, gamma, stats, dx, workspace, rows); break;
-        default: hipLaunchKernelGGL(layernorm_bwd_kernel<64>, grid, block, 0, st, x, x_stride, dy, dy_stride, gamma, stats, dx, workspace, rows); break;
-        }
+#define MLAGG_LN_BWD(LPR, F4) hipLaunchKernelGGL((layernorm_bwd_kernel<LPR, F4>), grid, block, 0, st, x, x_stride, dy, dy_stride, gamma, stats, dx, workspace, rows)
+        MLAGG_LN_DISPATCH(C, MLAGG_LN_BWD)
+#undef MLAGG_LN_BWD
     }
     // partial rows are [d(gamma) | d(beta)]: column sums of an (nb x 2C) matrix
     hipLaunchKernelGGL(mlagg_internal::column_sum_split_kernel<0>, dim3((2 * C + 63) / 64), dim3(1024), 0, st, workspace, nb,

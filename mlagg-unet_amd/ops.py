@@ -277,6 +277,57 @@ def dwconv3d_nlc(x, weight, bias, dims, silu=False):
     return DWConv3dFn.apply(x, weight, bias, dims, silu)
 
 
+class SelectiveScan1Fn(torch.autograd.Function):
+    """K1s: the d_state = 1 selective scan of the 3-D network (UMambaEnc_SS3D.py:244-296 + the 12-way sum at :338) on the
+    token-major volume: u is gathered and y scattered through the permutation table inside the kernels.
+    tok (B, L, C), idx (K, L) int32, dtr (B, K, R, L), Bs / Cs (B, K, L), Wdt (K*C, R), A / D / bias (K*C) -> (B, L, C)."""
+
+    @staticmethod
+    def forward(ctx, tok, idx, dtr, Bs, Cs, Wdt, A, D, bias):
+        tok, ts = _rows(tok, "tok")
+        B, L, C = tok.shape
+        K, R = idx.shape[0], dtr.shape[2]
+        if idx.dtype != torch.int32 or tuple(idx.shape) != (K, L) or not idx.is_cuda:
+            raise RuntimeError("selective_scan1: idx must be an int32 (K, L) device table")
+        dtr = _require(dtr.contiguous(), "dtr", (B, K, R, L))
+        Bs = _require(Bs.contiguous(), "Bs", (B, K, L))
+        Cs = _require(Cs.contiguous(), "Cs", (B, K, L))
+        Wdt = _require(Wdt.contiguous(), "Wdt", (K * C, R))
+        A, D, bias = (_require(v.reshape(-1).contiguous(), n, (K * C,)) for v, n in ((A, "A"), (D, "D"), (bias, "delta_bias")))
+        lib = _lib.lib()
+        yk = torch.empty(B, L, K * C, device=tok.device, dtype=torch.float32)
+        state = torch.empty(lib.mlagg_selscan1_state_floats(B, L, C, K), device=tok.device, dtype=torch.float32)
+        _lib.check(lib.mlagg_selscan1_fwd(_ptr(tok), ts, _ptr(idx), _ptr(dtr), _ptr(Bs), _ptr(Cs), _ptr(Wdt), R, _ptr(A), _ptr(D),
+                                          _ptr(bias), _ptr(yk), _ptr(state), B, L, C, K, _stream()), "mlagg_selscan1_fwd")
+        y = torch.empty(B, L, C, device=tok.device, dtype=torch.float32)
+        _lib.check(lib.mlagg_block_sum(_ptr(yk), _ptr(y), B * L, K, C, _stream()), "mlagg_block_sum")
+        ctx.save_for_backward(tok, idx, dtr, Bs, Cs, Wdt, A, D, bias, state)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        tok, idx, dtr, Bs, Cs, Wdt, A, D, bias, state = ctx.saved_tensors
+        B, L, C = tok.shape
+        K, R = idx.shape[0], dtr.shape[2]
+        dy, ds = _rows(dy, "dy")
+        lib = _lib.lib()
+        dev = tok.device
+        duk = torch.empty(B, L, K * C, device=dev, dtype=torch.float32)
+        ddtr, dBs, dCs = torch.empty_like(dtr), torch.empty_like(Bs), torch.empty_like(Cs)
+        dpar = torch.empty(K * C, 3 + R, device=dev, dtype=torch.float32)
+        ws = torch.empty(lib.mlagg_selscan1_bwd_workspace_floats(B, L, C, K, R), device=dev, dtype=torch.float32)
+        _lib.check(lib.mlagg_selscan1_bwd(_ptr(tok), tok.stride(1), _ptr(idx), _ptr(dtr), _ptr(Bs), _ptr(Cs), _ptr(Wdt), R, _ptr(A),
+                                          _ptr(D), _ptr(bias), _ptr(dy), ds, _ptr(state), _ptr(duk), _ptr(ddtr), _ptr(dBs), _ptr(dCs),
+                                          _ptr(dpar), _ptr(ws), B, L, C, K, _stream()), "mlagg_selscan1_bwd")
+        dtok = torch.empty(B, L, C, device=dev, dtype=torch.float32)
+        _lib.check(lib.mlagg_block_sum(_ptr(duk), _ptr(dtok), B * L, K, C, _stream()), "mlagg_block_sum")
+        return dtok, None, ddtr, dBs, dCs, dpar[:, 3:], dpar[:, 0], dpar[:, 1], dpar[:, 2]
+
+
+def selective_scan1(tok, idx, dtr, Bs, Cs, Wdt, A, D, bias):
+    return SelectiveScan1Fn.apply(tok, idx, dtr, Bs, Cs, Wdt, A, D, bias)
+
+
 class LocalDiffAttnFn(torch.autograd.Function):
     """K3: fused 3x3-window differential attention + RMSNorm + LePE (AggregatedAttention local branch)."""
 
