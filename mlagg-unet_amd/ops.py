@@ -818,6 +818,53 @@ class IndexMergeFn(torch.autograd.Function):
         return dseq, None, None
 
 
+class IndexScanBCFn(torch.autograd.Function):
+    """The single consumer of the token-major x_proj output of the d_state = 1 blocks, (B, L, K * (R + 2)) split per direction as
+    [dt (R) | B | C] (UMambaEnc_SS3D.py:262-263): scan-order rows dtr (B, K, R, L), Bs (B, K, L), Cs (B, K, L).  One backward
+    assembles the whole x_proj gradient (every column is written: no zero-fill, no per-slice accumulation)."""
+
+    @staticmethod
+    def forward(ctx, xdbl, idx, R):
+        xdbl = _require(xdbl.contiguous(), "x_dbl")
+        B, L, width = xdbl.shape
+        K, per = idx.shape[0], R + 2
+        if width != K * per or idx.dtype != torch.int32 or tuple(idx.shape) != (K, L) or not idx.is_cuda:
+            raise RuntimeError("index_scan_bc: x_dbl must be (B, L, K * (R + 2)) and idx an int32 (K, L) device table")
+        lib = _lib.lib()
+        dtr = torch.empty(B, K * R, L, device=xdbl.device, dtype=torch.float32)
+        bc = torch.empty(2, B, K, L, device=xdbl.device, dtype=torch.float32)
+        base = xdbl.data_ptr()
+        _lib.check(lib.mlagg_index_scan(base, width, per, _ptr(idx), _ptr(dtr), B, L, K, R, _stream()), "mlagg_index_scan")
+        _lib.check(lib.mlagg_index_scan(base + 4 * R, width, per, _ptr(idx), _ptr(bc[0]), B, L, K, 1, _stream()), "mlagg_index_scan")
+        _lib.check(lib.mlagg_index_scan(base + 4 * (R + 1), width, per, _ptr(idx), _ptr(bc[1]), B, L, K, 1, _stream()),
+                   "mlagg_index_scan")
+        ctx.save_for_backward(idx)
+        ctx.meta = (R, width)
+        return dtr.view(B, K, R, L), bc[0], bc[1]
+
+    @staticmethod
+    def backward(ctx, ddtr, dBs, dCs):
+        (idx,) = ctx.saved_tensors
+        R, width = ctx.meta
+        per = R + 2
+        ddtr = _require(ddtr.contiguous(), "ddtr")
+        dBs = _require(dBs.contiguous(), "dBs")
+        dCs = _require(dCs.contiguous(), "dCs")
+        B, K, _, L = ddtr.shape
+        lib = _lib.lib()
+        dx = torch.empty(B, L, width, device=ddtr.device, dtype=torch.float32)
+        base = dx.data_ptr()
+        _lib.check(lib.mlagg_index_merge(_ptr(ddtr), _ptr(idx), base, width, per, B, L, K, R, _stream()), "mlagg_index_merge")
+        _lib.check(lib.mlagg_index_merge(_ptr(dBs), _ptr(idx), base + 4 * R, width, per, B, L, K, 1, _stream()), "mlagg_index_merge")
+        _lib.check(lib.mlagg_index_merge(_ptr(dCs), _ptr(idx), base + 4 * (R + 1), width, per, B, L, K, 1, _stream()),
+                   "mlagg_index_merge")
+        return dx, None, None
+
+
+def index_scan_bc(xdbl, idx, R):
+    return IndexScanBCFn.apply(xdbl, idx, R)
+
+
 def index_scan(tok, idx, CB, blk=0, col0=0):
     return IndexScanFn.apply(tok, idx, CB, blk, col0)
 

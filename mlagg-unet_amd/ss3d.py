@@ -43,8 +43,16 @@ class SS3D(nn.Module):
         self.d_model, self.d_state = d_model, d_state
         self.d_inner = int(expand * d_model)
         self.dt_rank = math.ceil(d_model / 16) if dt_rank == "auto" else dt_rank
-        if d_state != 16 or self.dt_rank > 4 or self.d_inner > 96:
-            raise RuntimeError("SS3D on MI355X: d_state 16, dt_rank <= 4 and d_inner <= 96 (the K1 kernels' build)")
+        if d_state == 16:
+            if self.dt_rank > 4 or self.d_inner > 96:
+                raise RuntimeError("SS3D on MI355X, d_state 16: dt_rank <= 4 and d_inner <= 96 (the K1 kernels' build)")
+        elif d_state == 1:
+            # the 3-D network's blocks (UMambaEnc_SS3D.py:640-655): K1s, csrc/selscan1.hip
+            if self.d_inner % 64 or self.dt_rank not in (1, 2, 3, 4, 8, 16, 20):
+                raise RuntimeError("SS3D on MI355X, d_state 1: d_inner a multiple of 64 and dt_rank in {1, 2, 3, 4, 8, 16, 20} "
+                                   "(the K1s kernels' build)")
+        else:
+            raise RuntimeError("SS3D on MI355X: d_state 16 (K1) or 1 (K1s)")
         self.in_proj = Linear(d_model, self.d_inner, bias=bias)
         self.conv3d = nn.Conv3d(self.d_inner, self.d_inner, d_conv, padding=(d_conv - 1) // 2, groups=self.d_inner, bias=conv_bias)
         K = 12
@@ -67,6 +75,12 @@ class SS3D(nn.Module):
         per = R + 2 * N
         idx = scan_orders_3d(*dims, tok.device)
         xdbl = ops.linear(tok, self.x_proj_weight.reshape(K * per, dI))                    # (B, L, 12 * per)
+        if N == 1:
+            # K1s: u is gathered and y scattered through `idx` inside the scan kernels; only the narrow x_proj columns
+            # (R + 2 floats per token and direction) are re-ordered up front
+            dtr, Bs, Cs = ops.index_scan_bc(xdbl, idx, R)
+            return ops.selective_scan1(tok, idx, dtr, Bs, Cs, self.dt_projs_weight.reshape(K * dI, R),
+                                       -torch.exp(self.A_logs).reshape(-1), self.Ds, self.dt_projs_bias.reshape(-1))
         dtr = ops.index_scan(xdbl, idx, R, per, 0).view(B, K, R, L)
         Bs = ops.index_scan(xdbl, idx, N, per, R).view(B, K, N, L)
         Cs = ops.index_scan(xdbl, idx, N, per, R + N).view(B, K, N, L)
@@ -84,7 +98,15 @@ class SS3D(nn.Module):
             # the strided view `h.transpose(1, 2)`, PyTorch takes the volume for channels_last_3d and MIOpen runs a far slower
             # path still: the block took 19.0 ms per forward + backward at 2 x 24 x 40 x 40 tokens; with real transposes
             # around MIOpen's naive depthwise kernels 6.8 ms)
-            tok = ops.dwconv3d_nlc(h, self.conv3d.weight, self.conv3d.bias, (D, H, W), silu=True)
+            if self.d_inner * 27 * 4 > 64 * 1024:
+                # K2v stages a (C, 27) weight tile in LDS: wider maps (640 channels at the two deepest, tiny stages of the
+                # 3-D network) go through it in two channel halves
+                hc = self.d_inner // 2
+                w, bias = self.conv3d.weight, self.conv3d.bias
+                tok = torch.cat([ops.dwconv3d_nlc(h[..., :hc], w[:hc], None if bias is None else bias[:hc], (D, H, W), silu=True),
+                                 ops.dwconv3d_nlc(h[..., hc:], w[hc:], None if bias is None else bias[hc:], (D, H, W), silu=True)], -1)
+            else:
+                tok = ops.dwconv3d_nlc(h, self.conv3d.weight, self.conv3d.bias, (D, H, W), silu=True)
         else:
             vol = F.silu(self.conv3d(h.transpose(1, 2).reshape(B, self.d_inner, D, H, W)))
             tok = vol.reshape(B, self.d_inner, -1).transpose(1, 2).contiguous()

@@ -200,7 +200,10 @@ def test_linear_wgrad_matches_torch(M, O, I, bias):
 
 @gpu
 @pytest.mark.parametrize("rows,C,strided", [(1000, 48, False), (4097, 96, True), (513, 192, False), (130, 384, True),
-                                             (77, 768, False), (5, 96, False)])
+                                             (77, 768, False), (5, 96, False),
+                                             # the widths of the 3-D network (UMambaEnc_SS3D.py features and their 2x expansions)
+                                             (3000, 32, False), (1025, 64, True), (700, 128, False), (300, 256, True),
+                                             (129, 320, False), (65, 512, False), (33, 640, True)])
 def test_layernorm_matches_torch(rows, C, strided):
     from mlagg_unet_amd import ops
     g = torch.Generator().manual_seed(rows + C)

@@ -4,6 +4,7 @@ reference classes), and the host logic of the product's 3-D model (state_dict ke
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import mlagg_oracle as O
@@ -48,3 +49,24 @@ def test_deep_supervision_scales_and_targets_follow_the_pooling_strides():
     assert len(sc) == 5 and sc[0] == [1.0, 1.0, 1.0] and sc[4] == [1 / 8, 1 / 16, 1 / 16]
     _, target = U.synthetic_batch_3d(1, 1, CFG["size"], CFG["strides"], 5)
     assert [tuple(t.shape[2:]) for t in target] == [(8, 64, 64), (4, 32, 32), (2, 16, 16), (1, 8, 8), (1, 4, 4)]
+
+
+def test_product_3d_network_has_the_reference_checkpoint_keys():
+    """Module / parameter names are the checkpoint ABI: the product's UMambaEnc must expose exactly the reference's 614 keys (the
+    ``decoder.encoder.*`` and ``all_modules.*`` duplicates included) with the reference's shapes."""
+    import mlagg_unet_amd  # noqa: F401
+    from mlagg_unet_amd import model3d
+    gold = np.load(GOLD)
+    n = len(CFG["strides"])
+    net = model3d.build_network_architecture_3d(CFG["in_ch"], CFG["n_cls"], [[3, 3, 3]] * n, CFG["strides"], [2] * n, [2] * (n - 1))
+    sd = net.state_dict()
+    assert sorted(sd.keys()) == [str(k) for k in gold["state_keys"]]
+    ref = _oracle_net().state_dict()
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(ref[k].shape), k
+    assert sum(p.numel() for p in net.parameters()) == sum(p.numel() for p in _oracle_net().parameters())
+    assert model3d.deep_supervision_scales(CFG["strides"]) == U.deep_supervision_scales(CFG["strides"])
+    net.deep_supervision = False
+    assert net.decoder.deep_supervision is False
+    with pytest.raises(RuntimeError):                        # the device ops have no host path
+        net(torch.zeros(1, 1, 8, 64, 64))
