@@ -34,6 +34,9 @@ CONFIGS = {
             name="AbdomenMRI-shaped 256x256x1, 14 classes, attention variant B (BASELINE.json configs[1])"),
     3: dict(img=(224, 224), in_ch=1, classes=4, batch=10, variant="B", precision="bf16", dtype="bf16",
             name="ACDC-shaped 224x224x1, 4 classes, attention variant B, bf16 operands / fp32 sums (BASELINE.json configs[2])"),
+    4: dict(img=(96, 160, 160), in_ch=1, classes=14, batch=2, variant=None, precision="fp32", dtype="f32",
+            name="BTCV-shaped 96x160x160 patches, 14 classes, 3-D network with 12-direction selective scans "
+                 "(UMambaEnc_SS3D design source; BASELINE.json configs[3])"),
     5: dict(img=(512, 640), in_ch=3, classes=8, batch=4, variant="A", precision="fp16", dtype="f16",
             name="Endovis17-shaped 512x640x3, 8 classes, shipped flash scaling (variant A), fp16 operands / fp32 sums + "
                  "GradScaler (BASELINE.json configs[4])"),
@@ -98,6 +101,123 @@ def cpu_baseline(budget_s=40.0):
     return {"value": round(value, 5), "unit": "images/sec", "cores": cores, "kind": "port", "sample": sample}
 
 
+def cpu_baseline_3d(size, strides, n_cls, budget_s=40.0):
+    """The CPU oracle of the 3-D network (oracle/umamba3d_oracle.py, torch eager, Python-loop scan) on a bounded sample: one
+    warm-up + one timed train step (forward, loss, backward, SGD) at batch 1 of a 1/240 volume (8 x 32 x 32: every stage keeps
+    more than one voxel), scaled to the full patch by the voxel ratio (the work is linear in the voxel count)."""
+    from oracle import mlagg_oracle as O
+    from oracle import umamba3d_oracle as U
+    cores = host_threads()
+    torch.set_num_threads(cores)
+    small = (8, 32, 32)
+    sm_strides = [[1, 1, 1], [2, 2, 2], [2, 2, 2], [2, 2, 2], [1, 2, 2], [1, 1, 1]]
+    torch.manual_seed(0)
+    net = U.build_reference_3d_model(1, n_cls, U.features_for(len(strides)), sm_strides).train()
+    opt = torch.optim.SGD(net.parameters(), 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+    data, target = U.synthetic_batch_3d(1, 1, small, sm_strides, n_cls)
+
+    def step():
+        opt.zero_grad()
+        loss = O.deep_supervision_loss(net(data), target, batch_dice=False)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 12)
+        opt.step()
+
+    step()
+    t0 = time.perf_counter()
+    step()
+    dt = time.perf_counter() - t0
+    ratio = (size[0] * size[1] * size[2]) / float(small[0] * small[1] * small[2])
+    return {"value": round(1.0 / (dt * ratio), 6), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"1 warm-up + 1 timed train step at batch 1 of an {small[0]}x{small[1]}x{small[2]} volume: {dt:.2f} s, scaled by "
+                      f"the voxel ratio {ratio:.0f} to {size[0]}x{size[1]}x{size[2]} patches; torch eager fp32, {cores} threads"}
+
+
+def main_3d(args, cfg, world, rank, dev, dev_index, ddp):
+    """BASELINE configs[3]: train step of the 3-D network (model3d.UMambaEnc) with the base trainer's recipe
+    (nnUNetTrainer.py:330-352 loss with batch_dice False as 3d_fullres plans set it, :448-452 SGD momentum 0.99 Nesterov,
+    :855-857 clip 12), patches resident in HBM.  Never the headline."""
+    import mlagg_unet_amd  # noqa: F401
+    from mlagg_unet_amd import _lib, miopen_tuning, model3d, profiling, trainer
+    _lib.lib()
+    miopen_tuning.use_tuned_convolutions(enabled=os.environ.get("MLAGG_BENCH_MIOPEN", "auto") == "find")
+    size, strides = tuple(cfg["img"]), model3d.BTCV_STRIDES
+    n = len(strides)
+    torch.manual_seed(0)
+    net = model3d.build_network_architecture_3d(cfg["in_ch"], cfg["classes"], [[3, 3, 3]] * n, strides, [2] * n, [2] * (n - 1))
+    net = net.to(dev).train()
+    opt = torch.optim.SGD(net.parameters(), 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+    step_net = trainer.wrap_ddp(net, dev_index) if ddp else net
+    data, target = model3d.synthetic_batch_3d(args.batch, cfg["in_ch"], size, strides, cfg["classes"], seed=1234 + rank, device=dev)
+
+    def one_step():
+        return trainer.train_step(step_net, opt, data, target, batch_dice=False, ddp=ddp)
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    for i in range(args.warmup):
+        one_step()
+        torch.cuda.synchronize()
+        note(f"warm-up step {i + 1}/{args.warmup} done ({torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB peak)")
+    tokens = size[0] * size[1] * size[2]
+    dominant, table, fixed = None, {}, []
+    if not args.no_roofline:
+        profiling.select_all()
+        one_step()
+        table = profiling.collect()
+        fixed = [k for k in table if profiling.algorithmic_bytes_sel1(k, args.batch, tokens) > 0]
+        dominant = max(fixed, key=lambda k: table[k]["ms"]) if fixed else None
+        profiling.select(dominant)
+    if ddp:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    if ddp:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if ddp:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    roof = None
+    if dominant is not None:
+        res = profiling.collect()[dominant]
+        avg_ms = res["ms"] / max(res["count"], 1)
+        alg = profiling.algorithmic_bytes_sel1(dominant, args.batch, tokens)
+        achieved = alg / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                "launches_timed": res["count"], "algorithmic_bytes_per_launch": alg,
+                "shape": f"stage 0: batch {args.batch} x {tokens} tokens x 64 channels x 12 directions, rank 2, one state",
+                "fixed_shape_kernels": {
+                    k: {"ms_per_launch": round(table[k]["ms"] / table[k]["count"], 4),
+                        "achieved_GBs": round(profiling.algorithmic_bytes_sel1(k, args.batch, tokens)
+                                              / (table[k]["ms"] / table[k]["count"] * 1e-3) / 1e9, 1)} for k in sorted(fixed)},
+                "all_kernels_ms_per_step": {k: round(v["ms"], 3) for k, v in sorted(table.items())}}
+        profiling.select(None)
+    if rank == 0:
+        n_img = args.batch * world * args.steps
+        line = {"metric": f"images/sec (train step) 3-D network {size[0]}x{size[1]}x{size[2]} bs{args.batch}",
+                "value": round(n_img / dt, 4), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": cfg["dtype"], "data": "synthetic",
+                "config": {"workload": "nnUNetTrainerUMambaEnc_SS3D train step (SGD momentum 0.99 Nesterov, clip 12), " + cfg["name"],
+                           "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                           "final_loss": round(float(loss), 5), "launch": "eager", "miopen": "immediate mode",
+                           "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
+                "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_3d(size, strides, cfg["classes"])
+        print(json.dumps(line), flush=True)
+    if ddp:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,6 +263,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
         else:
             dist.init_process_group(backend)
+
+    if args.config == 4:
+        return main_3d(args, cfg, world, rank, dev, dev_index, ddp)
 
     import mlagg_unet_amd  # noqa: F401
     from mlagg_unet_amd import _lib, gemm_tuning, miopen_tuning, model, profiling, trainer

@@ -378,6 +378,27 @@ int mlagg_plane_norm_bwd(const float *x, const float *dy, const float *gamma, co
                          long HW, int act, float slope, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K15: weight gradient of the full convolutions on channel-major maps as tap GEMMs on the fp32 matrix cores.  Replaces MIOpen's
+ * weight-gradient solvers behind the backward of `nn.Conv3d` / `nn.Conv2d` (kernel 3 with padding 1, or kernel 1; stride 1 or 2) of
+ * the 3-D network's BasicResBlock / BasicBlockD / UpsampleLayer / seg layers (variants/mamba/UMambaEnc_SS3D.py:49-66, 477-513,
+ * 589-637, 744-779) and of the 2-D network's 3x3 / 1x1 convolutions (nnUNetTrainer_MLAgg_2D_dt_MS.py:976-977, 278-296; MambaSkip.py:703).
+ *   mlagg_conv_pad_geometry: box (Dq, Hq, Wq) and guard (floats in front of and behind every channel row) of the padded copies for an
+ *       input of (D, H, W) voxels (D = 1: a 2-D map, stride 1 only).
+ *   mlagg_volume_pad: src (B, C, D, H, W) -> dst (B, phases, C, 2 * guard + Dq * Hq * Wq): zero-padded copy (stride 1: one phase, data
+ *       at origin 1) or the 8 parity phases of the zero-padded input (stride 2).  as_output = 1: an output-sized map (out_D, out_H,
+ *       out_W) laid into the box of the input geometry (D, H, W) with a zero ring (origin 1 for stride 1, 0 for stride 2).
+ *   mlagg_conv_wgrad_taps: dW (O, I, ntaps) (+)= sum_{b, q < Q} A[b][o][q] * B[b][i][q + tap_off[t]].  Q and the row strides are
+ *       multiples of 4 floats (Q of 8), tap_off is a HOST array of ntaps <= 27 element offsets; workspace of
+ *       mlagg_conv_wgrad_taps_workspace_floats() floats.  fp32 in, fp32 MFMA (exact products), fixed summation order.
+ * ------------------------------------------------------------------------------------------ */
+int mlagg_conv_pad_geometry(int D, int H, int W, int stride, int *Dq, int *Hq, int *Wq, long *guard);
+int mlagg_volume_pad(const float *src, float *dst, int B, int C, int D, int H, int W, int stride, int as_output, int out_D,
+                     int out_H, int out_W, void *stream);
+size_t mlagg_conv_wgrad_taps_workspace_floats(int batch, long Q, int O, int I, int ntaps);
+int mlagg_conv_wgrad_taps(const float *A, long a_batch, long a_row, const float *B, long b_batch, long b_row, const long *tap_off,
+                          int ntaps, long Q, int O, int I, int batch, float *dW, int accumulate, float *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * K11: clip_grad_norm_ + AdamW.step() of the train step (nnUNetTrainer.py:855-857; optimizer of
  * nnUNetTrainer_MLAgg_2D_dt_MS.py:137-147) for every parameter in two launches.
  * tensor_table: device array of rows {param*, grad*, exp_avg*, exp_avg_sq*, int64 numel} (5 x 8 bytes each);

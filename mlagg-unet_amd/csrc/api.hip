@@ -26,7 +26,11 @@ const char *const kNames[K_COUNT] = {
     "pooled_attn_bwd2_kernel", "dwconv_tiled_kernel<fwd>", "dwconv_tiled_kernel<dgrad>", "dwconv_bwd_weight_kernel", "linear_wgrad_kernel", "layernorm_fwd_kernel",
     "layernorm_bwd_kernel", "dwconv_nchw_fwd_kernel", "dwconv_nchw_bwd (data+weight+reduce)",
     "cross_scan_kernel<false>", "cross_scan_kernel<true>", "gate_fwd_kernel", "gate_bwd_kernel",
-    "linear_mfma_kernel<true>", "linear_mfma_kernel<false>", "row_scale_kernel", "dice_ce_stats_kernel", "dice_ce_grad_kernel", "transpose_tile_kernel", "bias gradient (plane_sum / column_sum)", "plane_norm_fwd_kernel", "plane_norm_bwd_kernel", "adamw (sumsq + update)", "flash_fwd_kernel", "flash_bwd (dq + dk/dv)", "channel_epilogue (bias + residual + GELU)"};
+    "linear_mfma_kernel<true>", "linear_mfma_kernel<false>", "row_scale_kernel", "dice_ce_stats_kernel", "dice_ce_grad_kernel", "transpose_tile_kernel", "bias gradient (plane_sum / column_sum)", "plane_norm_fwd_kernel", "plane_norm_bwd_kernel", "adamw (sumsq + update)", "flash_fwd_kernel", "flash_bwd (dq + dk/dv)", "channel_epilogue (bias + residual + GELU)",
+    "sel1_fwd_kernel<2, false>", "sel1_fwd_kernel<2, true>", "sel1_bwd_local_kernel<2>", "sel1_bwd_kernel<2>",
+    "sel1_fwd_kernel<R != 2, false>", "sel1_fwd_kernel<R != 2, true>", "sel1_bwd_local_kernel<R != 2>", "sel1_bwd_kernel<R != 2>",
+    "sel1_prefix_kernel", "sel1 reductions (step partials + per-chunk rows)",
+    "volume_pad_kernel (+ guard fill)", "conv_wgrad_taps_kernel", "conv_wgrad_reduce_kernel"};
 }  // namespace
 
 // begin/end pairs of one kernel are issued back to back from one host thread (the launcher), so the

@@ -468,16 +468,16 @@ extern "C" int mlagg_selscan1_fwd(const float *tok, long tok_stride, const int *
 #define SEL1_FWD(RR)                                                                                                             \
     {                                                                                                                            \
         {                                                                                                                        \
-            MLAGG_TIMED(K_SELSCAN_FWD_LOCAL, st);                                                                                \
+            mlagg_prof::Scope sc_(RR == 2 ? mlagg_prof::K_SEL1_FWD_LOCAL_R2 : mlagg_prof::K_SEL1_FWD_LOCAL, st);                                                                                \
             hipLaunchKernelGGL((sel1_fwd_kernel<RR, false>), grid, block, 0, st, tok, idx, dtr, Bs, Cs, Wdt, A, D, bias, yk, Hin, \
                                Dsum, Hs, g);                                                                                     \
         }                                                                                                                        \
         {                                                                                                                        \
-            MLAGG_TIMED(K_SELSCAN_PREFIX, st);                                                                                   \
+            MLAGG_TIMED(K_SEL1_PREFIX, st);                                                                                   \
             hipLaunchKernelGGL(sel1_prefix_kernel<false>, dim3(K * g.nblk, B), block, 0, st, Hin, Dsum, A, g);                   \
         }                                                                                                                        \
         {                                                                                                                        \
-            MLAGG_TIMED(K_SELSCAN_FWD_FINAL, st);                                                                                \
+            mlagg_prof::Scope sc_(RR == 2 ? mlagg_prof::K_SEL1_FWD_FINAL_R2 : mlagg_prof::K_SEL1_FWD_FINAL, st);                                                                                \
             hipLaunchKernelGGL((sel1_fwd_kernel<RR, true>), grid, block, 0, st, tok, idx, dtr, Bs, Cs, Wdt, A, D, bias, yk, Hin,  \
                                Dsum, Hs, g);                                                                                     \
         }                                                                                                                        \
@@ -514,22 +514,22 @@ extern "C" int mlagg_selscan1_bwd(const float *tok, long tok_stride, const int *
 #define SEL1_BWD(RR)                                                                                                              \
     {                                                                                                                             \
         {                                                                                                                         \
-            MLAGG_TIMED(K_SELSCAN_BWD_LOCAL, st);                                                                                 \
+            mlagg_prof::Scope sc_(RR == 2 ? mlagg_prof::K_SEL1_BWD_LOCAL_R2 : mlagg_prof::K_SEL1_BWD_LOCAL, st);                                                                                 \
             hipLaunchKernelGGL(sel1_bwd_local_kernel<RR>, grid, block, 0, st, dout, idx, dtr, Bs, Cs, Wdt, A, bias, Q, g);        \
         }                                                                                                                         \
         {                                                                                                                         \
-            MLAGG_TIMED(K_SELSCAN_PREFIX, st);                                                                                    \
+            MLAGG_TIMED(K_SEL1_PREFIX, st);                                                                                    \
             hipLaunchKernelGGL(sel1_prefix_kernel<true>, dim3(K * g.nblk, B), block, 0, st, Q, Dsum, A, g);                       \
         }                                                                                                                         \
         {                                                                                                                         \
-            MLAGG_TIMED(K_SELSCAN_BWD, st);                                                                                       \
+            mlagg_prof::Scope sc_(RR == 2 ? mlagg_prof::K_SEL1_BWD_R2 : mlagg_prof::K_SEL1_BWD, st);                                                                                       \
             hipLaunchKernelGGL(sel1_bwd_kernel<RR>, grid, block, 0, st, tok, dout, idx, dtr, Bs, Cs, Wdt, A, D, bias, Hs, Q, duk,  \
                                dBs, dCs, ddtr, stepws, part, dump, g);                                                            \
         }                                                                                                                         \
     }
     SEL1_DISPATCH_R(R, SEL1_BWD)
 #undef SEL1_BWD
-    MLAGG_TIMED(K_SELSCAN_REDUCE, st);
+    MLAGG_TIMED(K_SEL1_REDUCE, st);
     if (g.nblk > 1)
         hipLaunchKernelGGL(sel1_step_reduce_kernel, dim3((L + 255) / 256, 2 + R, B * K), dim3(256), 0, st, stepws, dBs, dCs, ddtr,
                            g.nblk, R, L);

@@ -75,13 +75,13 @@ class Conv3d(nn.Conv3d):
     def forward(self, x):
         if not x.is_cuda:
             return super().forward(x)
-        y = F.conv3d(x, self.weight, None, self.stride, self.padding, self.dilation, self.groups)
+        y = ops.conv_nd(x, self.weight, self.stride, self.padding)
         return y if self.bias is None else ops.channel_bias(y, self.bias)
 
     def normed(self, x):
         if not x.is_cuda:
             return super().forward(x)
-        y = F.conv3d(x, self.weight, None, self.stride, self.padding, self.dilation, self.groups)
+        y = ops.conv_nd(x, self.weight, self.stride, self.padding)
         return y if self.bias is None else _ZeroGradParam.apply(y, self.bias)
 
 

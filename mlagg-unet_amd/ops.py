@@ -1193,3 +1193,100 @@ class PlaneNormFn(torch.autograd.Function):
 
 def plane_norm(x, gamma, beta, eps=1e-5, act=ACT_NONE, slope=0.0, res=None):
     return PlaneNormFn.apply(x, gamma, beta, res, eps, act, slope)
+
+
+# ------------------------------------------------------------------------------------------------
+# K15: full convolutions with the weight gradient on this package's tap-GEMM kernel
+# ------------------------------------------------------------------------------------------------
+def _pad_geometry(D, H, W, stride):
+    import ctypes
+    Dq, Hq, Wq, guard = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_long()
+    _lib.check(_lib.lib().mlagg_conv_pad_geometry(D, H, W, stride, ctypes.byref(Dq), ctypes.byref(Hq), ctypes.byref(Wq),
+                                                  ctypes.byref(guard)), "mlagg_conv_pad_geometry")
+    return Dq.value, Hq.value, Wq.value, guard.value
+
+
+def conv_wgrad_supported(x, weight, stride, padding):
+    """Kernel 3 with padding 1 or kernel 1 with padding 0, isotropic, stride 1 (2-D and 3-D) or 2 (3-D), fp32 device maps."""
+    nd = x.dim() - 2
+    k = weight.shape[2]
+    return (x.is_cuda and x.dtype == torch.float32 and nd in (2, 3) and all(int(v) == k for v in weight.shape[2:]) and k in (1, 3)
+            and all(int(v) == k // 2 for v in padding) and len(set(int(v) for v in stride)) == 1
+            and (int(stride[0]) == 1 or (int(stride[0]) == 2 and nd == 3 and all(int(v) > 1 for v in x.shape[2:]))))
+
+
+def conv_weight_grad(x, dy, k, stride):
+    """dW (O, I, k^nd) of a convolution y = conv(x, W, stride, padding k // 2) from x (B, I, *dims) and dy (B, O, *out_dims)."""
+    import ctypes
+    lib = _lib.lib()
+    x = _require(x.contiguous(), "x")
+    dy = _require(dy.contiguous(), "dy")
+    B, I = x.shape[:2]
+    O = dy.shape[1]
+    dims = tuple(x.shape[2:]) if x.dim() == 5 else (1,) + tuple(x.shape[2:])
+    odims = tuple(dy.shape[2:]) if dy.dim() == 5 else (1,) + tuple(dy.shape[2:])
+    nd = x.dim() - 2
+    Dq, Hq, Wq, guard = _pad_geometry(*dims, stride)
+    Q = Dq * Hq * Wq
+    row = 2 * guard + Q
+    nph = 1 if stride == 1 else 8
+    xp = torch.empty(B, nph, I, row, device=x.device, dtype=torch.float32)
+    dyp = torch.empty(B, 1, O, row, device=x.device, dtype=torch.float32)
+    _lib.check(lib.mlagg_volume_pad(_ptr(x), _ptr(xp), B, I, *dims, stride, 0, 0, 0, 0, _stream()), "mlagg_volume_pad")
+    _lib.check(lib.mlagg_volume_pad(_ptr(dy), _ptr(dyp), B, O, *dims, stride, 1, *odims, _stream()), "mlagg_volume_pad")
+    taps = []
+    kz_range = range(k) if nd == 3 else (k // 2,)
+    for kz in kz_range:
+        for ky in range(k):
+            for kx in range(k):
+                if stride == 1:
+                    dz = (kz - k // 2) if nd == 3 else 0
+                    taps.append(dz * Hq * Wq + (ky - k // 2) * Wq + (kx - k // 2))
+                else:
+                    # padded input index 2 z + kz (k = 3) or 2 z + 1 (k = 1): parity phase + shift
+                    az, ay, ax = (kz, ky, kx) if k == 3 else (1, 1, 1)
+                    ph = ((az & 1) << 2) | ((ay & 1) << 1) | (ax & 1)
+                    taps.append(ph * I * row + (az >> 1) * Hq * Wq + (ay >> 1) * Wq + (ax >> 1))
+    ntaps = len(taps)
+    Q8 = (Q + 7) & ~7
+    off = (ctypes.c_long * ntaps)(*taps)
+    dW = torch.empty(O, I, ntaps, device=x.device, dtype=torch.float32)
+    ws = torch.empty(lib.mlagg_conv_wgrad_taps_workspace_floats(B, Q8, O, I, ntaps), device=x.device, dtype=torch.float32)
+    _lib.check(lib.mlagg_conv_wgrad_taps(dyp.data_ptr() + 4 * guard, O * row, row, xp.data_ptr() + 4 * guard, nph * I * row, row, off,
+                                         ntaps, Q8, O, I, B, _ptr(dW), 0, _ptr(ws), _stream()), "mlagg_conv_wgrad_taps")
+    return dW
+
+
+class ConvNdFn(torch.autograd.Function):
+    """y = conv(x, W) (no bias) on channel-major maps: forward and the data gradient stay MIOpen's (library convolutions, the
+    north star's "conv stem / decoder stages live in PyTorch-ROCm"); the weight gradient is K15."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding):
+        conv = torch.nn.functional.conv3d if x.dim() == 5 else torch.nn.functional.conv2d
+        y = conv(x, weight, None, stride, padding)
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (tuple(int(v) for v in stride), tuple(int(v) for v in padding))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, padding = ctx.geom
+        nd = x.dim() - 2
+        dx = dW = None
+        dy = dy.contiguous()
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(dy, x, weight, None, stride, padding, (1,) * nd, False, (0,) * nd, 1,
+                                                     (True, False, False))[0]
+        if ctx.needs_input_grad[1]:
+            dW = conv_weight_grad(x, dy, int(weight.shape[2]), stride[0]).view(weight.shape)
+        return dx, dW, None, None
+
+
+def conv_nd(x, weight, stride, padding):
+    """Bias-free convolution; the tap-GEMM weight gradient when the shape is one it is built for, plain torch otherwise."""
+    if conv_wgrad_supported(x, weight, stride, padding):
+        return ConvNdFn.apply(x, weight, tuple(stride), tuple(padding))
+    conv = torch.nn.functional.conv3d if x.dim() == 5 else torch.nn.functional.conv2d
+    return conv(x, weight, None, stride, padding)

@@ -62,3 +62,19 @@ def algorithmic_bytes(kernel, batch, img):
     # K2 / K2n / K5w / K6 / K1' are launched with several shapes per step (different callers): they have no
     # single bytes-per-launch figure and are reported by time only
     return int(per_module.get(kernel, 0) * batch)
+
+
+def algorithmic_bytes_sel1(kernel, batch, tokens, C=64, K=12, R=2):
+    """Bytes one launch of a K1s kernel must move at the widest stage of the 3-D network (stage 0: `tokens` = D*H*W of the patch,
+    C = d_inner 64, K = 12 directions, rank 2; only that stage runs the R = 2 instantiations, so these kernel names see one shape
+    per step).  Op-boundary counting in the sense of SURVEY 8(d)'s "fully fused lower bound": u is read once per direction, the
+    MERGED y / du is written once (the kernels as built write all K direction blocks and a block sum merges them: that extra
+    traffic counts against them), per-step parameters are idx + B + C + R rank rows."""
+    par = 4 * (3 + R)
+    per_token = {
+        "sel1_fwd_kernel<2, false>": K * (4 * C + par),                                  # read u, params
+        "sel1_fwd_kernel<2, true>": K * (4 * C + par) + 4 * C,                           # read u, params; write merged y
+        "sel1_bwd_local_kernel<2>": K * (4 * C + par),                                   # read dy, params
+        "sel1_bwd_kernel<2>": K * (8 * C + par + 4 * (2 + R)) + 4 * C,                   # read u, dy, params; write dB, dC, ddtr, merged du
+    }
+    return int(per_token.get(kernel, 0)) * tokens * batch

@@ -126,7 +126,7 @@ def test_product_and_tools_never_import_the_oracle():
                 offenders.append(os.path.relpath(path, root))
     assert not offenders, offenders
     # bench.py and __graft_entry__.py: the import sits inside cpu_baseline's helper / smoke() only
-    for name, allowed in (("bench.py", {"_oracle_step_seconds"}), ("__graft_entry__.py", {"smoke"})):
+    for name, allowed in (("bench.py", {"_oracle_step_seconds", "cpu_baseline_3d"}), ("__graft_entry__.py", {"smoke"})):
         tree = ast.parse(open(os.path.join(root, name)).read())
         for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
             uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(fn))

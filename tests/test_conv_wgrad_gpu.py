@@ -1,0 +1,61 @@
+"""GPU parity: K15, the tap-GEMM weight gradient of the full convolutions (csrc/conv_wgrad.hip through the C ABI), against
+torch's convolution weight gradient in float64 on the host; and ops.conv_nd (MIOpen forward / data gradient + K15) end to end."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+gpu = pytest.mark.gpu
+
+CASES = [
+    # (B, I, O, dims, k, stride)
+    (2, 3, 5, (5, 6, 7), 3, 1),            # 3-D 3x3x3, odd extents, partial 32-channel tiles
+    (1, 40, 70, (4, 9, 10), 3, 1),         # more than one tile of input and output channels (27 taps: three tap groups)
+    (2, 4, 6, (6, 5, 8), 3, 2),            # stride 2: the 8 parity phases, odd and even extents
+    (1, 33, 8, (7, 7, 3), 3, 2),
+    (2, 6, 4, (5, 6, 7), 1, 1),            # 1x1x1
+    (2, 6, 4, (6, 5, 8), 1, 2),            # 1x1x1 stride 2 (the residual convolution of a down-sampling BasicResBlock)
+    (2, 1, 32, (8, 16, 16), 3, 1),         # the stem: one input channel
+    (2, 5, 7, (9, 13), 3, 1),              # 2-D 3x3
+    (1, 48, 96, (12, 20), 1, 1),           # 2-D 1x1
+    (1, 32, 32, (24, 40, 40), 3, 1),       # a stage of BASELINE configs[3] at 1/64 of its voxels: several slabs per sample
+]
+
+
+@gpu
+@pytest.mark.parametrize("B,I,O,dims,k,stride", CASES)
+def test_conv_weight_grad_matches_torch(B, I, O, dims, k, stride):
+    from mlagg_unet_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + I + O + k + stride)
+    nd = len(dims)
+    x = torch.randn(B, I, *dims, generator=g)
+    w = torch.randn(O, I, *([k] * nd), generator=g).double().requires_grad_(True)
+    conv = F.conv3d if nd == 3 else F.conv2d
+    y = conv(x.double(), w, None, stride, k // 2)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    dev = torch.device("cuda:0")
+    assert ops.conv_wgrad_supported(x.to(dev), w.float().to(dev), (stride,) * nd, (k // 2,) * nd)
+    got = ops.conv_weight_grad(x.to(dev), dy.to(dev), k, stride).view(w.shape).cpu().double()
+    ref = w.grad
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-5, float((got - ref).abs().max())
+
+
+@gpu
+def test_conv_nd_forward_and_both_gradients():
+    from mlagg_unet_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 8, 6, 10, 12, generator=g)
+    w = torch.randn(16, 8, 3, 3, 3, generator=g) * 0.2
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv3d(xr, wr, None, 2, 1)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    y = ops.conv_nd(xg, wg, (2, 2, 2), (1, 1, 1))
+    y.backward(dy.to(dev))
+    for name, a, b in (("y", y.detach(), yr.detach()), ("dx", xg.grad, xr.grad), ("dW", wg.grad, wr.grad)):
+        assert float((a.cpu().double() - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-5, name
+    # anisotropic stride (the last pooling of the BTCV plan): not a K15 shape, plain library path, same numbers
+    y2 = ops.conv_nd(xg, wg, (1, 2, 2), (1, 1, 1))
+    assert float((y2.detach().cpu().double() - F.conv3d(xr, wr, None, (1, 2, 2), 1).detach()).abs().max()) < 1e-4

@@ -52,8 +52,8 @@ def test_3d_network_matches_the_reference_golden():
             assert abs(got - want) <= 5e-3 * want + 1e-9, (n, got, want)
     # elementwise: relative L2 per tensor.  The bound is the conditioning of the network, not of the kernels: the reference's own
     # fp32 run is 1e-3 ... 8.5e-3 away from a float64 run of itself on this case (every LeakyReLU behind an InstanceNorm flips sign
-    # for a few elements; tools/scripts/umamba3d_gradient_conditioning.py), and the product measures 3.7e-3 ... 5.4e-3 against the
-    # golden in the deepest tensors (stem, stage-0 scan block) and 1e-5 in the heads (tools/scripts/dbg3d.py: against float64 the
+    # for a few elements; tests/perf/umamba3d_gradient_conditioning.py), and the product measures 3.7e-3 ... 5.4e-3 against the
+    # golden in the deepest tensors (stem, stage-0 scan block) and 1e-5 in the heads (tests/perf/umamba3d_gradient_vs_oracle.py: against float64 the
     # product is as close as the reference's fp32 run is)
     for k in gold.files:
         if k.startswith("grad/"):

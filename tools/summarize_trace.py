@@ -17,7 +17,8 @@ import re
 def family(n):
     if n.startswith("Cijk_"):
         return "GEMM (rocBLAS/hipBLASLt)"
-    for key, lab in (("linear_lp", "HIP K5 projections (fwd, dx), 16-bit operands"), ("selscan", "HIP K1 selective scan"), ("cross_scan_kernel", "HIP K1' cross-scan / merge"),
+    for key, lab in (("linear_lp", "HIP K5 projections (fwd, dx), 16-bit operands"), ("selscan", "HIP K1 selective scan"), ("sel1_", "HIP K1s one-state selective scan (3-D)"),
+                     ("index_scan_kernel", "HIP K14 index scan / merge"), ("block_sum_kernel", "HIP K14 index scan / merge"), ("cross_scan_kernel", "HIP K1' cross-scan / merge"),
                      ("dwconv", "HIP K2 depthwise conv"),
                      ("local_attn", "HIP K3 local diff-attention"), ("pooled_attn", "HIP K4 pooled diff-attention"),
                      ("linear_wgrad", "HIP K5w linear weight-grad"), ("linear_mfma", "HIP K5 projections (fwd, dx)"),
@@ -50,10 +51,12 @@ def main():
     ap.add_argument("trace")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--mark", default=r"selscan_bwd_(group_)?kernel",
+                    help="regex of the kernel dispatched exactly once per step (3-D network: 'sel1_bwd_kernel<2>')")
     a = ap.parse_args()
     rows = list(csv.DictReader(open(a.trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if re.search(r"selscan_bwd_(group_)?kernel", r["Kernel_Name"])]
+    marks = [i for i, r in enumerate(rows) if re.search(a.mark, r["Kernel_Name"])]
     if len(marks) < a.steps + 1:
         raise SystemExit(f"only {len(marks)} steps in the trace")
     lo, hi = marks[-a.steps - 1], marks[-1]          # [bwd-scan of step k-1, bwd-scan of the last step)
