@@ -368,11 +368,15 @@ int mlagg_dice_ce_grad(const float *logits, const float *target, const float *g_
  * (nnUNetTrainer_MLAgg_2D_dt_MS.py:268-270, 357, 500-502), nn.InstanceNorm2d + LeakyReLU(0.01) of the MONAI UnetResBlock
  * (T:1339-1357; structure at MambaSkip.py:581-667) and nn.InstanceNorm2d(affine) + SiLU (MambaSkip.py:700-706).
  * stats (B*C, 2) receives mean and rstd for the backward, which overwrites dx and, when non-NULL, dgamma / dbeta (C);
- * workspace: mlagg_plane_norm_bwd_workspace_floats(B, C) floats (needed only with dgamma / dbeta).
+ * also nn.InstanceNorm3d(affine) + LeakyReLU of the 3-D network (variants/mamba/UMambaEnc_SS3D.py:477-513): planes of 256 Ki
+ * elements and more are cut into 16 Ki-element segments, one workgroup each, with exact pooled statistics.
+ * workspace: mlagg_plane_norm_fwd_workspace_floats / _bwd_workspace_floats(B, C, HW) floats (forward: 0 floats -- NULL allowed --
+ * unless the planes are cut into segments; backward: needed with dgamma / dbeta or segments).
  * ------------------------------------------------------------------------------------------ */
-int mlagg_plane_norm_fwd(const float *x, const float *gamma, const float *beta, const float *res, float *y, float *stats, int B,
-                         int C, long HW, float eps, int act, float slope, void *stream);
-size_t mlagg_plane_norm_bwd_workspace_floats(int B, int C);
+size_t mlagg_plane_norm_fwd_workspace_floats(int B, int C, long HW);
+int mlagg_plane_norm_fwd(const float *x, const float *gamma, const float *beta, const float *res, float *y, float *stats,
+                         float *workspace, int B, int C, long HW, float eps, int act, float slope, void *stream);
+size_t mlagg_plane_norm_bwd_workspace_floats(int B, int C, long HW);
 int mlagg_plane_norm_bwd(const float *x, const float *dy, const float *gamma, const float *beta, const float *res,
                          const float *stats, float *dx, float *dres, float *dgamma, float *dbeta, float *workspace, int B, int C,
                          long HW, int act, float slope, void *stream);

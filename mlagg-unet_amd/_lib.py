@@ -65,8 +65,9 @@ SIGNATURES = {
     "mlagg_channel_sum_workspace_floats": (_SZ, [_I, _I]),
     "mlagg_channel_sum": (_I, [_F, _F, _F, _I, _I, ctypes.c_long, _S]),
     "mlagg_column_sum": (_I, [_F, _I, _F, _I, _I, _S]),
-    "mlagg_plane_norm_fwd": (_I, [_F, _F, _F, _F, _F, _F, _I, _I, ctypes.c_long, ctypes.c_float, _I, ctypes.c_float, _S]),
-    "mlagg_plane_norm_bwd_workspace_floats": (_SZ, [_I, _I]),
+    "mlagg_plane_norm_fwd_workspace_floats": (_SZ, [_I, _I, ctypes.c_long]),
+    "mlagg_plane_norm_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _I, _I, ctypes.c_long, ctypes.c_float, _I, ctypes.c_float, _S]),
+    "mlagg_plane_norm_bwd_workspace_floats": (_SZ, [_I, _I, ctypes.c_long]),
     "mlagg_plane_norm_bwd": (_I, [_F] * 11 + [_I, _I, ctypes.c_long, _I, ctypes.c_float, _S]),
     "mlagg_adamw_chunk_elements": (_I, []),
     "mlagg_adamw_clip_step": (_I, [_F, _F, _I, _F] + [ctypes.c_float] * 6 + [_I, _S]),

@@ -248,6 +248,167 @@ plane_norm_fwd_reg_kernel(const float *__restrict__ x, const float *__restrict__
     if (threadIdx.x == 0) { stats[2 * plane] = mean; stats[2 * plane + 1] = rstd; }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Large planes (the 3-D network: InstanceNorm3d over 96 x 160 x 160 = 2.46 M voxels, 64 planes per map): one workgroup per plane
+// leaves 3/4 of the CUs idle and streams 10 MB through a single workgroup three times (2.5-3.9 ms per launch).  A plane is cut
+// into SEG-float segments, one workgroup each:
+//   forward 1: the segment stays in registers: its mean and its sum of squared deviations about THAT mean;
+//   forward 2: every workgroup combines the S partials (Chan's update: exact pooled mean / variance, no sum-of-squares
+//              cancellation), then normalises its segment: 2 reads + 1 write of the map instead of 3 + 1 through 64 workgroups;
+//   backward 1 / 2: the two per-plane sums as segment partials, then the gradient; d(gamma) / d(beta) partials per plane as before.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int SEG4 = 4096;                       // float4 per segment: 256 threads x 16
+
+__global__ void __launch_bounds__(256)
+plane_split_stats_kernel(const float *__restrict__ x, float *__restrict__ partial, long HW, int S)
+{
+    __shared__ float red[4];
+    const long plane = blockIdx.y;
+    const int seg = blockIdx.x;
+    const float4 *xp = reinterpret_cast<const float4 *>(x + plane * HW);
+    const long n4 = HW >> 2, lo = (long)seg * SEG4, cnt = min((long)SEG4, n4 - lo);
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const long idx = threadIdx.x + i * 256;
+        v[i] = idx < cnt ? xp[lo + idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float n = 4.f * (float)cnt, mean = block_sum(s, red) / n;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (threadIdx.x + i * 256 < cnt) {
+            const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    }
+    const float m2 = block_sum(q, red);
+    if (threadIdx.x == 0) {
+        float *p = partial + (plane * S + seg) * 3;
+        p[0] = mean; p[1] = m2; p[2] = n;
+    }
+}
+
+// pooled mean / rstd of a plane from its S segment partials, by every thread of the workgroup (S <= a few hundred)
+__device__ __forceinline__ void pooled_stats(const float *__restrict__ partial, long plane, int S, long HW, float eps, float *red,
+                                             float &mean, float &rstd)
+{
+    const float *p = partial + plane * S * 3;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < S; i += 256) a += p[3 * i] * p[3 * i + 2];
+    mean = block_sum(a, red) / (float)HW;
+    float b = 0.f;
+    for (int i = threadIdx.x; i < S; i += 256) { const float d = p[3 * i] - mean; b += p[3 * i + 1] + p[3 * i + 2] * d * d; }
+    rstd = rsqrtf(block_sum(b, red) / (float)HW + eps);
+}
+
+__global__ void __launch_bounds__(256)
+plane_split_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+                         const float *__restrict__ res, float *__restrict__ y, float *__restrict__ stats,
+                         const float *__restrict__ partial, int C, long HW, int S, float eps, int act, float slope)
+{
+    __shared__ float red[4];
+    const long plane = blockIdx.y;
+    const int seg = blockIdx.x, c = (int)(plane % C);
+    float mean, rstd;
+    pooled_stats(partial, plane, S, HW, eps, red, mean, rstd);
+    const float ga = (gamma ? gamma[c] : 1.f) * rstd, be = (beta ? beta[c] : 0.f) - mean * ga;
+    const float4 *xp = reinterpret_cast<const float4 *>(x + plane * HW);
+    float4 *yp = reinterpret_cast<float4 *>(y + plane * HW);
+    const float4 *rp = res ? reinterpret_cast<const float4 *>(res + plane * HW) : xp;
+    const bool has_res = res != nullptr;
+    const long n4 = HW >> 2, lo = (long)seg * SEG4, cnt = min((long)SEG4, n4 - lo);
+    float4 v[NV], r[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const long idx = min((long)(threadIdx.x + i * 256), cnt - 1);          // unconditional loads (clamped)
+        v[i] = xp[lo + idx];
+        r[i] = rp[lo + idx];
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const long idx = threadIdx.x + i * 256;
+        if (idx < cnt) {
+            const float r0 = has_res ? r[i].x : 0.f, r1 = has_res ? r[i].y : 0.f, r2 = has_res ? r[i].z : 0.f, r3 = has_res ? r[i].w : 0.f;
+            yp[lo + idx] = make_float4(act_fwd(v[i].x * ga + be + r0, act, slope), act_fwd(v[i].y * ga + be + r1, act, slope),
+                                       act_fwd(v[i].z * ga + be + r2, act, slope), act_fwd(v[i].w * ga + be + r3, act, slope));
+        }
+    }
+    if (seg == 0 && threadIdx.x == 0) { stats[2 * plane] = mean; stats[2 * plane + 1] = rstd; }
+}
+
+template <bool RES, bool APPLY>
+__global__ void __launch_bounds__(256)
+plane_split_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ gamma,
+                       const float *__restrict__ beta, const float *__restrict__ res, const float *__restrict__ stats,
+                       float *__restrict__ dx, float *__restrict__ dres, float *__restrict__ part, float *__restrict__ partial, int C,
+                       long HW, int S, int act, float slope)
+{
+    __shared__ float red[4];
+    const long plane = blockIdx.y;
+    const int seg = blockIdx.x, c = (int)(plane % C);
+    const float mean = stats[2 * plane], rstd = stats[2 * plane + 1];
+    const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    const float4 *xp = reinterpret_cast<const float4 *>(x + plane * HW), *gp = reinterpret_cast<const float4 *>(dy + plane * HW);
+    const float4 *rp = RES ? reinterpret_cast<const float4 *>(res + plane * HW) : xp;
+    const long n4 = HW >> 2, lo = (long)seg * SEG4, cnt = min((long)SEG4, n4 - lo);
+    auto term = [&](float xv, float gv, float rv, float &xh) {
+        xh = (xv - mean) * rstd;
+        return act == ACT_NONE ? gv : gv * act_bwd(xh * ga + be + rv, act, slope);
+    };
+    float m1 = 0.f, m2 = 0.f;
+    if (APPLY) {
+        const float *p = partial + plane * S * 2;
+        float a = 0.f, b = 0.f;
+        for (int i = threadIdx.x; i < S; i += 256) { a += p[2 * i]; b += p[2 * i + 1]; }
+        const float S1 = block_sum(a, red), S2 = block_sum(b, red);
+        m1 = S1 / (float)HW; m2 = S2 / (float)HW;
+        if (seg == 0 && threadIdx.x == 0 && part) { part[2 * plane] = S2; part[2 * plane + 1] = S1; }
+    }
+    const float k = rstd * ga;
+    float s1 = 0.f, s2 = 0.f;
+    constexpr int UN = 4;
+#pragma unroll
+    for (int i0 = 0; i0 < NV; i0 += UN) {
+        float4 a[UN], g4[UN], r[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long idx = min((long)(threadIdx.x + (i0 + u) * 256), cnt - 1);
+            a[u] = xp[lo + idx];
+            g4[u] = gp[lo + idx];
+            r[u] = RES ? rp[lo + idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long idx = threadIdx.x + (i0 + u) * 256;
+            if (idx >= cnt) continue;
+            float xh;
+            float4 o, tr;
+            float t = term(a[u].x, g4[u].x, r[u].x, xh); s1 += t; s2 += t * xh; o.x = k * (t - m1 - xh * m2); tr.x = t;
+            t = term(a[u].y, g4[u].y, r[u].y, xh); s1 += t; s2 += t * xh; o.y = k * (t - m1 - xh * m2); tr.y = t;
+            t = term(a[u].z, g4[u].z, r[u].z, xh); s1 += t; s2 += t * xh; o.z = k * (t - m1 - xh * m2); tr.z = t;
+            t = term(a[u].w, g4[u].w, r[u].w, xh); s1 += t; s2 += t * xh; o.w = k * (t - m1 - xh * m2); tr.w = t;
+            if (APPLY) {
+                reinterpret_cast<float4 *>(dx + plane * HW)[lo + idx] = o;
+                if (RES && dres) reinterpret_cast<float4 *>(dres + plane * HW)[lo + idx] = tr;
+            }
+        }
+    }
+    if (!APPLY) {
+        const float S1 = block_sum(s1, red), S2 = block_sum(s2, red);
+        if (threadIdx.x == 0) { partial[(plane * S + seg) * 2] = S1; partial[(plane * S + seg) * 2 + 1] = S2; }
+    }
+}
+
+inline int split_segments(long HW)          // 0: the one-workgroup-per-plane kernels
+{
+    if ((HW & 3) || HW < 64L * 4096) return 0;
+    return (int)(((HW >> 2) + SEG4 - 1) / SEG4);
+}
+
 int check(int B, int C, long HW, int act)
 {
     if (B <= 0 || C <= 0 || HW <= 0 || (long)B * C > 2147483647L || act < 0 || act > 2) return MLAGG_E_UNSUPPORTED;
@@ -256,16 +417,33 @@ int check(int B, int C, long HW, int act)
 
 }  // namespace
 
-extern "C" size_t mlagg_plane_norm_bwd_workspace_floats(int B, int C) { return (size_t)(B > 0 ? B : 0) * (C > 0 ? C : 0) * 2; }
+extern "C" size_t mlagg_plane_norm_fwd_workspace_floats(int B, int C, long HW)
+{
+    return (size_t)(B > 0 ? B : 0) * (C > 0 ? C : 0) * split_segments(HW) * 3;
+}
+
+extern "C" size_t mlagg_plane_norm_bwd_workspace_floats(int B, int C, long HW)
+{
+    return (size_t)(B > 0 ? B : 0) * (C > 0 ? C : 0) * (2 + 2 * (size_t)split_segments(HW));
+}
 
 extern "C" int mlagg_plane_norm_fwd(const float *x, const float *gamma, const float *beta, const float *res, float *y, float *stats,
-                                    int B, int C, long HW, float eps, int act, float slope, void *stream)
+                                    float *workspace, int B, int C, long HW, float eps, int act, float slope, void *stream)
 {
     if (!x || !y || !stats) return MLAGG_E_NULLPTR;
     if (int rc = check(B, C, HW, act)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool vec = (HW & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)res)) & 15) == 0;
     MLAGG_TIMED(K_PLANE_NORM_FWD, st);
+    const int S = vec ? split_segments(HW) : 0;
+    if (S > 0) {
+        if (!workspace) return MLAGG_E_WORKSPACE;
+        if (S > 65535 || (long)B * C > 65535) return MLAGG_E_UNSUPPORTED;
+        hipLaunchKernelGGL(plane_split_stats_kernel, dim3(S, B * C), dim3(256), 0, st, x, workspace, HW, S);
+        hipLaunchKernelGGL(plane_split_apply_kernel, dim3(S, B * C), dim3(256), 0, st, x, gamma, beta, res, y, stats, workspace, C, HW,
+                           S, eps, act, slope);
+        return (int)hipGetLastError();
+    }
     if (vec && HW <= 256 * 4 * NV) hipLaunchKernelGGL(plane_norm_fwd_reg_kernel<256>, dim3(B * C), dim3(256), 0, st, x, gamma, beta, res, y, stats, C, HW, eps, act, slope);
     else if (vec && HW <= 1024 * 4 * NV) hipLaunchKernelGGL(plane_norm_fwd_reg_kernel<1024>, dim3(B * C), dim3(1024), 0, st, x, gamma, beta, res, y, stats, C, HW, eps, act, slope);
     else if (vec) hipLaunchKernelGGL(plane_norm_fwd_kernel<true>, dim3(B * C), dim3(256), 0, st, x, gamma, beta, res, y, stats, C, HW, eps, act, slope);
@@ -282,7 +460,25 @@ extern "C" int mlagg_plane_norm_bwd(const float *x, const float *dy, const float
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool vec = (HW & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)res) | ((uintptr_t)dres)) & 15) == 0;
     float *part = (dgamma || dbeta) ? workspace : nullptr;
-    {
+    const int S = vec ? split_segments(HW) : 0;
+    if (S > 0) {
+        if (!workspace) return MLAGG_E_WORKSPACE;
+        if (S > 65535 || (long)B * C > 65535) return MLAGG_E_UNSUPPORTED;
+        float *partial = workspace + (size_t)B * C * 2;
+        MLAGG_TIMED(K_PLANE_NORM_BWD, st);
+        const dim3 grid(S, B * C), block(256);
+        if (res) {
+            hipLaunchKernelGGL((plane_split_bwd_kernel<true, false>), grid, block, 0, st, x, dy, gamma, beta, res, stats, dx, dres, part,
+                               partial, C, HW, S, act, slope);
+            hipLaunchKernelGGL((plane_split_bwd_kernel<true, true>), grid, block, 0, st, x, dy, gamma, beta, res, stats, dx, dres, part,
+                               partial, C, HW, S, act, slope);
+        } else {
+            hipLaunchKernelGGL((plane_split_bwd_kernel<false, false>), grid, block, 0, st, x, dy, gamma, beta, res, stats, dx, dres, part,
+                               partial, C, HW, S, act, slope);
+            hipLaunchKernelGGL((plane_split_bwd_kernel<false, true>), grid, block, 0, st, x, dy, gamma, beta, res, stats, dx, dres, part,
+                               partial, C, HW, S, act, slope);
+        }
+    } else {
         MLAGG_TIMED(K_PLANE_NORM_BWD, st);
 #define MLAGG_PN_BWD(VEC, RES) hipLaunchKernelGGL((plane_norm_bwd_kernel<VEC, RES>), dim3(B * C), dim3(256), 0, st, x, dy, gamma, beta, res, stats, dx, \
                                                   dres, part, C, HW, act, slope)

@@ -1166,7 +1166,9 @@ class PlaneNormFn(torch.autograd.Function):
         hw = x.numel() // (B * C)
         y = torch.empty_like(x)
         stats = torch.empty(B * C, 2, device=x.device, dtype=torch.float32)
-        _lib.check(_lib.lib().mlagg_plane_norm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(res), _ptr(y), _ptr(stats), B, C, hw,
+        nws = _lib.lib().mlagg_plane_norm_fwd_workspace_floats(B, C, hw)          # > 0: planes cut into segments (3-D volumes)
+        ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
+        _lib.check(_lib.lib().mlagg_plane_norm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(res), _ptr(y), _ptr(stats), _ptr(ws), B, C, hw,
                                                    float(eps), int(act), float(slope), _stream()), "mlagg_plane_norm_fwd")
         ctx.save_for_backward(x, gamma, beta, res, stats)
         ctx.meta = (int(act), float(slope))
@@ -1184,8 +1186,9 @@ class PlaneNormFn(torch.autograd.Function):
         dres = torch.empty_like(x) if (res is not None and ctx.needs_input_grad[3]) else None
         dg = torch.empty_like(gamma) if gamma is not None else None
         db = torch.empty_like(beta) if beta is not None else None
-        ws = torch.empty(lib.mlagg_plane_norm_bwd_workspace_floats(B, C), device=x.device, dtype=torch.float32) \
-            if (dg is not None or db is not None) else None
+        segmented = lib.mlagg_plane_norm_fwd_workspace_floats(B, C, hw) > 0
+        ws = torch.empty(lib.mlagg_plane_norm_bwd_workspace_floats(B, C, hw), device=x.device, dtype=torch.float32) \
+            if (dg is not None or db is not None or segmented) else None
         _lib.check(lib.mlagg_plane_norm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(res), _ptr(stats), _ptr(dx), _ptr(dres),
                                             _ptr(dg), _ptr(db), _ptr(ws), B, C, hw, act, slope, _stream()), "mlagg_plane_norm_bwd")
         return dx, dg, db, dres, None, None, None

@@ -436,6 +436,35 @@ def test_plane_norm_residual_before_activation():
 
 
 @gpu
+@pytest.mark.parametrize("res", [False, True])
+def test_plane_norm_segmented_planes_match_torch(res):
+    """Planes of 256 Ki elements and more (InstanceNorm3d(affine) + LeakyReLU of the 3-D network, UMambaEnc_SS3D.py:477-513) are cut
+    into 16 Ki-element segments with pooled statistics: against F.instance_norm in float64, a ragged last segment, an offset far
+    larger than the spread (the case a sum-of-squares variance would lose), with and without the residual."""
+    from mlagg_unet_amd import _lib, ops
+    B, C, dims = 2, 3, (10, 164, 164)                     # 268 960 voxels: 17 segments, the last one 6 816 elements
+    assert _lib.lib().mlagg_plane_norm_fwd_workspace_floats(B, C, dims[0] * dims[1] * dims[2]) == B * C * 17 * 3
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, C, *dims, generator=g) * 0.5 + 40.0
+    r = torch.randn(B, C, *dims, generator=g)
+    gamma, beta = torch.randn(C, generator=g) * 0.5 + 1, torch.randn(C, generator=g)
+    gy = torch.randn(B, C, *dims, generator=g)
+    xb, rb = x.double().requires_grad_(True), r.double().requires_grad_(True)
+    gb, bb = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yb = F.instance_norm(xb, weight=gb, bias=bb, eps=1e-5)
+    yb = F.silu(yb + rb if res else yb)          # a smooth activation: behind LeakyReLU a handful of the 1.6 M elements sit within
+    yb.backward(gy.double())                     # rounding distance of 0 and flip slope between any two fp32 evaluations
+    xa, ra = x.to(DEV).requires_grad_(True), r.to(DEV).requires_grad_(True)
+    ga, ba = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    ya = ops.plane_norm(xa, ga, ba, 1e-5, ops.ACT_SILU, 0.0, ra if res else None)
+    ya.backward(gy.to(DEV))
+    assert float((ya.detach().cpu().double() - yb.detach()).abs().max()) < 1e-3          # x / std ~ 80: 1e-5 relative of the input
+    for name, a, b in (("dx", xa.grad, xb.grad), ("dgamma", ga.grad, gb.grad), ("dbeta", ba.grad, bb.grad)) + \
+            ((("dres", ra.grad, rb.grad),) if res else ()):
+        assert float((a.cpu().double() - b).abs().max()) <= 5e-4 * float(b.abs().max()), name
+
+
+@gpu
 @pytest.mark.parametrize("max_norm", [12.0, 0.05, 0.0])
 def test_clip_adamw_matches_torch(max_norm):
     """K11 against torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW over several steps (clip active, inactive, off)."""
