@@ -132,3 +132,73 @@ def make_trainer_class(nnUNetTrainer, variant="B", precision="fp32"):
             pass
 
     return nnUNetTrainer_MLAgg_2D_dt_MS
+
+
+def make_umamba_enc_ss3d_trainer_class(nnUNetTrainer):
+    """``nnUNetTrainerUMambaEnc_SS3D`` (reference variants/mamba/nnUNetTrainerUMambaEnc_SS3D.py:8-31) on the MI355X 3-D network
+    (model3d.UMambaEnc; BASELINE configs[3]).  The reference class overrides ``build_network_architecture`` only and inherits the
+    base trainer's recipe (SGD momentum 0.99 Nesterov + PolyLR, nnUNetTrainer.py:448-452; DC_and_CE deep-supervision loss,
+    :330-352); so does this one, plus what the device network needs from the loop: the fp32 step without autocast / GradScaler
+    (B:848-858), the fused K9 loss, ``trainer.wrap_ddp``, and the deep-supervision switch on the unwrapped module."""
+    from . import model3d
+
+    class nnUNetTrainerUMambaEnc_SS3D(nnUNetTrainer):
+        def __init__(self, plans, configuration, fold, dataset_json, unpack_dataset=True, device=None):
+            super().__init__(plans, configuration, fold, dataset_json, unpack_dataset,
+                             device if device is not None else torch.device("cuda"))
+            self.grad_scaler = None                                                  # fp32 step: no loss scaling (B:152)
+            miopen_tuning.use_tuned_convolutions(enabled=False)                      # no committed records for 3-D convolutions
+
+        @staticmethod
+        def build_network_architecture(plans_manager, dataset_json, configuration_manager, num_input_channels,
+                                       enable_deep_supervision=True):
+            cm = configuration_manager                                               # get_umamba_enc_3d_from_plans, S:890-942
+            if len(cm.conv_kernel_sizes[0]) != 3:
+                raise RuntimeError("nnUNetTrainerUMambaEnc_SS3D on MI355X: 3-D configurations only")
+            label_manager = plans_manager.get_label_manager(dataset_json)
+            return model3d.build_network_architecture_3d(
+                num_input_channels, label_manager.num_segmentation_heads, cm.conv_kernel_sizes, cm.pool_op_kernel_sizes,
+                cm.n_conv_per_stage_encoder, cm.n_conv_per_stage_decoder, cm.UNet_base_num_features, cm.unet_max_num_features,
+                enable_deep_supervision)
+
+        def initialize(self):                                                        # reference B:193-215
+            ddp = self.is_ddp
+            self.is_ddp = False
+            try:
+                super().initialize()
+            finally:
+                self.is_ddp = ddp
+            if ddp:
+                self.network = trainer.wrap_ddp(self.network, self.device.index if self.device.type == "cuda" else None)
+                self.loss = self._build_loss()
+
+        def set_deep_supervision_enabled(self, enabled):                             # B: self.network.decoder.deep_supervision
+            trainer.set_deep_supervision_enabled(self.network, enabled)
+
+        def _build_loss(self):                                                       # reference B:330-352
+            lm = self.label_manager
+            if getattr(lm, "has_regions", False):
+                return super()._build_loss()
+            batch_dice, ddp = bool(self.configuration_manager.batch_dice), bool(self.is_ddp)
+            ignore = getattr(lm, "ignore_label", None)
+
+            def loss(output, target):
+                if not isinstance(output, (list, tuple)):
+                    output, target = [output], [target if torch.is_tensor(target) else target[0]]
+                return trainer.deep_supervision_loss(list(output), list(target[:len(output)]), batch_dice, ddp, ignore_label=ignore)
+
+            return loss
+
+        def train_step(self, batch):                                                 # reference B:833-863
+            data = batch["data"].to(self.device, non_blocking=True)
+            target = batch["target"]
+            target = [t.to(self.device, non_blocking=True) for t in target] if isinstance(target, list) else \
+                [target.to(self.device, non_blocking=True)]
+            loss = trainer.train_step(self.network, self.optimizer, data.float(), [t.float() for t in target], clip=12.0,
+                                      loss_fn=self.loss)
+            return {"loss": loss.cpu().numpy()}
+
+        def plot_network_architecture(self):
+            pass
+
+    return nnUNetTrainerUMambaEnc_SS3D

@@ -32,6 +32,11 @@ class _ConfigurationManager:
         self.batch_dice = bool(cfg.get("batch_dice", True))
         self.previous_stage_name = None
         self.data_identifier = cfg.get("data_identifier", "nnUNetPlans_2d")
+        # the architecture entries of a plans file (plans_handler.py:94-120); absent from the 2-D MLAgg test plans
+        for key in ("conv_kernel_sizes", "pool_op_kernel_sizes", "n_conv_per_stage_encoder", "n_conv_per_stage_decoder",
+                    "UNet_base_num_features", "unet_max_num_features"):
+            if key in cfg:
+                setattr(self, key, cfg[key])
 
 
 class _PlansManager:
@@ -59,6 +64,17 @@ def make_plans(patch_size, batch_size, batch_dice=True):
     return {"dataset_name": "Dataset702_AbdomenMR", "plans_name": "nnUNetPlans",
             "configurations": {"2d_bs10": {"patch_size": list(patch_size), "batch_size": batch_size,
                                            "batch_dice": batch_dice}}}
+
+
+def make_plans_3d(patch_size, batch_size, strides, base=32, cap=320):
+    """A 3d_fullres configuration as the experiment planner writes it: 3x3x3 kernels, 2 convolutions per stage, no batch dice."""
+    n = len(strides)
+    return {"dataset_name": "Dataset703_BTCV", "plans_name": "nnUNetPlans",
+            "configurations": {"3d_fullres": {"patch_size": list(patch_size), "batch_size": batch_size, "batch_dice": False,
+                                              "conv_kernel_sizes": [[3, 3, 3]] * n, "pool_op_kernel_sizes": [list(s) for s in strides],
+                                              "n_conv_per_stage_encoder": [2] * n, "n_conv_per_stage_decoder": [2] * (n - 1),
+                                              "UNet_base_num_features": base, "unet_max_num_features": cap,
+                                              "data_identifier": "nnUNetPlans_3d_fullres"}}}
 
 
 def make_dataset_json(n_classes, in_channels=1):
@@ -101,11 +117,26 @@ class nnUNetTrainer:
                                    enable_deep_supervision=True):
         raise NotImplementedError
 
-    def configure_optimizers(self):
-        raise NotImplementedError
+    def configure_optimizers(self):                                                 # B:448-452 (PolyLRScheduler restated)
+        optimizer = torch.optim.SGD(self.network.parameters(), self.initial_lr, weight_decay=self.weight_decay, momentum=0.99,
+                                    nesterov=True)
 
-    def _get_deep_supervision_scales(self):
-        raise NotImplementedError
+        class _PolyLR:
+            def __init__(self, opt, initial_lr, max_steps, exponent=0.9):
+                self.opt, self.initial_lr, self.max_steps, self.exponent, self.ctr = opt, initial_lr, max_steps, exponent, 0
+
+            def step(self, current_step=None):
+                if current_step is None or current_step == -1:
+                    current_step = self.ctr
+                    self.ctr += 1
+                for group in self.opt.param_groups:
+                    group["lr"] = self.initial_lr * (1 - current_step / self.max_steps) ** self.exponent
+
+        return optimizer, _PolyLR(optimizer, self.initial_lr, self.num_epochs)
+
+    def _get_deep_supervision_scales(self):                                         # B:278-281
+        import numpy as np
+        return list(list(i) for i in 1 / np.cumprod(np.vstack(self.configuration_manager.pool_op_kernel_sizes), axis=0))[:-1]
 
     def _build_loss(self):
         """B:330-352 builds DeepSupervisionWrapper(DC_and_CE_loss | DC_and_BCE_loss); the loss classes are not importable

@@ -190,3 +190,35 @@ def test_tuned_convolution_database_is_used_only_for_the_shapes_it_holds(monkeyp
         cls = nnunet_plugin.make_trainer_class(FK.nnUNetTrainer, precision=precision)
         cls(FK.make_plans(patch, 3), "2d_bs10", 0, FK.make_dataset_json(5), device=torch.device("cpu"))
         assert calls[-1] is want, (precision, patch)
+
+
+def test_3d_trainer_plugin_reads_the_plan_and_keeps_the_base_recipe(monkeypatch):
+    """nnUNetTrainerUMambaEnc_SS3D (variants/mamba/nnUNetTrainerUMambaEnc_SS3D.py:8-31): the class overrides the network factory and
+    inherits SGD + PolyLR + the deep-supervision scales of the base trainer; the factory hands the plan's architecture entries to
+    model3d as get_umamba_enc_3d_from_plans (UMambaEnc_SS3D.py:890-942) does."""
+    import mlagg_unet_amd  # noqa: F401
+    from mlagg_unet_amd import miopen_tuning, model3d, nnunet_plugin
+    seen = {}
+
+    def build(in_ch, n_cls, kernels, strides, n_enc, n_dec, base, cap, ds):
+        seen["args"] = (in_ch, n_cls, kernels, strides, n_enc, n_dec, base, cap, ds)
+        return StubNet(in_ch, n_cls, ds)
+
+    monkeypatch.setattr(model3d, "build_network_architecture_3d", build)
+    monkeypatch.setattr(miopen_tuning, "use_tuned_convolutions", lambda enabled=True: seen.setdefault("miopen", enabled))
+    cls = nnunet_plugin.make_umamba_enc_ss3d_trainer_class(FK.nnUNetTrainer)
+    assert cls.__name__ == "nnUNetTrainerUMambaEnc_SS3D" and issubclass(cls, FK.nnUNetTrainer)
+    strides = [[1, 1, 1], [2, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2], [1, 2, 2]]
+    tr = cls(FK.make_plans_3d((96, 160, 160), 2, strides), "3d_fullres", 0, FK.make_dataset_json(14), device=torch.device("cpu"))
+    assert tr.grad_scaler is None and seen["miopen"] is False
+    tr.initialize()
+    assert seen["args"] == (1, 14, [[3, 3, 3]] * 6, strides, [2] * 6, [2] * 5, 32, 320, True)
+    assert isinstance(tr.optimizer, torch.optim.SGD) and tr.optimizer.defaults["momentum"] == 0.99 and tr.optimizer.defaults["nesterov"]
+    assert tr.initial_lr == 1e-2 and tr.base_calls["_build_loss"] == 0 and callable(tr.loss)
+    sc = tr._get_deep_supervision_scales()
+    assert len(sc) == 5 and sc[-1] == [1 / 16, 1 / 16, 1 / 16]
+    # 2-D plans are refused by the factory
+    tr2 = cls(FK.make_plans((32, 32), 2), "2d_bs10", 0, FK.make_dataset_json(5), device=torch.device("cpu"))
+    tr2.configuration_manager.conv_kernel_sizes = [[3, 3]] * 4
+    with pytest.raises(RuntimeError):
+        tr2.initialize()
