@@ -34,7 +34,8 @@ def use_tuned_gemms(enabled=True):
     tn = torch.cuda.tunable
     tn.enable(True)
     tn.tuning_enable(False)
-    tn.write_file_on_exit(False)                      # nothing is tuned here, so there is nothing to write back
+    if hasattr(tn, "write_file_on_exit"):
+        tn.write_file_on_exit(False)                  # nothing is tuned here, so there is nothing to write back (newer PyTorch only)
     tn.set_filename(private)
     ok = tn.read_file(private)                        # False when the Validator rows (library versions) do not match
     if not ok or not tn.get_results():

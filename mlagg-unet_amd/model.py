@@ -97,19 +97,22 @@ class DropPath(nn.Module):
 
 class Conv2d(nn.Conv2d):
     """nn.Conv2d (same parameter names): MIOpen convolution without its bias, then K8's in-place channel bias whose
-    gradient is one plane-sum launch (inside convolution_backward it is a generic ATen reduction at 1.3-2 TB/s)."""
+    gradient is one plane-sum launch (inside convolution_backward it is a generic ATen reduction at 1.3-2 TB/s).  In fp32 mode the
+    weight gradient of the dense 3x3 / 1x1 stride-1 convolutions is K15 (ops.conv_nd), not MIOpen's NHWC implicit GEMM."""
+
+    def _conv(self, x, cdt):
+        if cdt == torch.float32 and self.groups == 1 and ops.K15_2D and tuple(self.dilation) == (1, 1):
+            return ops.conv_nd(x, self.weight, self.stride, self.padding)
+        y = F.conv2d(ops.lp(x, cdt), ops.lp(self.weight, cdt), None, self.stride, self.padding, self.dilation, self.groups)
+        return y.float() if cdt != torch.float32 else y
 
     def forward(self, x):
         cdt = ops.conv_dtype()
         if not x.is_cuda or self.padding_mode != "zeros":
             return super().forward(x)
-        if self.bias is None and cdt == torch.float32:
-            return super().forward(x)
         # mixed precision: the convolution runs on 16-bit operands (what autocast makes of it, reference B:848); the
         # map comes back fp32 for the HIP kernels that follow
-        y = F.conv2d(ops.lp(x, cdt), ops.lp(self.weight, cdt), None, self.stride, self.padding, self.dilation, self.groups)
-        if cdt != torch.float32:
-            y = y.float()
+        y = self._conv(x, cdt)
         return y if self.bias is None else ops.channel_bias(y, self.bias)
 
     def fused(self, x, res=None, act=ops.EPI_NONE):
@@ -118,11 +121,7 @@ class Conv2d(nn.Conv2d):
             y = super().forward(x)
             y = y if res is None else y + res
             return F.gelu(y) if act == ops.EPI_GELU else y
-        cdt = ops.conv_dtype()
-        y = F.conv2d(ops.lp(x, cdt), ops.lp(self.weight, cdt), None, self.stride, self.padding, self.dilation, self.groups)
-        if cdt != torch.float32:
-            y = y.float()
-        return ops.channel_epilogue(y, self.bias, res, act)
+        return ops.channel_epilogue(self._conv(x, ops.conv_dtype()), self.bias, res, act)
 
 
 class ConvTranspose2d(nn.ConvTranspose2d):

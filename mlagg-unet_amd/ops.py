@@ -1209,6 +1209,13 @@ def _pad_geometry(D, H, W, stride):
     return Dq.value, Hq.value, Wq.value, guard.value
 
 
+# K15 for the 2-D network's dense convolutions: OFF.  Measured on the 21 convolution shapes of the 256 x 256 step
+# (profiles/round3_conv_wgrad_2d_shapes_k15_vs_miopen.log): MIOpen's weight-gradient solvers are 1.1-1.9x faster on the 3x3 shapes
+# (K15 incl. its two pad copies reaches 28-59 TFLOP/s there) and 4-7x on the 1x1 shapes (plain GEMMs); step 43.5 -> 56.2 ms with it
+# on.  It pays where MIOpen has no tuned solver: the 3-D convolutions (8.2 s -> 66 ms per step at 2 x 96x160x160 voxels).
+K15_2D = _os.environ.get("MLAGG_K15_2D", "0") == "1"
+
+
 def conv_wgrad_supported(x, weight, stride, padding):
     """Kernel 3 with padding 1 or kernel 1 with padding 0, isotropic, stride 1 (2-D and 3-D) or 2 (3-D), fp32 device maps."""
     nd = x.dim() - 2
