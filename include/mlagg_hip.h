@@ -346,16 +346,21 @@ int mlagg_channel_gelu_bwd(const float *pre, const float *dy, float *dpre, float
  * masked products, spatial sums, log_softmax + nll and all their backward kernels of DC_and_CE_loss
  * (loss/compound_losses.py:31-57, loss/dice.py:73-117, loss/robust_ce_loss.py:12-16).
  * logits (B, C, HW) fp32, 2 <= C <= mlagg_dice_ce_max_classes(); target (B, HW) float labels in [0, C).
- * stats: ACCUMULATES (caller zero-fills) stats_ip[b][0][c] = sum_p softmax_c [y == c], stats_ip[b][1][c] = sum_p softmax_c,
+ * stats: stats_ip[b][0][c] = sum_p softmax_c [y == c], stats_ip[b][1][c] = sum_p softmax_c,
  * stats_g[b][c] = sum_p [y == c], ce_sum[0] = sum_{b,p} -log softmax_y.
  * grad: dlogits = d(loss)/d(logits) for upstream gradients g_ip (B, 2, C) of stats_ip and g_ce[0] of ce_sum (device scalars:
  * no host synchronisation).
  * ignore_label >= 0: pixels carrying that label take no part in any sum and get a zero gradient -- the loss mask of
  * DC_and_CE_loss(ignore_label=...) (loss/compound_losses.py:38-50; the number of valid pixels is sum_{b,c} stats_g); -1: none.
- * ------------------------------------------------------------------------------------------ */
+ */
 int mlagg_dice_ce_max_classes(void);
-int mlagg_dice_ce_stats(const float *logits, const float *target, float *stats_ip, float *stats_g, float *ce_sum, int B, int C,
-                        long HW, int ignore_label, void *stream);
+/*
+ * stats OVERWRITES its three outputs: per-workgroup partial rows in `workspace` (mlagg_dice_ce_stats_workspace_floats floats) are
+ * summed in a fixed order -- the value of the loss is bit-reproducible from run to run.
+ * ------------------------------------------------------------------------------------------ */
+size_t mlagg_dice_ce_stats_workspace_floats(int B, int C, long HW);
+int mlagg_dice_ce_stats(const float *logits, const float *target, float *stats_ip, float *stats_g, float *ce_sum,
+                        float *workspace, int B, int C, long HW, int ignore_label, void *stream);
 int mlagg_dice_ce_grad(const float *logits, const float *target, const float *g_ip, const float *g_ce, float *dlogits, int B,
                        int C, long HW, int ignore_label, void *stream);
 
@@ -407,7 +412,8 @@ int mlagg_conv_wgrad_taps(const float *A, long a_batch, long a_row, const float 
  * nnUNetTrainer_MLAgg_2D_dt_MS.py:137-147) for every parameter in two launches.
  * tensor_table: device array of rows {param*, grad*, exp_avg*, exp_avg_sq*, int64 numel} (5 x 8 bytes each);
  * work_list: device array of int32 pairs (tensor index, chunk index), one per mlagg_adamw_chunk_elements() elements;
- * sumsq: one device double (scratch).  max_norm > 0: gradients are scaled by min(1, max_norm / (||g||_2 + 1e-6)) as they are
+ * sumsq: 1 + n_work device doubles (scratch: [0] the squared global norm, then one partial per work item, summed in a fixed
+ * order: bit-reproducible).  max_norm > 0: gradients are scaled by min(1, max_norm / (||g||_2 + 1e-6)) as they are
  * read (the global norm is formed on the device; no host synchronisation; gradients in memory stay unscaled); <= 0: no clipping.
  * step: 1-based step count for the bias corrections.  Arithmetic of torch.optim.AdamW (decoupled decay, amsgrad off).
  * ------------------------------------------------------------------------------------------ */

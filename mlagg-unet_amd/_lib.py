@@ -60,7 +60,8 @@ SIGNATURES = {
     "mlagg_diff_lambda_bwd": (_I, [_F, _F, _F, _F, _F, _F, _I, _F, _F, _F, _F, _S]),
     "mlagg_scaled_residual": (_I, [_F, _F, _F, _F, _I, ctypes.c_long, _S]),
     "mlagg_dice_ce_max_classes": (_I, []),
-    "mlagg_dice_ce_stats": (_I, [_F, _F, _F, _F, _F, _I, _I, ctypes.c_long, _I, _S]),
+    "mlagg_dice_ce_stats_workspace_floats": (_SZ, [_I, _I, ctypes.c_long]),
+    "mlagg_dice_ce_stats": (_I, [_F, _F, _F, _F, _F, _F, _I, _I, ctypes.c_long, _I, _S]),
     "mlagg_dice_ce_grad": (_I, [_F, _F, _F, _F, _F, _I, _I, ctypes.c_long, _I, _S]),
     "mlagg_channel_sum_workspace_floats": (_SZ, [_I, _I]),
     "mlagg_channel_sum": (_I, [_F, _F, _F, _I, _I, ctypes.c_long, _S]),

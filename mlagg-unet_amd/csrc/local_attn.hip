@@ -210,11 +210,9 @@ local_attn_fwd_kernel(const float *__restrict__ q, const float *__restrict__ kv,
 __global__ void __launch_bounds__(256)
 local_attn_bwd_a_kernel(const float *__restrict__ q, const float *__restrict__ kv, const float *__restrict__ lamp,
                         const float *__restrict__ subln_w, const float *__restrict__ dout, int dout_stride,
-                        float *__restrict__ dq, int dq_stride, float *__restrict__ ws, float *__restrict__ dlam,
-                        float *__restrict__ dsubln_w, Geom g)
+                        float *__restrict__ dq, int dq_stride, float *__restrict__ ws, float *__restrict__ pgrad, Geom g)
 {
-    __shared__ float red[4][PER + 1];      // per quad-lane r: 12 subln-weight partials (+ dlam in [0][12])
-    for (int i = threadIdx.x; i < 4 * (PER + 1); i += blockDim.x) (&red[0][0])[i] = 0.f;
+    __shared__ float red[4][4][PER + 1];   // per wave and quad-lane r: 12 subln-weight partials (+ dlam in [w][0][12])
     __syncthreads();
     const Unit u = unit_id(g);
     const float lam = lamp[0];
@@ -314,17 +312,23 @@ local_attn_bwd_a_kernel(const float *__restrict__ q, const float *__restrict__ k
         float v = dw[e];
 #pragma unroll
         for (int off = 4; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
-        if ((threadIdx.x & 63) < 4) atomicAdd(&red[threadIdx.x & 3][e], v);
+        if ((threadIdx.x & 63) < 4) red[threadIdx.x >> 6][threadIdx.x & 3][e] = v;
     }
     {
         float v = dl_acc;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&red[0][PER], v);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][0][PER] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 4 * PER) atomicAdd(dsubln_w + threadIdx.x, red[threadIdx.x / PER][threadIdx.x % PER]);
-    if (threadIdx.x == 63) atomicAdd(dlam, red[0][PER]);
+    // one partial row [d(subln_w) (48) | d(lambda)] per workgroup, summed over workgroups in a fixed order by the launcher's column
+    // sum (the first version added them with float atomics: run-to-run differences in the last bits)
+    float *prow = pgrad + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (4 * PER + 1);
+    if (threadIdx.x < 4 * PER) {
+        const int r = threadIdx.x / PER, e = threadIdx.x % PER;
+        prow[threadIdx.x] = (red[0][r][e] + red[1][r][e]) + (red[2][r][e] + red[3][r][e]);
+    }
+    if (threadIdx.x == 63) prow[4 * PER] = (red[0][0][PER] + red[1][0][PER]) + (red[2][0][PER] + red[3][0][PER]);
 }
 
 // backward B: gather dk, dv for token t from the <= 9 windows that contain it
@@ -401,7 +405,9 @@ extern "C" int mlagg_local_attn_fwd(const float *q, int q_stride, const float *k
 
 extern "C" size_t mlagg_local_attn_bwd_workspace_floats(int batch, int H, int W, int nh)
 {
-    return (size_t)batch * H * W * nh * WS_PER_UNIT + mlagg_internal::dwconv_wgrad_workspace_floats(batch, H, W, nh * HD2);
+    const size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE) * nh * batch;
+    return (size_t)batch * H * W * nh * WS_PER_UNIT + mlagg_internal::dwconv_wgrad_workspace_floats(batch, H, W, nh * HD2) +
+           tiles * (4 * PER + 1);
 }
 
 extern "C" int mlagg_local_attn_bwd(const float *q, int q_stride, const float *kv, int kv_stride,
@@ -420,8 +426,13 @@ extern "C" int mlagg_local_attn_bwd(const float *q, int q_stride, const float *k
         (dkv_stride & 3))
         return MLAGG_E_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    { MLAGG_TIMED(K_LOCAL_BWD_A, st); hipLaunchKernelGGL(local_attn_bwd_a_kernel, tile_grid(g), dim3(256), 0, st, q, kv, lam, subln_w, dout,
-                       dout_stride, dq, dq_stride, workspace, dlam, dsubln_w, g); }
+    const dim3 tg = tile_grid(g);
+    const int nwg = (int)(tg.x * tg.y * tg.z);
+    float *pgrad = workspace + (size_t)batch * H * W * nh * WS_PER_UNIT + mlagg_internal::dwconv_wgrad_workspace_floats(batch, H, W, g.d);
+    { MLAGG_TIMED(K_LOCAL_BWD_A, st); hipLaunchKernelGGL(local_attn_bwd_a_kernel, tg, dim3(256), 0, st, q, kv, lam, subln_w, dout,
+                       dout_stride, dq, dq_stride, workspace, pgrad, g);
+      hipLaunchKernelGGL(mlagg_internal::column_sum_split_kernel<0>, dim3(1), dim3(1024), 0, st, pgrad, nwg, 4 * PER + 1, 4 * PER + 1,
+                         4 * PER, dsubln_w, dlam); }
     { MLAGG_TIMED(K_LOCAL_BWD_B, st); hipLaunchKernelGGL(local_attn_bwd_b_kernel, tile_grid(g), dim3(256), 0, st, q, lepe_w, dout, dout_stride,
                        workspace, dkv, dkv_stride, g); }
     // LePE is a depthwise 3x3 on v: its weight/bias gradients are K2's weight-gradient kernel on (v, dout)

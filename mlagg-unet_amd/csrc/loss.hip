@@ -41,19 +41,20 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// Partial sums leave the workgroup as ONE row [I(C) | P(C) | G(C) | ce] of `part` and are added up in a fixed order by
+// dice_ce_reduce_kernel: the first version accumulated them with float atomics (LDS, then global), which made the LOSS VALUE -- and
+// through the dice gradient every gradient of the step -- differ in the last bits between two runs on identical inputs
+// (tools/find_nondeterminism.py; profiles/round3_nondeterminism.log).
 __global__ void __launch_bounds__(TPB)
-dice_ce_stats_kernel(const float *__restrict__ logits, const float *__restrict__ target, float *__restrict__ stats_ip,
-                     float *__restrict__ stats_g, float *__restrict__ ce_sum, LossGeom g)
+dice_ce_stats_kernel(const float *__restrict__ logits, const float *__restrict__ target, float *__restrict__ part, LossGeom g)
 {
-    __shared__ float red[3 * MAXC + 1];
+    __shared__ float red[TPB / 64][3 * MAXC + 1];
     const int b = blockIdx.y, C = g.C;
     const float *zb = logits + (size_t)b * C * g.HW;
     const float *tb = target + (size_t)b * g.HW;
     float aI[MAXC], aP[MAXC], aG[MAXC], ace = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) aI[c] = aP[c] = aG[c] = 0.f;
-    for (int i = threadIdx.x; i < 3 * MAXC + 1; i += TPB) red[i] = 0.f;
-    __syncthreads();
 
     const long p0 = (long)blockIdx.x * (TPB * PPT) + threadIdx.x;
 #pragma unroll
@@ -88,27 +89,55 @@ dice_ce_stats_kernel(const float *__restrict__ logits, const float *__restrict__
         }
         ace += valid ? logf(s) - zy : 0.f;                 // -log softmax(z)_y (CrossEntropyLoss(ignore_index))
     }
-    // block reduction: wave butterflies, then LDS adds, then one global add per value
+    // block reduction: wave butterflies, one LDS row per wave, the four rows added in a fixed order, one partial row per workgroup
+    const int wv = threadIdx.x >> 6;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         if (c < C) {
             const float vI = wave_sum(aI[c]), vP = wave_sum(aP[c]), vG = wave_sum(aG[c]);
-            if ((threadIdx.x & 63) == 0) {
-                atomicAdd(red + c, vI);
-                atomicAdd(red + MAXC + c, vP);
-                atomicAdd(red + 2 * MAXC + c, vG);
-            }
+            if ((threadIdx.x & 63) == 0) { red[wv][c] = vI; red[wv][MAXC + c] = vP; red[wv][2 * MAXC + c] = vG; }
         }
     }
     ace = wave_sum(ace);
-    if ((threadIdx.x & 63) == 0) atomicAdd(red + 3 * MAXC, ace);
+    if ((threadIdx.x & 63) == 0) red[wv][3 * MAXC] = ace;
     __syncthreads();
-    if (threadIdx.x < C) {
-        atomicAdd(stats_ip + ((size_t)b * 2 + 0) * C + threadIdx.x, red[threadIdx.x]);
-        atomicAdd(stats_ip + ((size_t)b * 2 + 1) * C + threadIdx.x, red[MAXC + threadIdx.x]);
-        atomicAdd(stats_g + (size_t)b * C + threadIdx.x, red[2 * MAXC + threadIdx.x]);
+    float *row = part + ((size_t)b * gridDim.x + blockIdx.x) * (3 * C + 1);
+    if (threadIdx.x < 3 * C) {
+        const int which = threadIdx.x / C, c = threadIdx.x - which * C, i = which * MAXC + c;
+        row[threadIdx.x] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
     }
-    if (threadIdx.x == 0) atomicAdd(ce_sum, red[3 * MAXC]);
+    if (threadIdx.x == 3 * C) row[3 * C] = (red[0][3 * MAXC] + red[1][3 * MAXC]) + (red[2][3 * MAXC] + red[3][3 * MAXC]);
+}
+
+// stats_ip (B, 2, C), stats_g (B, C) = column sums of the nblk partial rows of every sample; ce_sum = sum of all ce partials.
+// One workgroup, fixed assignment and order: deterministic.
+__global__ void __launch_bounds__(256)
+dice_ce_reduce_kernel(const float *__restrict__ part, int nblk, float *__restrict__ stats_ip, float *__restrict__ stats_g,
+                      float *__restrict__ ce_sum, int B, int C)
+{
+    __shared__ float red[256];
+    const int W = 3 * C + 1;
+    for (int i = threadIdx.x; i < B * 3 * C; i += 256) {
+        const int b = i / (3 * C), v = i - b * 3 * C;
+        const float *p = part + (size_t)b * nblk * W + v;
+        float s0 = 0.f, s1 = 0.f;
+        int r = 0;
+        for (; r + 1 < nblk; r += 2) { s0 += p[(size_t)r * W]; s1 += p[(size_t)(r + 1) * W]; }
+        if (r < nblk) s0 += p[(size_t)r * W];
+        const float s = s0 + s1;
+        const int which = v / C, c = v - which * C;
+        if (which < 2) stats_ip[((size_t)b * 2 + which) * C + c] = s;
+        else stats_g[(size_t)b * C + c] = s;
+    }
+    float a = 0.f;
+    for (long i = threadIdx.x; i < (long)B * nblk; i += 256) a += part[(size_t)i * W + 3 * C];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *ce_sum = red[0];
 }
 
 __global__ void __launch_bounds__(TPB)
@@ -174,16 +203,23 @@ int check(int B, int C, long HW)
 
 extern "C" int mlagg_dice_ce_max_classes(void) { return MAXC; }
 
-extern "C" int mlagg_dice_ce_stats(const float *logits, const float *target, float *stats_ip, float *stats_g, float *ce_sum,
-                                   int B, int C, long HW, int ignore_label, void *stream)
+extern "C" size_t mlagg_dice_ce_stats_workspace_floats(int B, int C, long HW)
 {
-    if (!logits || !target || !stats_ip || !stats_g || !ce_sum) return MLAGG_E_NULLPTR;
+    if (B <= 0 || C <= 0 || HW <= 0) return 0;
+    return (size_t)B * ((HW + TPB * PPT - 1) / (TPB * PPT)) * (3 * C + 1);
+}
+
+extern "C" int mlagg_dice_ce_stats(const float *logits, const float *target, float *stats_ip, float *stats_g, float *ce_sum,
+                                   float *workspace, int B, int C, long HW, int ignore_label, void *stream)
+{
+    if (!logits || !target || !stats_ip || !stats_g || !ce_sum || !workspace) return MLAGG_E_NULLPTR;
     if (int rc = check(B, C, HW)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     LossGeom g{B, C, HW, ignore_label};
+    const unsigned nblk = (unsigned)((HW + TPB * PPT - 1) / (TPB * PPT));
     MLAGG_TIMED(K_LOSS_STATS, st);
-    hipLaunchKernelGGL(dice_ce_stats_kernel, dim3((unsigned)((HW + TPB * PPT - 1) / (TPB * PPT)), B), dim3(TPB), 0, st, logits,
-                       target, stats_ip, stats_g, ce_sum, g);
+    hipLaunchKernelGGL(dice_ce_stats_kernel, dim3(nblk, B), dim3(TPB), 0, st, logits, target, workspace, g);
+    hipLaunchKernelGGL(dice_ce_reduce_kernel, dim3(1), dim3(256), 0, st, workspace, (int)nblk, stats_ip, stats_g, ce_sum, B, C);
     return (int)hipGetLastError();
 }
 

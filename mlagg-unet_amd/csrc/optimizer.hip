@@ -56,7 +56,24 @@ adamw_sumsq_kernel(const TensorRow *__restrict__ table, const int2 *__restrict__
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(sumsq, (double)((red[0] + red[1]) + (red[2] + red[3])));
+    // one partial per work item, added up in a fixed order by adamw_sumsq_reduce_kernel (a double atomic add made the clip
+    // coefficient -- hence every parameter -- depend on the arrival order in the last bit)
+    if (threadIdx.x == 0) sumsq[1 + blockIdx.x] = (double)((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+__global__ void __launch_bounds__(OPT_TPB)
+adamw_sumsq_reduce_kernel(double *__restrict__ sumsq, int n_work)
+{
+    __shared__ double red[OPT_TPB];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n_work; i += OPT_TPB) s += sumsq[1 + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = OPT_TPB / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sumsq[0] = red[0];
 }
 
 struct AdamArgs {
@@ -124,8 +141,8 @@ extern "C" int mlagg_adamw_clip_step(const void *tensor_table, const void *work_
     a.bias_c2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     MLAGG_TIMED(K_ADAMW, st);
     if (max_norm > 0.f) {
-        (void)hipMemsetAsync(sumsq, 0, sizeof(double), st);
         hipLaunchKernelGGL(adamw_sumsq_kernel, dim3(n_work), dim3(OPT_TPB), 0, st, table, work, sumsq);
+        hipLaunchKernelGGL(adamw_sumsq_reduce_kernel, dim3(1), dim3(OPT_TPB), 0, st, sumsq, n_work);
     }
     hipLaunchKernelGGL(adamw_update_kernel, dim3(n_work), dim3(OPT_TPB), 0, st, table, work, sumsq, a);
     return (int)hipGetLastError();

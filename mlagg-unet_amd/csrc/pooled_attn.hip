@@ -22,6 +22,7 @@
 
 #include "mlagg_hip.h"
 #include "prof.h"
+#include "internal.h"
 
 namespace {
 
@@ -156,7 +157,7 @@ pooled_attn_bwd1_kernel(const float *__restrict__ q, const float *__restrict__ k
                         const float *__restrict__ lamp, const float *__restrict__ subln_w,
                         const float *__restrict__ dout, int dout_stride, const float *__restrict__ lse,
                         const float *__restrict__ o_pre, float *__restrict__ dq, int dq_stride,
-                        float *__restrict__ ws, float *__restrict__ dlam, float *__restrict__ dsubln_w, Geom g)
+                        float *__restrict__ ws, float *__restrict__ pgrad, Geom g)
 {
     extern __shared__ float4 smem4[];
     float *sK = reinterpret_cast<float *>(smem4);
@@ -238,8 +239,8 @@ pooled_attn_bwd1_kernel(const float *__restrict__ q, const float *__restrict__ k
     if (threadIdx.x < 49) {
         float s = 0.f;
         for (int i = 0; i < TOK_PER_BLOCK; ++i) s += red[i * 49 + threadIdx.x];
-        if (threadIdx.x < HD2) atomicAdd(dsubln_w + threadIdx.x, s);
-        else atomicAdd(dlam, s);
+        // one partial row [d(subln_w) (48) | d(lambda)] per workgroup; the launcher's column sum adds them in a fixed order
+        pgrad[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 49 + threadIdx.x] = s;
     }
 }
 
@@ -421,7 +422,8 @@ extern "C" int mlagg_pooled_attn_fwd(const float *q, int q_stride, const float *
 extern "C" size_t mlagg_pooled_attn_bwd_workspace_floats(int batch, int N, int P, int nh)
 {
     const size_t nblocks = (size_t)((P + 63) / 64) * ((N + B2_TPB - 1) / B2_TPB);
-    return (size_t)batch * N * nh * WS_PER_UNIT + (size_t)batch * nh * nblocks * 2 * (64 * HD2);
+    return (size_t)batch * N * nh * WS_PER_UNIT + (size_t)batch * nh * nblocks * 2 * (64 * HD2) +
+           (size_t)batch * nh * ((N + TOK_PER_BLOCK - 1) / TOK_PER_BLOCK) * 49;
 }
 
 extern "C" int mlagg_pooled_attn_bwd(const float *q, int q_stride, const float *kp, int kp_stride, const float *vp,
@@ -441,12 +443,15 @@ extern "C" int mlagg_pooled_attn_bwd(const float *q, int q_stride, const float *
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t lds = kv_lds_bytes(g, true);
     if (int rc = allow_lds(pooled_attn_bwd1_kernel, lds)) return rc;
-    { MLAGG_TIMED(K_POOLED_BWD1, st); hipLaunchKernelGGL(pooled_attn_bwd1_kernel, dim3((N + TOK_PER_BLOCK - 1) / TOK_PER_BLOCK, nh, batch), dim3(256),
-                       lds, st, q, kp, vp, lam, subln_w, dout, dout_stride, lse, o_pre, dq, dq_stride, workspace,
-                       dlam, dsubln_w, g); }
     const int pblocks = (P + 63) / 64;
     const int tblocks = (N + B2_TPB - 1) / B2_TPB;
     float *part = workspace + (size_t)batch * N * nh * WS_PER_UNIT;
+    float *pgrad = part + (size_t)batch * nh * pblocks * tblocks * 2 * (64 * HD2);
+    const int nb1 = (N + TOK_PER_BLOCK - 1) / TOK_PER_BLOCK;
+    { MLAGG_TIMED(K_POOLED_BWD1, st); hipLaunchKernelGGL(pooled_attn_bwd1_kernel, dim3(nb1, nh, batch), dim3(256),
+                       lds, st, q, kp, vp, lam, subln_w, dout, dout_stride, lse, o_pre, dq, dq_stride, workspace, pgrad, g);
+      hipLaunchKernelGGL(mlagg_internal::column_sum_split_kernel<0>, dim3(1), dim3(1024), 0, st, pgrad, nb1 * nh * batch, 49, 49, 48,
+                         dsubln_w, dlam); }
     {
         MLAGG_TIMED(K_POOLED_BWD2, st);
         hipLaunchKernelGGL(pooled_attn_bwd2_kernel, dim3(pblocks * tblocks, nh, batch), dim3(256), 0, st, q, kp, vp,

@@ -1006,7 +1006,7 @@ class DiceCEStatsFn(torch.autograd.Function):
         lib = _lib.lib()
         if C > lib.mlagg_dice_ce_max_classes():
             raise RuntimeError(f"dice_ce_stats: at most {lib.mlagg_dice_ce_max_classes()} classes")
-        buf = torch.zeros(n * B * 3 * C + n, device=dev, dtype=torch.float32)       # ONE fill for all levels
+        buf = torch.empty(n * B * 3 * C + n, device=dev, dtype=torch.float32)       # every entry is written by the level's reduce
         ip = buf[:n * B * 2 * C].view(n, B, 2, C)
         gt = buf[n * B * 2 * C:n * B * 3 * C].view(n, B, C)
         ce = buf[n * B * 3 * C:]
@@ -1017,7 +1017,8 @@ class DiceCEStatsFn(torch.autograd.Function):
             if z.shape[:2] != (B, C) or t.numel() * C != z.numel():
                 raise RuntimeError("dice_ce_stats: logits / target shapes of a level do not match")
             hw = z.numel() // (B * C)
-            _lib.check(lib.mlagg_dice_ce_stats(_ptr(z), _ptr(t), _ptr(ip[i]), _ptr(gt[i]), ce.data_ptr() + 4 * i, B, C, hw,
+            ws = torch.empty(lib.mlagg_dice_ce_stats_workspace_floats(B, C, hw), device=dev, dtype=torch.float32)
+            _lib.check(lib.mlagg_dice_ce_stats(_ptr(z), _ptr(t), _ptr(ip[i]), _ptr(gt[i]), ce.data_ptr() + 4 * i, _ptr(ws), B, C, hw,
                                                ctx.ignore, _stream()), "mlagg_dice_ce_stats")
             saved += [z, t]
         ctx.save_for_backward(*saved)

@@ -213,8 +213,8 @@ class ClipAdamW(torch.optim.Optimizer):
                 if not (p.grad.is_contiguous() and p.grad.dtype == torch.float32):
                     raise RuntimeError("ClipAdamW: fp32 contiguous gradients expected")
             table = host.pin_memory().to(dev, non_blocking=True)
-            if self._sumsq is None or self._sumsq.device != dev:
-                self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+            if self._sumsq is None or self._sumsq.device != dev or self._sumsq.numel() != 1 + work.shape[0]:
+                self._sumsq = torch.zeros(1 + work.shape[0], dtype=torch.float64, device=dev)       # [0]: total; one partial per work item
             b1, b2 = group["betas"]
             lr = float(group["lr"])
             _lib.check(lib.mlagg_adamw_clip_step(table.data_ptr(), work.data_ptr(), work.shape[0], self._sumsq.data_ptr(), lr,
@@ -226,7 +226,7 @@ class ClipAdamW(torch.optim.Optimizer):
 
     def grad_norm(self):
         """||g||_2 of the last step (device tensor; reading it synchronises)."""
-        return self._sumsq.sqrt().float()
+        return self._sumsq[:1].sqrt().float()
 
 
 def configure_optimizers(model, initial_lr=5e-4, weight_decay=3e-5, fused=None, capturable=False):
@@ -293,6 +293,17 @@ def wrap_ddp(model, device_index=None, bucket_cap_mb=25):
     ids = None if device_index is None else [device_index]
     return DDP(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True,
                broadcast_buffers=False)
+
+
+def set_deterministic(enabled=True):
+    """Bit-reproducible train steps.  This package's kernels on the train path hold no float atomics (per-workgroup partials
+    summed in a fixed order; round 3 removed the last ones: K9's loss statistics, K3 / K4's d(lambda) / d(subln) sums, the clip
+    norm); what still differed between two runs on identical inputs were MIOpen solvers that accumulate with atomics (the 1x1 /
+    transposed-convolution weight gradients and one data gradient: tools/find_nondeterminism.py, profiles/round3_nondeterminism_*).
+    ``torch.backends.cudnn.deterministic`` is PyTorch's switch for MIOpen's deterministic-solvers-only attribute: with it all 524
+    gradients of a 256 x 256 batch-10 step are bit-identical from run to run.  Not the default: it takes the tuned find-db's
+    solver picks away from those layers."""
+    torch.backends.cudnn.deterministic = bool(enabled)
 
 
 def set_deep_supervision_enabled(network, enabled):

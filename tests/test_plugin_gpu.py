@@ -51,6 +51,30 @@ def test_plugin_train_step_equals_trainer_train_step():
     assert_same_trajectory(tr.network, twin, steps=2, lr=tr.initial_lr)
 
 
+def test_plugin_and_trainer_steps_are_bit_identical_in_deterministic_mode():
+    """The strict form of the test above: with ``trainer.set_deterministic`` two independent runs of the
+    same two steps -- the plugin's ``train_step`` behind the reference loop and ``trainer.train_step`` on a twin -- end on
+    bit-identical losses and parameters.  (The float-atomic kernels that used to differ were this package's own K9 statistics,
+    K3 / K4 parameter sums and clip norm, all replaced by fixed-order reductions, plus MIOpen's atomic solvers, which the
+    deterministic attribute excludes: profiles/round3_nondeterminism_*.log.)"""
+    from mlagg_unet_amd import trainer
+    trainer.set_deterministic(True)
+    try:
+        tr = _trainer()
+        twin = copy.deepcopy(tr.network)
+        twin_opt, _ = trainer.configure_optimizers(twin, tr.initial_lr, tr.weight_decay)
+        for b in _batches(2):
+            torch.manual_seed(5)
+            got = tr.train_step(b)
+            torch.manual_seed(5)
+            want = trainer.train_step(twin, twin_opt, b["data"].cuda(), [t.cuda() for t in b["target"]], batch_dice=True)
+            assert float(got["loss"]) == float(want)
+        for (k, a), b in zip(tr.network.state_dict().items(), twin.state_dict().values()):
+            assert torch.equal(a, b), k
+    finally:
+        trainer.set_deterministic(False)
+
+
 def test_reference_amp_step_also_runs_on_the_product_network():
     """The inherited body of B:833-863 (autocast('cuda') + GradScaler) is not what the plugin runs, but a maintainer who
     keeps it must not crash: the network leaves autocast for its own precision, gradients come back fp32, and the scaled
