@@ -256,9 +256,14 @@ def main():
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    ddp = world > 1
+    # MLAGG_FORCE_DDP=1: the data-parallel code path (RCCL process group, DDP buckets, batch-dice all-reduce) with ONE rank -- the
+    # only way to execute the `nccl` branch on a single-GPU box (RCCL refuses two ranks per device); a rehearsal, never a result
+    ddp = world > 1 or os.environ.get("MLAGG_FORCE_DDP", "0") == "1"
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
         else:
@@ -282,7 +287,7 @@ def main():
     gemm_db = gemm_tuning.use_tuned_gemms(enabled=mode == "auto" and args.precision is None and args.config == 2)
     torch.manual_seed(0)
     net = model.build_network_architecture(IMG, cfg["in_ch"], N_CLASSES, True, cfg["variant"], cfg["precision"]).to(dev).train()
-    use_graph = args.graph and not ddp and not args.no_graph and cfg["precision"] == "fp32"
+    use_graph = args.graph and not ddp and not args.no_graph and cfg["precision"] == "fp32"      # DDP: eager (trainer.GraphedTrainStep)
     opt, sched = trainer.configure_optimizers(net, capturable=use_graph)
     sched.step(0)
     step_net = trainer.wrap_ddp(net, dev_index) if ddp else net
@@ -373,7 +378,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
             "config": {"workload": "nnUNetTrainer_MLAgg_2D_dt_MS train step, " + cfg["name"],
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}", "final_loss": round(float(loss), 5),
+                       "parallelism": f"dp{world}" + (" (single-rank RCCL rehearsal of the DDP path)" if ddp and world == 1 else ""),
+                       "final_loss": round(float(loss), 5),
                        "launch": "hipGraph replay of the whole step" if use_graph else "eager",
                        "miopen": "tuned find-db (mlagg-unet_amd/miopen_db)" if miopen_db else "immediate mode",
                        "library_gemm": "TunableOp table (mlagg-unet_amd/gemm_db), tuning off" if gemm_db else "library default"},

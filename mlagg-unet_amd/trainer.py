@@ -347,10 +347,16 @@ class GraphedTrainStep:
     """The whole train step (zero_grad, forward, loss, backward, clip, AdamW) captured once into a hipGraph
     and replayed: ~3400 kernel launches per step otherwise cost more host time than the MI355X needs to
     execute them.  Inputs are copied into static buffers; every HIP op of this package launches on the
-    capturing stream and never allocates or synchronises, so it records cleanly.  Single-process use
-    (the DDP path stays eager: its bucketed RCCL all-reduces are launched from autograd hooks)."""
+    capturing stream and never allocates or synchronises, so it records cleanly.  Single-process use: the DDP path stays eager.
+    Measured in round 3 with one RCCL rank (bench.py MLAGG_FORCE_DDP=1): the eager DDP step runs (44.7 vs 43.5 ms per step); capturing
+    it -- PyTorch's documented DDP-in-graph recipe, 11 side-stream warm-ups -- ends in a segmentation fault inside the capture on this
+    PyTorch 2.10 / ROCm 7.0 build (AccumulateGrad nodes stashed by DDP on another stream, then a crash in the RCCL work enqueue:
+    profiles/round3_ddp_graph_capture_segfault.log), so a DistributedDataParallel network is refused here."""
 
     def __init__(self, network, optimizer, data, target, batch_dice=True, clip=12.0, warmup=3):
+        if isinstance(network, torch.nn.parallel.DistributedDataParallel):
+            raise RuntimeError("GraphedTrainStep: a DistributedDataParallel network cannot be captured on this build "
+                               "(segmentation fault inside the capture); run the data-parallel step eagerly")
         self.data = data.clone()
         self.target = [t.clone() for t in target]
         body = lambda: train_step(network, optimizer, self.data, self.target, batch_dice, False, clip)  # noqa: E731
