@@ -387,6 +387,24 @@ int mlagg_plane_norm_bwd(const float *x, const float *dy, const float *gamma, co
                          long HW, int act, float slope, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K4lp: pooled differential attention on the 16-bit matrix cores (fp32 tensors in memory; q * scale, k, v, the softmax weights and
+ * d(o) rounded to bf16 / fp16 operands, fp32 sums / softmax / RMSNorm).  Replaces, under the reference's autocast step, the four
+ * `flash_attn_func(q_j, k_j, v_i, causal=False)` launches of the pooled branch, the lambda subtraction, RMSNorm and 0.2 gain
+ * (nnUNetTrainer_MLAgg_2D_dt_MS.py:733-760) and their backward.  Layouts and strides as mlagg_pooled_attn_fwd / _bwd; P <= 320.
+ * Saved for backward: lse (B, N, nh, 2) and the two maps' own outputs o1 = P1 v, o2 = P2 v (B, N, d) (NULL, NULL, NULL: inference).
+ * dtype: MLAGG_DTYPE_BF16 / MLAGG_DTYPE_F16.  Backward overwrites dq, dkp, dvp, dlam[1], dsubln_w[48]; fixed summation order.
+ * ------------------------------------------------------------------------------------------ */
+int mlagg_pooled_attn_lp_fwd(const float *q, int q_stride, const float *kp, int kp_stride, const float *vp, int vp_stride,
+                             const float *lam, const float *subln_w, float *out, int out_stride, float *lse, float *o1, float *o2,
+                             int batch, int N, int P, int nh, float scale, int dtype, void *stream);
+size_t mlagg_pooled_attn_lp_bwd_workspace_floats(int batch, int N, int P, int nh);
+int mlagg_pooled_attn_lp_bwd(const float *q, int q_stride, const float *kp, int kp_stride, const float *vp, int vp_stride,
+                             const float *lam, const float *subln_w, const float *dout, int dout_stride, const float *lse,
+                             const float *o1, const float *o2, float *dq, int dq_stride, float *dkp, int dkp_stride, float *dvp,
+                             int dvp_stride, float *dlam, float *dsubln_w, float *workspace, int batch, int N, int P, int nh,
+                             float scale, int dtype, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * K15: weight gradient of the full convolutions on channel-major maps as tap GEMMs on the fp32 matrix cores.  Replaces MIOpen's
  * weight-gradient solvers behind the backward of `nn.Conv3d` / `nn.Conv2d` (kernel 3 with padding 1, or kernel 1; stride 1 or 2) of
  * the 3-D network's BasicResBlock / BasicBlockD / UpsampleLayer / seg layers (variants/mamba/UMambaEnc_SS3D.py:49-66, 477-513,

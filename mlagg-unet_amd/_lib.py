@@ -39,6 +39,10 @@ SIGNATURES = {
     "mlagg_pooled_attn_bwd_workspace_floats": (_SZ, [_I, _I, _I, _I]),
     "mlagg_pooled_attn_bwd": (_I, [_F, _I, _F, _I, _F, _I, _F, _F, _F, _I, _F, _F, _F, _I, _F, _I, _F, _I, _F, _F,
                                    _F, _I, _I, _I, _I, _FL, _S]),
+    "mlagg_pooled_attn_lp_fwd": (_I, [_F, _I, _F, _I, _F, _I, _F, _F, _F, _I, _F, _F, _F, _I, _I, _I, _I, _FL, _I, _S]),
+    "mlagg_pooled_attn_lp_bwd_workspace_floats": (_SZ, [_I, _I, _I, _I]),
+    "mlagg_pooled_attn_lp_bwd": (_I, [_F, _I, _F, _I, _F, _I, _F, _F, _F, _I, _F, _F, _F, _F, _I, _F, _I, _F, _I, _F, _F, _F,
+                                      _I, _I, _I, _I, _FL, _I, _S]),
     "mlagg_dwconv3x3_fwd": (_I, [_F, _I, _F, _F, _F, _I, _F, _I, _I, _I, _I, _I, _S]),
     "mlagg_dwconv3x3_bwd_workspace_floats": (_SZ, [_I, _I, _I, _I]),
     "mlagg_dwconv3x3_bwd": (_I, [_F, _I, _F, _F, _I, _F, _F, _I, _F, _F, _F, _I, _I, _I, _I, _I, _S]),

@@ -414,6 +414,53 @@ class PooledDiffAttnFn(torch.autograd.Function):
         return dq, dkp, dvp, small[0].reshape(()), small[1:], None, None
 
 
+class PooledDiffAttnLpFn(torch.autograd.Function):
+    """K4lp: the pooled differential attention on the 16-bit matrix cores (csrc/pooled_attn_lp.hip) -- the 16-bit modes' form of K4:
+    q * scale, k, v, the softmax weights and d(o) are bf16 / fp16 MFMA operands (what the reference's four flash_attn_func calls see,
+    nnUNetTrainer_MLAgg_2D_dt_MS.py:733-751), sums / softmax / RMSNorm and every tensor in memory fp32."""
+
+    @staticmethod
+    def forward(ctx, q, kp, vp, lam, subln_w, nh, scale, cdt):
+        q, qs = _rows(q, "q")
+        kp, kps = _rows(kp, "k_pool")
+        vp, vps = _rows(vp, "v_pool")
+        B, N, d = q.shape
+        P = kp.shape[1]
+        if d != nh * 48 or tuple(kp.shape) != (B, P, d) or tuple(vp.shape) != (B, P, d):
+            raise RuntimeError(f"pooled_diff_attn: bad shapes q {tuple(q.shape)} k {tuple(kp.shape)} v {tuple(vp.shape)}")
+        lam = _require(lam.reshape(1).contiguous(), "lambda")
+        subln_w = _require(subln_w.contiguous(), "subln.weight", (48,))
+        out = torch.empty(B, N, d, device=q.device, dtype=torch.float32)
+        need = any(ctx.needs_input_grad)
+        lse = torch.empty(B, N, nh, 2, device=q.device, dtype=torch.float32) if need else None
+        o12 = torch.empty(2, B, N, d, device=q.device, dtype=torch.float32) if need else None
+        _lib.check(_lib.lib().mlagg_pooled_attn_lp_fwd(_ptr(q), qs, _ptr(kp), kps, _ptr(vp), vps, _ptr(lam), _ptr(subln_w), _ptr(out), d,
+                                                       _ptr(lse), _ptr(o12[0]) if need else None, _ptr(o12[1]) if need else None, B, N, P,
+                                                       nh, float(scale), _LP_CODE[cdt], _stream()), "mlagg_pooled_attn_lp_fwd")
+        ctx.save_for_backward(q, kp, vp, lam, subln_w, lse, o12)
+        ctx.geom = (nh, float(scale), cdt)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kp, vp, lam, subln_w, lse, o12 = ctx.saved_tensors
+        nh, scale, cdt = ctx.geom
+        B, N, d = q.shape
+        P = kp.shape[1]
+        dout, dos = _rows(dout, "dout")
+        lib = _lib.lib()
+        dq = torch.empty(B, N, d, device=q.device, dtype=torch.float32)
+        dkp = torch.empty(B, P, d, device=q.device, dtype=torch.float32)
+        dvp = torch.empty(B, P, d, device=q.device, dtype=torch.float32)
+        small = torch.empty(1 + 48, device=q.device, dtype=torch.float32)
+        ws = torch.empty(lib.mlagg_pooled_attn_lp_bwd_workspace_floats(B, N, P, nh), device=q.device, dtype=torch.float32)
+        _lib.check(lib.mlagg_pooled_attn_lp_bwd(_ptr(q), q.stride(1), _ptr(kp), kp.stride(1), _ptr(vp), vp.stride(1), _ptr(lam),
+                                                _ptr(subln_w), _ptr(dout), dos, _ptr(lse), _ptr(o12[0]), _ptr(o12[1]), _ptr(dq), d,
+                                                _ptr(dkp), d, _ptr(dvp), d, _ptr(small[:1]), _ptr(small[1:]), _ptr(ws), B, N, P, nh, scale,
+                                                _LP_CODE[cdt], _stream()), "mlagg_pooled_attn_lp_bwd")
+        return dq, dkp, dvp, small[0].reshape(()), small[1:], None, None, None
+
+
 class FlashAttnFn(torch.autograd.Function):
     """Boundary #3: softmax(q k^T scale) v on 16-bit (B, N, nh, 24) / (B, P, nh, 24) tensors, fp32 arithmetic."""
 
@@ -459,7 +506,13 @@ def local_diff_attn(q, kv, lam, subln_w, lepe_w, lepe_b, H, W, nh, scale):
     return LocalDiffAttnFn.apply(q, kv, lam, subln_w, lepe_w, lepe_b, H, W, nh, scale)
 
 
+K4_LP = _os.environ.get("MLAGG_K4_LP", "1") == "1"
+
+
 def pooled_diff_attn(q, k_pool, v_pool, lam, subln_w, nh, scale):
+    cdt = compute_dtype()
+    if cdt != torch.float32 and K4_LP and k_pool.shape[1] <= 320:
+        return PooledDiffAttnLpFn.apply(q, k_pool, v_pool, lam, subln_w, nh, scale, cdt)
     return PooledDiffAttnFn.apply(q, k_pool, v_pool, lam, subln_w, nh, scale)
 
 
