@@ -598,10 +598,13 @@ int allow_lds(K kernel, size_t bytes)
     return 0;
 }
 
-inline int kv_chunk_tokens(int batch, int nh, int N)
+// tokens per workgroup of the key-side kernel: enough workgroups that batch * heads * chunks * key tiles (= waves) fill the chip
+// four times over (with 49 or 64 keys a workgroup is only two waves: 0.73 ms per step at 224 x 224 with 256-token chunks)
+inline int kv_chunk_tokens(int batch, int nh, int N, int P)
 {
+    const int ntile = (P + 31) / 32;
     int ch = 4096;
-    while (ch > 256 && (long)batch * nh * ((N + ch - 1) / ch) < 512) ch >>= 1;
+    while (ch > 64 && (long)batch * nh * ((N + ch - 1) / ch) * ntile < 4096) ch >>= 1;
     return ch;
 }
 
@@ -633,7 +636,7 @@ extern "C" size_t mlagg_pooled_attn_lp_bwd_workspace_floats(int batch, int N, in
 {
     if (batch <= 0 || N <= 0 || P <= 0 || nh <= 0) return 0;
     const size_t units = (size_t)batch * N * nh;
-    const size_t nchunk = (N + kv_chunk_tokens(batch, nh, N) - 1) / kv_chunk_tokens(batch, nh, N);
+    const size_t nchunk = (N + kv_chunk_tokens(batch, nh, N, P) - 1) / kv_chunk_tokens(batch, nh, N, P);
     return units * WS_PER_UNIT + ((units + 255) / 256) * 49 + (size_t)batch * nh * nchunk * P * 96;
 }
 
@@ -653,7 +656,7 @@ extern "C" int mlagg_pooled_attn_lp_bwd(const float *q, int q_stride, const floa
     const size_t units = (size_t)batch * N * nh;
     const int nprep = (int)((units + 255) / 256);
     float *ws = workspace, *pgrad = ws + units * WS_PER_UNIT, *part = pgrad + (size_t)nprep * 49;
-    const int ch = kv_chunk_tokens(batch, nh, N), nchunk = (N + ch - 1) / ch;
+    const int ch = kv_chunk_tokens(batch, nh, N, P), nchunk = (N + ch - 1) / ch;
     {
         MLAGG_TIMED(K_POOLED_BWD1, st);
         hipLaunchKernelGGL(pooled_lp_prep_kernel, dim3(nprep), dim3(256), 0, st, dout, dout_stride, o1, o2, lam, subln_w, ws, pgrad, g);
