@@ -340,6 +340,16 @@ int mlagg_channel_epilogue_fwd(float *x, const float *bias, const float *res, fl
                                void *stream);
 int mlagg_channel_gelu_bwd(const float *pre, const float *dy, float *dpre, float *dbias, float *workspace, int B, int C,
                            long HW, void *stream);
+/* The same epilogue in the 16-bit modes, with the element type of every map in memory as an argument (MLAGG_DTYPE_*; HW % 4 == 0):
+ * x is the bf16 / fp16 output of the library convolution and is left untouched, y = act(x + bias[c] + res) is written in y_dtype
+ * (16-bit when only the next 16-bit convolution reads it, fp32 when it joins the residual stream): no cast kernels on either side
+ * of the convolution.  Backward: dx = dy * act'(x + bias + res) in dx_dtype (the convolution's gradient operand) and dbias in one
+ * pass (act 0: x / bias / res may be NULL).  Arithmetic fp32. */
+int mlagg_channel_epilogue_lp_fwd(const void *x, int x_dtype, const float *bias, const void *res, int res_dtype, void *y, int y_dtype,
+                                  int B, int C, long HW, int act, void *stream);
+int mlagg_channel_epilogue_lp_bwd(const void *x, int x_dtype, const float *bias, const void *res, int res_dtype, const void *dy,
+                                  int dy_dtype, void *dx, int dx_dtype, float *dbias, float *workspace, int B, int C, long HW, int act,
+                                  void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K9: Dice + cross-entropy statistics and gradient of one deep-supervision level.  Replaces softmax, one-hot scatter,
@@ -379,12 +389,17 @@ int mlagg_dice_ce_grad(const float *logits, const float *target, const float *g_
  * unless the planes are cut into segments; backward: needed with dgamma / dbeta or segments).
  * ------------------------------------------------------------------------------------------ */
 size_t mlagg_plane_norm_fwd_workspace_floats(int B, int C, long HW);
-int mlagg_plane_norm_fwd(const float *x, const float *gamma, const float *beta, const float *res, float *y, float *stats,
-                         float *workspace, int B, int C, long HW, float eps, int act, float slope, void *stream);
+/* x_dtype / res_dtype / y_dtype (forward), x_dtype / dy_dtype / res_dtype (backward; dx has x's type, dres res's): MLAGG_DTYPE_F32,
+ * _BF16 or _F16 -- the element type of each map IN MEMORY (arithmetic and statistics are fp32).  In the 16-bit modes a map that only
+ * a 16-bit library convolution reads or wrote is kept 16-bit (the reference's autocast tensors, nnUNetTrainer.py:848): no cast
+ * kernels around the convolutions, half the bytes through this kernel. */
+int mlagg_plane_norm_fwd(const void *x, const float *gamma, const float *beta, const void *res, void *y, float *stats,
+                         float *workspace, int B, int C, long HW, float eps, int act, float slope, int x_dtype, int res_dtype,
+                         int y_dtype, void *stream);
 size_t mlagg_plane_norm_bwd_workspace_floats(int B, int C, long HW);
-int mlagg_plane_norm_bwd(const float *x, const float *dy, const float *gamma, const float *beta, const float *res,
-                         const float *stats, float *dx, float *dres, float *dgamma, float *dbeta, float *workspace, int B, int C,
-                         long HW, int act, float slope, void *stream);
+int mlagg_plane_norm_bwd(const void *x, const void *dy, const float *gamma, const float *beta, const void *res, const float *stats,
+                         void *dx, void *dres, float *dgamma, float *dbeta, float *workspace, int B, int C, long HW, int act,
+                         float slope, int x_dtype, int dy_dtype, int res_dtype, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K4lp: pooled differential attention on the 16-bit matrix cores (fp32 tensors in memory; q * scale, k, v, the softmax weights and

@@ -71,9 +71,9 @@ SIGNATURES = {
     "mlagg_channel_sum": (_I, [_F, _F, _F, _I, _I, ctypes.c_long, _S]),
     "mlagg_column_sum": (_I, [_F, _I, _F, _I, _I, _S]),
     "mlagg_plane_norm_fwd_workspace_floats": (_SZ, [_I, _I, ctypes.c_long]),
-    "mlagg_plane_norm_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _I, _I, ctypes.c_long, ctypes.c_float, _I, ctypes.c_float, _S]),
+    "mlagg_plane_norm_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _I, _I, ctypes.c_long, ctypes.c_float, _I, ctypes.c_float, _I, _I, _I, _S]),
     "mlagg_plane_norm_bwd_workspace_floats": (_SZ, [_I, _I, ctypes.c_long]),
-    "mlagg_plane_norm_bwd": (_I, [_F] * 11 + [_I, _I, ctypes.c_long, _I, ctypes.c_float, _S]),
+    "mlagg_plane_norm_bwd": (_I, [_F] * 11 + [_I, _I, ctypes.c_long, _I, ctypes.c_float, _I, _I, _I, _S]),
     "mlagg_adamw_chunk_elements": (_I, []),
     "mlagg_adamw_clip_step": (_I, [_F, _F, _I, _F] + [ctypes.c_float] * 6 + [_I, _S]),
     "mlagg_transpose_2d": (_I, [_F, ctypes.c_long, _F, _I, _I, _I, _S]),
@@ -88,6 +88,8 @@ SIGNATURES = {
     "mlagg_flash_attn_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _FL, _I, _S]),
     "mlagg_channel_epilogue_fwd": (_I, [_F, _F, _F, _F, _I, _I, ctypes.c_long, _I, _S]),
     "mlagg_channel_gelu_bwd": (_I, [_F, _F, _F, _F, _F, _I, _I, ctypes.c_long, _S]),
+    "mlagg_channel_epilogue_lp_fwd": (_I, [_F, _I, _F, _F, _I, _F, _I, _I, _I, ctypes.c_long, _I, _S]),
+    "mlagg_channel_epilogue_lp_bwd": (_I, [_F, _I, _F, _F, _I, _F, _I, _F, _I, _F, _F, _I, _I, ctypes.c_long, _I, _S]),
     "mlagg_index_scan": (_I, [_F, ctypes.c_long, _I, _F, _F, _I, _I, _I, _I, _S]),
     "mlagg_index_merge": (_I, [_F, _F, _F, ctypes.c_long, _I, _I, _I, _I, _I, _S]),
     "mlagg_block_sum": (_I, [_F, _F, ctypes.c_long, _I, _I, _S]),

@@ -10,13 +10,17 @@
 // config 2.  A workgroup owns one plane: pass 1 sums it from HBM, passes 2 (variance about the mean) and 3 (write) re-read
 // it from L2 (a plane is at most 256 KB); backward the same with two reductions.  d(gamma), d(beta) leave as per-plane
 // partials and are summed over the batch by the shared column-sum kernel.
-// HBM-bound: 8 bytes per element forward, 12 backward.
+// HBM-bound: 8 bytes per element forward, 12 backward (fp32 maps).
+//
+// Round 3: every map (x, res, y; dy, dx, dres) carries an element-type code (lpio.h): in the bf16 / fp16 modes a map that only a
+// 16-bit library convolution reads or wrote stays 16-bit in memory (the reference's autocast tensors), statistics and arithmetic fp32.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "mlagg_hip.h"
 #include "prof.h"
 #include "internal.h"
+#include "lpio.h"
 
 namespace {
 
@@ -49,65 +53,87 @@ __device__ __forceinline__ float act_bwd(float v, int act, float slope)      // 
     return 1.f;
 }
 
+
+using namespace mlagg_lpio;
+
+struct PNF {                 // forward operands
+    const void *x, *res;
+    void *y;
+    const float *gamma, *beta;
+    float *stats;
+    int xdt, rdt, ydt, C, act;
+    long HW;
+    float eps, slope;
+};
+
+struct PNB {                 // backward operands
+    const void *x, *dy, *res;
+    void *dx, *dres;
+    const float *gamma, *beta, *stats;
+    float *part;
+    int xdt, gdt, rdt, C, act;
+    long HW;
+    float slope;
+};
+
+// streaming forward: three passes over the plane (the second and third from L2); VEC: HW % 4 == 0 and aligned planes
 template <bool VEC>
 __global__ void __launch_bounds__(256)
-plane_norm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
-                      const float *__restrict__ res, float *__restrict__ y, float *__restrict__ stats, int C, long HW,
-                      float eps, int act, float slope)
+plane_norm_fwd_kernel(PNF a)
 {
     __shared__ float red[4];
-    const long plane = blockIdx.x;
-    const int c = (int)(plane % C);
-    const float *xp = x + plane * HW;
-    float *yp = y + plane * HW;
-    const float *rp = res ? res + plane * HW : nullptr;
+    const long plane = blockIdx.x, HW = a.HW;
+    const int c = (int)(plane % a.C);
+    const void *xp = plane_ptr(a.x, plane, HW, a.xdt);
+    void *yp = plane_ptr(a.y, plane, HW, a.ydt);
+    const void *rp = a.res ? plane_ptr(a.res, plane, HW, a.rdt) : nullptr;
     const long n4 = VEC ? HW >> 2 : 0;
     float s = 0.f;
     for (long i = threadIdx.x; i < n4; i += 256) {
-        const float4 a = reinterpret_cast<const float4 *>(xp)[i];
-        s += (a.x + a.y) + (a.z + a.w);
+        const float4 v = ld4(xp, i, a.xdt);
+        s += (v.x + v.y) + (v.z + v.w);
     }
-    for (long i = 4 * n4 + threadIdx.x; i < HW; i += 256) s += xp[i];
+    for (long i = 4 * n4 + threadIdx.x; i < HW; i += 256) s += ld1(xp, i, a.xdt);
     const float mean = block_sum(s, red) / (float)HW;
     float q = 0.f;
     for (long i = threadIdx.x; i < n4; i += 256) {
-        const float4 a = reinterpret_cast<const float4 *>(xp)[i];
-        const float d0 = a.x - mean, d1 = a.y - mean, d2 = a.z - mean, d3 = a.w - mean;
+        const float4 v = ld4(xp, i, a.xdt);
+        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
         q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
     }
-    for (long i = 4 * n4 + threadIdx.x; i < HW; i += 256) { const float d = xp[i] - mean; q += d * d; }
-    const float rstd = rsqrtf(block_sum(q, red) / (float)HW + eps);
-    const float ga = (gamma ? gamma[c] : 1.f) * rstd, be = (beta ? beta[c] : 0.f) - mean * ga;
+    for (long i = 4 * n4 + threadIdx.x; i < HW; i += 256) { const float d = ld1(xp, i, a.xdt) - mean; q += d * d; }
+    const float rstd = rsqrtf(block_sum(q, red) / (float)HW + a.eps);
+    const float ga = (a.gamma ? a.gamma[c] : 1.f) * rstd, be = (a.beta ? a.beta[c] : 0.f) - mean * ga;
+    const int act = a.act;
+    const float slope = a.slope;
     for (long i = threadIdx.x; i < n4; i += 256) {
-        const float4 a = reinterpret_cast<const float4 *>(xp)[i];
-        const float4 r = rp ? reinterpret_cast<const float4 *>(rp)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        reinterpret_cast<float4 *>(yp)[i] = make_float4(act_fwd(a.x * ga + be + r.x, act, slope), act_fwd(a.y * ga + be + r.y, act, slope),
-                                                         act_fwd(a.z * ga + be + r.z, act, slope), act_fwd(a.w * ga + be + r.w, act, slope));
+        const float4 v = ld4(xp, i, a.xdt);
+        const float4 r = rp ? ld4(rp, i, a.rdt) : make_float4(0.f, 0.f, 0.f, 0.f);
+        st4(yp, i, a.ydt, make_float4(act_fwd(v.x * ga + be + r.x, act, slope), act_fwd(v.y * ga + be + r.y, act, slope),
+                                      act_fwd(v.z * ga + be + r.z, act, slope), act_fwd(v.w * ga + be + r.w, act, slope)));
     }
-    for (long i = 4 * n4 + threadIdx.x; i < HW; i += 256) yp[i] = act_fwd(xp[i] * ga + be + (rp ? rp[i] : 0.f), act, slope);
-    if (threadIdx.x == 0) { stats[2 * plane] = mean; stats[2 * plane + 1] = rstd; }
+    for (long i = 4 * n4 + threadIdx.x; i < HW; i += 256)
+        st1(yp, i, a.ydt, act_fwd(ld1(xp, i, a.xdt) * ga + be + (rp ? ld1(rp, i, a.rdt) : 0.f), act, slope));
+    if (threadIdx.x == 0) { a.stats[2 * plane] = mean; a.stats[2 * plane + 1] = rstd; }
 }
 
 // g = dy * act'(pre);  dx = rstd * gamma * (g - mean(g) - xhat * mean(g * xhat));  partials: sum g * xhat, sum g
-// RES as a template flag and 4 float4 groups per loop trip: with `rp ? load : 0` inside a rolled loop every trip had one or
-// two loads in flight per lane and a wait between x / dy and the residual; planes are few (B * C workgroups), so the loop
-// itself has to provide the memory-level parallelism.
+// RES as a template flag and 4 groups per loop trip: planes are few (B * C workgroups), so the loop itself has to provide the
+// memory-level parallelism.
 template <bool VEC, bool RES>
 __global__ void __launch_bounds__(256)
-plane_norm_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ gamma,
-                      const float *__restrict__ beta, const float *__restrict__ res, const float *__restrict__ stats,
-                      float *__restrict__ dx, float *__restrict__ dres, float *__restrict__ part, int C, long HW, int act,
-                      float slope)
+plane_norm_bwd_kernel(PNB a)
 {
     __shared__ float red[4];
-    const long plane = blockIdx.x;
-    const int c = (int)(plane % C);
-    const float *xp = x + plane * HW, *gp = dy + plane * HW;
-    float *dp = dx + plane * HW;
-    const float *rp = res ? res + plane * HW : nullptr;
-    float *drp = dres ? dres + plane * HW : nullptr;
-    const float mean = stats[2 * plane], rstd = stats[2 * plane + 1];
-    const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    const long plane = blockIdx.x, HW = a.HW;
+    const int c = (int)(plane % a.C), act = a.act;
+    const float slope = a.slope;
+    const void *xp = plane_ptr(a.x, plane, HW, a.xdt), *gp = plane_ptr(a.dy, plane, HW, a.gdt);
+    void *dp = plane_ptr(a.dx, plane, HW, a.xdt);
+    const void *rp = RES ? plane_ptr(a.res, plane, HW, a.rdt) : nullptr;
+    void *drp = (RES && a.dres) ? plane_ptr(a.dres, plane, HW, a.rdt) : nullptr;
+    const float mean = a.stats[2 * plane], rstd = a.stats[2 * plane + 1];
+    const float ga = a.gamma ? a.gamma[c] : 1.f, be = a.beta ? a.beta[c] : 0.f;
     const long n4 = VEC ? HW >> 2 : 0;
     float s1 = 0.f, s2 = 0.f;
     auto term = [&](float xv, float gv, float rv, float &xh) {
@@ -118,73 +144,71 @@ plane_norm_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy,
     constexpr int UN = 4;
     long i0 = threadIdx.x;
     for (; i0 + 256 * (UN - 1) < n4; i0 += 256 * UN) {
-        float4 a[UN], g4[UN], r[UN];
+        float4 x4[UN], g4[UN], r[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            a[u] = reinterpret_cast<const float4 *>(xp)[i0 + 256 * u];
-            g4[u] = reinterpret_cast<const float4 *>(gp)[i0 + 256 * u];
-            r[u] = RES ? reinterpret_cast<const float4 *>(rp)[i0 + 256 * u] : z4;
+            x4[u] = ld4(xp, i0 + 256 * u, a.xdt);
+            g4[u] = ld4(gp, i0 + 256 * u, a.gdt);
+            r[u] = RES ? ld4(rp, i0 + 256 * u, a.rdt) : z4;
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             float xh;
-            float t = term(a[u].x, g4[u].x, r[u].x, xh); s1 += t; s2 += t * xh;
-            t = term(a[u].y, g4[u].y, r[u].y, xh); s1 += t; s2 += t * xh;
-            t = term(a[u].z, g4[u].z, r[u].z, xh); s1 += t; s2 += t * xh;
-            t = term(a[u].w, g4[u].w, r[u].w, xh); s1 += t; s2 += t * xh;
+            float t = term(x4[u].x, g4[u].x, r[u].x, xh); s1 += t; s2 += t * xh;
+            t = term(x4[u].y, g4[u].y, r[u].y, xh); s1 += t; s2 += t * xh;
+            t = term(x4[u].z, g4[u].z, r[u].z, xh); s1 += t; s2 += t * xh;
+            t = term(x4[u].w, g4[u].w, r[u].w, xh); s1 += t; s2 += t * xh;
         }
     }
     for (long i = i0; i < n4; i += 256) {
-        const float4 a = reinterpret_cast<const float4 *>(xp)[i], g4 = reinterpret_cast<const float4 *>(gp)[i];
-        const float4 r = RES ? reinterpret_cast<const float4 *>(rp)[i] : z4;
+        const float4 x4 = ld4(xp, i, a.xdt), g4 = ld4(gp, i, a.gdt);
+        const float4 r = RES ? ld4(rp, i, a.rdt) : z4;
         float xh;
-        float t = term(a.x, g4.x, r.x, xh); s1 += t; s2 += t * xh;
-        t = term(a.y, g4.y, r.y, xh); s1 += t; s2 += t * xh;
-        t = term(a.z, g4.z, r.z, xh); s1 += t; s2 += t * xh;
-        t = term(a.w, g4.w, r.w, xh); s1 += t; s2 += t * xh;
+        float t = term(x4.x, g4.x, r.x, xh); s1 += t; s2 += t * xh;
+        t = term(x4.y, g4.y, r.y, xh); s1 += t; s2 += t * xh;
+        t = term(x4.z, g4.z, r.z, xh); s1 += t; s2 += t * xh;
+        t = term(x4.w, g4.w, r.w, xh); s1 += t; s2 += t * xh;
     }
     for (long i = 4 * n4 + threadIdx.x; i < HW; i += 256) {
         float xh;
-        const float t = term(xp[i], gp[i], RES ? rp[i] : 0.f, xh);
+        const float t = term(ld1(xp, i, a.xdt), ld1(gp, i, a.gdt), RES ? ld1(rp, i, a.rdt) : 0.f, xh);
         s1 += t; s2 += t * xh;
     }
     const float S1 = block_sum(s1, red), S2 = block_sum(s2, red);
     const float m1 = S1 / (float)HW, m2 = S2 / (float)HW, k = rstd * ga;
-    auto finish = [&](long i, const float4 &a, const float4 &g4, const float4 &r) {
+    auto finish = [&](long i, const float4 &x4, const float4 &g4, const float4 &r) {
         float xh;
         float4 o, tr;
-        float t = term(a.x, g4.x, r.x, xh); o.x = k * (t - m1 - xh * m2); tr.x = t;
-        t = term(a.y, g4.y, r.y, xh); o.y = k * (t - m1 - xh * m2); tr.y = t;
-        t = term(a.z, g4.z, r.z, xh); o.z = k * (t - m1 - xh * m2); tr.z = t;
-        t = term(a.w, g4.w, r.w, xh); o.w = k * (t - m1 - xh * m2); tr.w = t;
-        reinterpret_cast<float4 *>(dp)[i] = o;
-        if (RES && drp) reinterpret_cast<float4 *>(drp)[i] = tr;   // gradient of the residual input (optional)
+        float t = term(x4.x, g4.x, r.x, xh); o.x = k * (t - m1 - xh * m2); tr.x = t;
+        t = term(x4.y, g4.y, r.y, xh); o.y = k * (t - m1 - xh * m2); tr.y = t;
+        t = term(x4.z, g4.z, r.z, xh); o.z = k * (t - m1 - xh * m2); tr.z = t;
+        t = term(x4.w, g4.w, r.w, xh); o.w = k * (t - m1 - xh * m2); tr.w = t;
+        st4(dp, i, a.xdt, o);
+        if (RES && drp) st4(drp, i, a.rdt, tr);              // gradient of the residual input (optional)
     };
     i0 = threadIdx.x;
     for (; i0 + 256 * (UN - 1) < n4; i0 += 256 * UN) {
-        float4 a[UN], g4[UN], r[UN];
+        float4 x4[UN], g4[UN], r[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            a[u] = reinterpret_cast<const float4 *>(xp)[i0 + 256 * u];
-            g4[u] = reinterpret_cast<const float4 *>(gp)[i0 + 256 * u];
-            r[u] = RES ? reinterpret_cast<const float4 *>(rp)[i0 + 256 * u] : z4;
+            x4[u] = ld4(xp, i0 + 256 * u, a.xdt);
+            g4[u] = ld4(gp, i0 + 256 * u, a.gdt);
+            r[u] = RES ? ld4(rp, i0 + 256 * u, a.rdt) : z4;
         }
 #pragma unroll
-        for (int u = 0; u < UN; ++u) finish(i0 + 256 * u, a[u], g4[u], r[u]);
+        for (int u = 0; u < UN; ++u) finish(i0 + 256 * u, x4[u], g4[u], r[u]);
     }
-    for (long i = i0; i < n4; i += 256)
-        finish(i, reinterpret_cast<const float4 *>(xp)[i], reinterpret_cast<const float4 *>(gp)[i],
-               RES ? reinterpret_cast<const float4 *>(rp)[i] : z4);
+    for (long i = i0; i < n4; i += 256) finish(i, ld4(xp, i, a.xdt), ld4(gp, i, a.gdt), RES ? ld4(rp, i, a.rdt) : z4);
     for (long i = 4 * n4 + threadIdx.x; i < HW; i += 256) {
         float xh;
-        const float t = term(xp[i], gp[i], RES ? rp[i] : 0.f, xh);
-        dp[i] = k * (t - m1 - xh * m2);
-        if (RES && drp) drp[i] = t;
+        const float t = term(ld1(xp, i, a.xdt), ld1(gp, i, a.gdt), RES ? ld1(rp, i, a.rdt) : 0.f, xh);
+        st1(dp, i, a.xdt, k * (t - m1 - xh * m2));
+        if (RES && drp) st1(drp, i, a.rdt, t);
     }
-    if (threadIdx.x == 0 && part) { part[2 * plane] = S2; part[2 * plane + 1] = S1; }     // d(gamma), d(beta) of this plane
+    if (threadIdx.x == 0 && a.part) { a.part[2 * plane] = S2; a.part[2 * plane + 1] = S1; }     // d(gamma), d(beta) of this plane
 }
 
-// Register-resident forward for planes of at most NT * 64 floats (HW % 4 == 0): every thread keeps its 16 float4 of the
+// Register-resident forward for planes of at most NT * 64 elements (HW % 4 == 0): every thread keeps its 16 groups of 4 of the
 // plane in VGPRs, so the plane is read from HBM exactly once (the streaming kernel above re-reads it twice, and 256
 // workgroups x 256 KB do not stay in L2).  NT = 256 covers 128 x 128 maps, NT = 1024 256 x 256: 0.84 -> 0.61 ms per step.
 // (The same for the backward needs 2 x 64 data registers: measured slower at 155 VGPRs, spills at 1024 threads; it streams.)
@@ -206,23 +230,21 @@ constexpr int NV = 16;
 
 template <int NT>
 __global__ void __launch_bounds__(NT)
-plane_norm_fwd_reg_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
-                          const float *__restrict__ res, float *__restrict__ y, float *__restrict__ stats, int C, long HW,
-                          float eps, int act, float slope)
+plane_norm_fwd_reg_kernel(PNF a)
 {
     __shared__ float red[NT / 64];
-    const long plane = blockIdx.x;
-    const int c = (int)(plane % C);
-    const float4 *xp = reinterpret_cast<const float4 *>(x + plane * HW);
-    float4 *yp = reinterpret_cast<float4 *>(y + plane * HW);
-    const float4 *rp = res ? reinterpret_cast<const float4 *>(res + plane * HW) : nullptr;
+    const long plane = blockIdx.x, HW = a.HW;
+    const int c = (int)(plane % a.C);
+    const void *xp = plane_ptr(a.x, plane, HW, a.xdt);
+    void *yp = plane_ptr(a.y, plane, HW, a.ydt);
+    const void *rp = a.res ? plane_ptr(a.res, plane, HW, a.rdt) : nullptr;
     const int n4 = (int)(HW >> 2);
     float4 v[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = threadIdx.x + i * NT;
-        v[i] = idx < n4 ? xp[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[i] = idx < n4 ? ld4(xp, idx, a.xdt) : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = block_sum_nt<NT>(s, red) / (float)HW;
@@ -234,20 +256,21 @@ plane_norm_fwd_reg_kernel(const float *__restrict__ x, const float *__restrict__
             q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
     }
-    const float rstd = rsqrtf(block_sum_nt<NT>(q, red) / (float)HW + eps);
-    const float ga = (gamma ? gamma[c] : 1.f) * rstd, be = (beta ? beta[c] : 0.f) - mean * ga;
+    const float rstd = rsqrtf(block_sum_nt<NT>(q, red) / (float)HW + a.eps);
+    const float ga = (a.gamma ? a.gamma[c] : 1.f) * rstd, be = (a.beta ? a.beta[c] : 0.f) - mean * ga;
+    const int act = a.act;
+    const float slope = a.slope;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = threadIdx.x + i * NT;
         if (idx < n4) {
-            const float4 r = rp ? rp[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-            yp[idx] = make_float4(act_fwd(v[i].x * ga + be + r.x, act, slope), act_fwd(v[i].y * ga + be + r.y, act, slope),
-                                  act_fwd(v[i].z * ga + be + r.z, act, slope), act_fwd(v[i].w * ga + be + r.w, act, slope));
+            const float4 r = rp ? ld4(rp, idx, a.rdt) : make_float4(0.f, 0.f, 0.f, 0.f);
+            st4(yp, idx, a.ydt, make_float4(act_fwd(v[i].x * ga + be + r.x, act, slope), act_fwd(v[i].y * ga + be + r.y, act, slope),
+                                            act_fwd(v[i].z * ga + be + r.z, act, slope), act_fwd(v[i].w * ga + be + r.w, act, slope)));
         }
     }
-    if (threadIdx.x == 0) { stats[2 * plane] = mean; stats[2 * plane + 1] = rstd; }
+    if (threadIdx.x == 0) { a.stats[2 * plane] = mean; a.stats[2 * plane + 1] = rstd; }
 }
-
 
 // ------------------------------------------------------------------------------------------------------------------
 // Large planes (the 3-D network: InstanceNorm3d over 96 x 160 x 160 = 2.46 M voxels, 64 planes per map): one workgroup per plane
@@ -261,19 +284,19 @@ plane_norm_fwd_reg_kernel(const float *__restrict__ x, const float *__restrict__
 constexpr int SEG4 = 4096;                       // float4 per segment: 256 threads x 16
 
 __global__ void __launch_bounds__(256)
-plane_split_stats_kernel(const float *__restrict__ x, float *__restrict__ partial, long HW, int S)
+plane_split_stats_kernel(const void *__restrict__ x, int xdt, float *__restrict__ partial, long HW, int S)
 {
     __shared__ float red[4];
     const long plane = blockIdx.y;
     const int seg = blockIdx.x;
-    const float4 *xp = reinterpret_cast<const float4 *>(x + plane * HW);
+    const void *xp = plane_ptr(x, plane, HW, xdt);
     const long n4 = HW >> 2, lo = (long)seg * SEG4, cnt = min((long)SEG4, n4 - lo);
     float4 v[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const long idx = threadIdx.x + i * 256;
-        v[i] = idx < cnt ? xp[lo + idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[i] = idx < cnt ? ld4(xp, lo + idx, xdt) : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float n = 4.f * (float)cnt, mean = block_sum(s, red) / n;
@@ -306,35 +329,36 @@ __device__ __forceinline__ void pooled_stats(const float *__restrict__ partial, 
 }
 
 __global__ void __launch_bounds__(256)
-plane_split_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
-                         const float *__restrict__ res, float *__restrict__ y, float *__restrict__ stats,
-                         const float *__restrict__ partial, int C, long HW, int S, float eps, int act, float slope)
+plane_split_apply_kernel(PNF a, const float *__restrict__ partial, int S)
 {
     __shared__ float red[4];
-    const long plane = blockIdx.y;
-    const int seg = blockIdx.x, c = (int)(plane % C);
+    const long plane = blockIdx.y, HW = a.HW;
+    const int seg = blockIdx.x, c = (int)(plane % a.C), act = a.act;
+    const float slope = a.slope;
     float mean, rstd;
-    pooled_stats(partial, plane, S, HW, eps, red, mean, rstd);
-    const float ga = (gamma ? gamma[c] : 1.f) * rstd, be = (beta ? beta[c] : 0.f) - mean * ga;
-    const float4 *xp = reinterpret_cast<const float4 *>(x + plane * HW);
-    float4 *yp = reinterpret_cast<float4 *>(y + plane * HW);
-    const float4 *rp = res ? reinterpret_cast<const float4 *>(res + plane * HW) : xp;
-    const bool has_res = res != nullptr;
+    pooled_stats(partial, plane, S, HW, a.eps, red, mean, rstd);
+    const float ga = (a.gamma ? a.gamma[c] : 1.f) * rstd, be = (a.beta ? a.beta[c] : 0.f) - mean * ga;
+    const void *xp = plane_ptr(a.x, plane, HW, a.xdt);
+    void *yp = plane_ptr(a.y, plane, HW, a.ydt);
+    const bool has_res = a.res != nullptr;
+    const void *rp = has_res ? plane_ptr(a.res, plane, HW, a.rdt) : xp;
+    const int rdt = has_res ? a.rdt : a.xdt;
+    float *stats = a.stats;
     const long n4 = HW >> 2, lo = (long)seg * SEG4, cnt = min((long)SEG4, n4 - lo);
     float4 v[NV], r[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const long idx = min((long)(threadIdx.x + i * 256), cnt - 1);          // unconditional loads (clamped)
-        v[i] = xp[lo + idx];
-        r[i] = rp[lo + idx];
+        v[i] = ld4(xp, lo + idx, a.xdt);
+        r[i] = ld4(rp, lo + idx, rdt);
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const long idx = threadIdx.x + i * 256;
         if (idx < cnt) {
             const float r0 = has_res ? r[i].x : 0.f, r1 = has_res ? r[i].y : 0.f, r2 = has_res ? r[i].z : 0.f, r3 = has_res ? r[i].w : 0.f;
-            yp[lo + idx] = make_float4(act_fwd(v[i].x * ga + be + r0, act, slope), act_fwd(v[i].y * ga + be + r1, act, slope),
-                                       act_fwd(v[i].z * ga + be + r2, act, slope), act_fwd(v[i].w * ga + be + r3, act, slope));
+            st4(yp, lo + idx, a.ydt, make_float4(act_fwd(v[i].x * ga + be + r0, act, slope), act_fwd(v[i].y * ga + be + r1, act, slope),
+                                                 act_fwd(v[i].z * ga + be + r2, act, slope), act_fwd(v[i].w * ga + be + r3, act, slope)));
         }
     }
     if (seg == 0 && threadIdx.x == 0) { stats[2 * plane] = mean; stats[2 * plane + 1] = rstd; }
@@ -342,18 +366,19 @@ plane_split_apply_kernel(const float *__restrict__ x, const float *__restrict__ 
 
 template <bool RES, bool APPLY>
 __global__ void __launch_bounds__(256)
-plane_split_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ gamma,
-                       const float *__restrict__ beta, const float *__restrict__ res, const float *__restrict__ stats,
-                       float *__restrict__ dx, float *__restrict__ dres, float *__restrict__ part, float *__restrict__ partial, int C,
-                       long HW, int S, int act, float slope)
+plane_split_bwd_kernel(PNB a, float *__restrict__ partial, int S)
 {
     __shared__ float red[4];
-    const long plane = blockIdx.y;
-    const int seg = blockIdx.x, c = (int)(plane % C);
-    const float mean = stats[2 * plane], rstd = stats[2 * plane + 1];
-    const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-    const float4 *xp = reinterpret_cast<const float4 *>(x + plane * HW), *gp = reinterpret_cast<const float4 *>(dy + plane * HW);
-    const float4 *rp = RES ? reinterpret_cast<const float4 *>(res + plane * HW) : xp;
+    const long plane = blockIdx.y, HW = a.HW;
+    const int seg = blockIdx.x, c = (int)(plane % a.C), act = a.act;
+    const float slope = a.slope;
+    const float mean = a.stats[2 * plane], rstd = a.stats[2 * plane + 1];
+    const float ga = a.gamma ? a.gamma[c] : 1.f, be = a.beta ? a.beta[c] : 0.f;
+    const void *xp = plane_ptr(a.x, plane, HW, a.xdt), *gp = plane_ptr(a.dy, plane, HW, a.gdt);
+    const void *rp = RES ? plane_ptr(a.res, plane, HW, a.rdt) : xp;
+    void *dxp = plane_ptr(a.dx, plane, HW, a.xdt);
+    void *drp = (RES && a.dres) ? plane_ptr(a.dres, plane, HW, a.rdt) : nullptr;
+    float *part = a.part;
     const long n4 = HW >> 2, lo = (long)seg * SEG4, cnt = min((long)SEG4, n4 - lo);
     auto term = [&](float xv, float gv, float rv, float &xh) {
         xh = (xv - mean) * rstd;
@@ -373,13 +398,13 @@ plane_split_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy
     constexpr int UN = 4;
 #pragma unroll
     for (int i0 = 0; i0 < NV; i0 += UN) {
-        float4 a[UN], g4[UN], r[UN];
+        float4 x4[UN], g4[UN], r[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const long idx = min((long)(threadIdx.x + (i0 + u) * 256), cnt - 1);
-            a[u] = xp[lo + idx];
-            g4[u] = gp[lo + idx];
-            r[u] = RES ? rp[lo + idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+            x4[u] = ld4(xp, lo + idx, a.xdt);
+            g4[u] = ld4(gp, lo + idx, a.gdt);
+            r[u] = RES ? ld4(rp, lo + idx, a.rdt) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -387,13 +412,13 @@ plane_split_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy
             if (idx >= cnt) continue;
             float xh;
             float4 o, tr;
-            float t = term(a[u].x, g4[u].x, r[u].x, xh); s1 += t; s2 += t * xh; o.x = k * (t - m1 - xh * m2); tr.x = t;
-            t = term(a[u].y, g4[u].y, r[u].y, xh); s1 += t; s2 += t * xh; o.y = k * (t - m1 - xh * m2); tr.y = t;
-            t = term(a[u].z, g4[u].z, r[u].z, xh); s1 += t; s2 += t * xh; o.z = k * (t - m1 - xh * m2); tr.z = t;
-            t = term(a[u].w, g4[u].w, r[u].w, xh); s1 += t; s2 += t * xh; o.w = k * (t - m1 - xh * m2); tr.w = t;
+            float t = term(x4[u].x, g4[u].x, r[u].x, xh); s1 += t; s2 += t * xh; o.x = k * (t - m1 - xh * m2); tr.x = t;
+            t = term(x4[u].y, g4[u].y, r[u].y, xh); s1 += t; s2 += t * xh; o.y = k * (t - m1 - xh * m2); tr.y = t;
+            t = term(x4[u].z, g4[u].z, r[u].z, xh); s1 += t; s2 += t * xh; o.z = k * (t - m1 - xh * m2); tr.z = t;
+            t = term(x4[u].w, g4[u].w, r[u].w, xh); s1 += t; s2 += t * xh; o.w = k * (t - m1 - xh * m2); tr.w = t;
             if (APPLY) {
-                reinterpret_cast<float4 *>(dx + plane * HW)[lo + idx] = o;
-                if (RES && dres) reinterpret_cast<float4 *>(dres + plane * HW)[lo + idx] = tr;
+                st4(dxp, lo + idx, a.xdt, o);
+                if (RES && drp) st4(drp, lo + idx, a.rdt, tr);
             }
         }
     }
@@ -415,6 +440,9 @@ int check(int B, int C, long HW, int act)
     return 0;
 }
 
+inline bool dtype_ok(int dt) { return dt == MLAGG_DTYPE_F32 || dt == MLAGG_DTYPE_BF16 || dt == MLAGG_DTYPE_F16; }
+inline bool aligned(const void *p, int dt) { return (((uintptr_t)p) & (dt == 0 ? 15 : 7)) == 0; }
+
 }  // namespace
 
 extern "C" size_t mlagg_plane_norm_fwd_workspace_floats(int B, int C, long HW)
@@ -427,39 +455,44 @@ extern "C" size_t mlagg_plane_norm_bwd_workspace_floats(int B, int C, long HW)
     return (size_t)(B > 0 ? B : 0) * (C > 0 ? C : 0) * (2 + 2 * (size_t)split_segments(HW));
 }
 
-extern "C" int mlagg_plane_norm_fwd(const float *x, const float *gamma, const float *beta, const float *res, float *y, float *stats,
-                                    float *workspace, int B, int C, long HW, float eps, int act, float slope, void *stream)
+extern "C" int mlagg_plane_norm_fwd(const void *x, const float *gamma, const float *beta, const void *res, void *y, float *stats,
+                                    float *workspace, int B, int C, long HW, float eps, int act, float slope, int x_dtype,
+                                    int res_dtype, int y_dtype, void *stream)
 {
     if (!x || !y || !stats) return MLAGG_E_NULLPTR;
     if (int rc = check(B, C, HW, act)) return rc;
+    if (!dtype_ok(x_dtype) || !dtype_ok(y_dtype) || (res && !dtype_ok(res_dtype))) return MLAGG_E_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool vec = (HW & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)res)) & 15) == 0;
+    const bool vec = (HW & 3) == 0 && aligned(x, x_dtype) && aligned(y, y_dtype) && (!res || aligned(res, res_dtype));
+    PNF a{x, res, y, gamma, beta, stats, x_dtype, res_dtype, y_dtype, C, act, HW, eps, slope};
     MLAGG_TIMED(K_PLANE_NORM_FWD, st);
     const int S = vec ? split_segments(HW) : 0;
     if (S > 0) {
         if (!workspace) return MLAGG_E_WORKSPACE;
         if (S > 65535 || (long)B * C > 65535) return MLAGG_E_UNSUPPORTED;
-        hipLaunchKernelGGL(plane_split_stats_kernel, dim3(S, B * C), dim3(256), 0, st, x, workspace, HW, S);
-        hipLaunchKernelGGL(plane_split_apply_kernel, dim3(S, B * C), dim3(256), 0, st, x, gamma, beta, res, y, stats, workspace, C, HW,
-                           S, eps, act, slope);
+        hipLaunchKernelGGL(plane_split_stats_kernel, dim3(S, B * C), dim3(256), 0, st, x, x_dtype, workspace, HW, S);
+        hipLaunchKernelGGL(plane_split_apply_kernel, dim3(S, B * C), dim3(256), 0, st, a, workspace, S);
         return (int)hipGetLastError();
     }
-    if (vec && HW <= 256 * 4 * NV) hipLaunchKernelGGL(plane_norm_fwd_reg_kernel<256>, dim3(B * C), dim3(256), 0, st, x, gamma, beta, res, y, stats, C, HW, eps, act, slope);
-    else if (vec && HW <= 1024 * 4 * NV) hipLaunchKernelGGL(plane_norm_fwd_reg_kernel<1024>, dim3(B * C), dim3(1024), 0, st, x, gamma, beta, res, y, stats, C, HW, eps, act, slope);
-    else if (vec) hipLaunchKernelGGL(plane_norm_fwd_kernel<true>, dim3(B * C), dim3(256), 0, st, x, gamma, beta, res, y, stats, C, HW, eps, act, slope);
-    else hipLaunchKernelGGL(plane_norm_fwd_kernel<false>, dim3(B * C), dim3(256), 0, st, x, gamma, beta, res, y, stats, C, HW, eps, act, slope);
+    if (vec && HW <= 256 * 4 * NV) hipLaunchKernelGGL(plane_norm_fwd_reg_kernel<256>, dim3(B * C), dim3(256), 0, st, a);
+    else if (vec && HW <= 1024 * 4 * NV) hipLaunchKernelGGL(plane_norm_fwd_reg_kernel<1024>, dim3(B * C), dim3(1024), 0, st, a);
+    else if (vec) hipLaunchKernelGGL(plane_norm_fwd_kernel<true>, dim3(B * C), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(plane_norm_fwd_kernel<false>, dim3(B * C), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 
-extern "C" int mlagg_plane_norm_bwd(const float *x, const float *dy, const float *gamma, const float *beta, const float *res,
-                                    const float *stats, float *dx, float *dres, float *dgamma, float *dbeta, float *workspace,
-                                    int B, int C, long HW, int act, float slope, void *stream)
+extern "C" int mlagg_plane_norm_bwd(const void *x, const void *dy, const float *gamma, const float *beta, const void *res,
+                                    const float *stats, void *dx, void *dres, float *dgamma, float *dbeta, float *workspace,
+                                    int B, int C, long HW, int act, float slope, int x_dtype, int dy_dtype, int res_dtype, void *stream)
 {
     if (!x || !dy || !stats || !dx || ((dgamma || dbeta) && !workspace)) return MLAGG_E_NULLPTR;
     if (int rc = check(B, C, HW, act)) return rc;
+    if (!dtype_ok(x_dtype) || !dtype_ok(dy_dtype) || (res && !dtype_ok(res_dtype))) return MLAGG_E_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool vec = (HW & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)res) | ((uintptr_t)dres)) & 15) == 0;
+    const bool vec = (HW & 3) == 0 && aligned(x, x_dtype) && aligned(dy, dy_dtype) && aligned(dx, x_dtype) &&
+                     (!res || aligned(res, res_dtype)) && (!dres || aligned(dres, res_dtype));
     float *part = (dgamma || dbeta) ? workspace : nullptr;
+    PNB a{x, dy, res, dx, dres, gamma, beta, stats, part, x_dtype, dy_dtype, res_dtype, C, act, HW, slope};
     const int S = vec ? split_segments(HW) : 0;
     if (S > 0) {
         if (!workspace) return MLAGG_E_WORKSPACE;
@@ -468,20 +501,15 @@ extern "C" int mlagg_plane_norm_bwd(const float *x, const float *dy, const float
         MLAGG_TIMED(K_PLANE_NORM_BWD, st);
         const dim3 grid(S, B * C), block(256);
         if (res) {
-            hipLaunchKernelGGL((plane_split_bwd_kernel<true, false>), grid, block, 0, st, x, dy, gamma, beta, res, stats, dx, dres, part,
-                               partial, C, HW, S, act, slope);
-            hipLaunchKernelGGL((plane_split_bwd_kernel<true, true>), grid, block, 0, st, x, dy, gamma, beta, res, stats, dx, dres, part,
-                               partial, C, HW, S, act, slope);
+            hipLaunchKernelGGL((plane_split_bwd_kernel<true, false>), grid, block, 0, st, a, partial, S);
+            hipLaunchKernelGGL((plane_split_bwd_kernel<true, true>), grid, block, 0, st, a, partial, S);
         } else {
-            hipLaunchKernelGGL((plane_split_bwd_kernel<false, false>), grid, block, 0, st, x, dy, gamma, beta, res, stats, dx, dres, part,
-                               partial, C, HW, S, act, slope);
-            hipLaunchKernelGGL((plane_split_bwd_kernel<false, true>), grid, block, 0, st, x, dy, gamma, beta, res, stats, dx, dres, part,
-                               partial, C, HW, S, act, slope);
+            hipLaunchKernelGGL((plane_split_bwd_kernel<false, false>), grid, block, 0, st, a, partial, S);
+            hipLaunchKernelGGL((plane_split_bwd_kernel<false, true>), grid, block, 0, st, a, partial, S);
         }
     } else {
         MLAGG_TIMED(K_PLANE_NORM_BWD, st);
-#define MLAGG_PN_BWD(VEC, RES) hipLaunchKernelGGL((plane_norm_bwd_kernel<VEC, RES>), dim3(B * C), dim3(256), 0, st, x, dy, gamma, beta, res, stats, dx, \
-                                                  dres, part, C, HW, act, slope)
+#define MLAGG_PN_BWD(VEC, RES) hipLaunchKernelGGL((plane_norm_bwd_kernel<VEC, RES>), dim3(B * C), dim3(256), 0, st, a)
         const bool with_res = res != nullptr;
         if (vec && with_res) MLAGG_PN_BWD(true, true);
         else if (vec) MLAGG_PN_BWD(true, false);

@@ -95,74 +95,105 @@ class DropPath(nn.Module):
         return torch.addcmul(skip, branch, m.view((-1,) + (1,) * (branch.dim() - 1)))
 
 
-class Conv2d(nn.Conv2d):
-    """nn.Conv2d (same parameter names): MIOpen convolution without its bias, then K8's in-place channel bias whose
-    gradient is one plane-sum launch (inside convolution_backward it is a generic ATen reduction at 1.3-2 TB/s).  In fp32 mode the
-    weight gradient of the dense 3x3 / 1x1 stride-1 convolutions is K15 (ops.conv_nd), not MIOpen's NHWC implicit GEMM."""
+class _ConvMixin:
+    """Shared call forms of the library convolutions (same parameter names as the torch modules):
+      raw(x)                       the convolution alone, no bias: fp32 in fp32 mode, bf16 / fp16 in the 16-bit modes (operands cast,
+                                   what the reference's autocast makes of it, B:848) -- for a consumer that reads that type itself;
+      fused(x, res, act, dtype)    act(conv(x) + bias + res) with everything behind the convolution in one K13 pass; in the 16-bit
+                                   modes the epilogue reads the 16-bit convolution output and writes ``dtype`` (default fp32: the
+                                   map joins the residual stream) -- no cast kernel on either side;
+      forward(x)                   conv(x) + bias as an fp32 map.
+    In fp32 mode the weight gradient of dense 3x3 / 1x1 stride-1 convolutions may go to K15 (ops.K15_2D, off: MIOpen wins)."""
 
-    def _conv(self, x, cdt):
-        if cdt == torch.float32 and self.groups == 1 and ops.K15_2D and tuple(self.dilation) == (1, 1):
-            return ops.conv_nd(x, self.weight, self.stride, self.padding)
-        y = F.conv2d(ops.lp(x, cdt), ops.lp(self.weight, cdt), None, self.stride, self.padding, self.dilation, self.groups)
-        return y.float() if cdt != torch.float32 else y
+    def _lib_conv(self, x, w):
+        raise NotImplementedError
 
-    def forward(self, x):
+    def _fp32_conv(self, x):
+        return self._lib_conv(x, self.weight)
+
+    def raw(self, x):
         cdt = ops.conv_dtype()
-        if not x.is_cuda or self.padding_mode != "zeros":
-            return super().forward(x)
-        # mixed precision: the convolution runs on 16-bit operands (what autocast makes of it, reference B:848); the
-        # map comes back fp32 for the HIP kernels that follow
-        y = self._conv(x, cdt)
-        return y if self.bias is None else ops.channel_bias(y, self.bias)
+        if cdt == torch.float32:
+            return self._fp32_conv(x)
+        return self._lib_conv(x if x.dtype == cdt else x.to(cdt), self.weight.to(cdt))
 
-    def fused(self, x, res=None, act=ops.EPI_NONE):
-        """act(conv(x) + bias + res): the convolution in MIOpen, everything behind it in one K13 pass."""
-        if not x.is_cuda or self.padding_mode != "zeros":
-            y = super().forward(x)
+    def fused(self, x, res=None, act=ops.EPI_NONE, dtype=None):
+        if not x.is_cuda or getattr(self, "padding_mode", "zeros") != "zeros":
+            y = self._eager(x)
             y = y if res is None else y + res
             return F.gelu(y) if act == ops.EPI_GELU else y
-        return ops.channel_epilogue(self._conv(x, ops.conv_dtype()), self.bias, res, act)
+        y = self.raw(x)
+        if y.dtype == torch.float32:
+            return ops.channel_epilogue(y, self.bias, res, act)
+        if y.numel() // (y.shape[0] * y.shape[1]) % 4 or not ops.LP_IO:
+            return ops.channel_epilogue(y.float(), self.bias, None if res is None else res.float(), act)
+        return ops.channel_epilogue_lp(y, self.bias, res, act, dtype or torch.float32)
+
+    def _device_forward(self, x):
+        y = self.raw(x)
+        if y.dtype == torch.float32:
+            return y if self.bias is None else ops.channel_bias(y, self.bias)
+        if y.numel() // (y.shape[0] * y.shape[1]) % 4 or not ops.LP_IO:
+            y = y.float()
+            return y if self.bias is None else ops.channel_bias(y, self.bias)
+        return ops.channel_epilogue_lp(y, self.bias, None, ops.EPI_NONE, torch.float32)
 
 
-class ConvTranspose2d(nn.ConvTranspose2d):
+class Conv2d(_ConvMixin, nn.Conv2d):
+    """nn.Conv2d on MIOpen without its bias; the bias, residual and GELU behind it are K13 (see _ConvMixin)."""
+
+    def _lib_conv(self, x, w):
+        return F.conv2d(x, w, None, self.stride, self.padding, self.dilation, self.groups)
+
+    def _fp32_conv(self, x):
+        if self.groups == 1 and ops.K15_2D and tuple(self.dilation) == (1, 1):
+            return ops.conv_nd(x, self.weight, self.stride, self.padding)
+        return self._lib_conv(x, self.weight)
+
+    def _eager(self, x):
+        return nn.Conv2d.forward(self, x)
+
+    def forward(self, x):
+        if not x.is_cuda or self.padding_mode != "zeros":
+            return nn.Conv2d.forward(self, x)
+        return self._device_forward(x)
+
+
+class ConvTranspose2d(_ConvMixin, nn.ConvTranspose2d):
+    def _lib_conv(self, x, w):
+        return F.conv_transpose2d(x, w, None, self.stride, self.padding, self.output_padding, self.groups, self.dilation)
+
+    def _eager(self, x):
+        return nn.ConvTranspose2d.forward(self, x)
+
     def forward(self, x, output_size=None):
-        cdt = ops.conv_dtype()
         if not x.is_cuda or output_size is not None:
-            return super().forward(x, output_size)
-        if self.bias is None and cdt == torch.float32:
-            return super().forward(x, output_size)
-        y = F.conv_transpose2d(ops.lp(x, cdt), ops.lp(self.weight, cdt), None, self.stride, self.padding,
-                               self.output_padding, self.groups, self.dilation)
-        if cdt != torch.float32:
-            y = y.float()
-        return y if self.bias is None else ops.channel_bias(y, self.bias)
-
-    def fused(self, x, res=None):
-        """conv_transpose(x) + bias + res in one K13 pass behind the MIOpen call."""
-        if not x.is_cuda:
-            y = super().forward(x)
-            return y if res is None else y + res
-        cdt = ops.conv_dtype()
-        y = F.conv_transpose2d(ops.lp(x, cdt), ops.lp(self.weight, cdt), None, self.stride, self.padding,
-                               self.output_padding, self.groups, self.dilation)
-        if cdt != torch.float32:
-            y = y.float()
-        return ops.channel_epilogue(y, self.bias, res)
+            return nn.ConvTranspose2d.forward(self, x, output_size)
+        return self._device_forward(x)
 
 
 class GroupNorm(nn.GroupNorm):
     """nn.GroupNorm (same parameter names); with one channel per group -- every use on the path -- K10."""
 
-    def forward(self, x):
+    def forward(self, x, out_dtype=None):
         if self.num_groups == self.num_channels and x.is_cuda and x.dim() == 4:
-            return ops.plane_norm(x, self.weight, self.bias, self.eps)
+            return ops.plane_norm(x, self.weight, self.bias, self.eps, out_dtype=out_dtype)
         return super().forward(x)
 
 
-def _instance_norm_act(norm, x, act=ops.ACT_NONE, slope=0.0, res=None):
+def _chain_dtype(x):
+    """Element type of a map that only 16-bit library convolutions read, in the current mode: bf16 / fp16 in the 16-bit modes when
+    the kernels' vector path applies (plane size a multiple of 4), else None (= keep fp32)."""
+    cdt = ops.conv_dtype()
+    if cdt == torch.float32 or not ops.LP_IO or (x.numel() // (x.shape[0] * x.shape[1])) % 4:
+        return None
+    return cdt
+
+
+def _instance_norm_act(norm, x, act=ops.ACT_NONE, slope=0.0, res=None, out_dtype=None):
     """act(nn.InstanceNorm2d `norm`(x) + res), fused on K10 (plain modules off the device)."""
     if x.is_cuda and not norm.track_running_stats:
-        return ops.plane_norm(x, norm.weight, norm.bias, norm.eps, act, slope, res)
+        return ops.plane_norm(x, norm.weight, norm.bias, norm.eps, act, slope, res, out_dtype or torch.float32)
     y = norm(x) if res is None else norm(x) + res
     return F.leaky_relu(y, slope) if act == ops.ACT_LEAKY else (F.silu(y) if act == ops.ACT_SILU else y)
 
@@ -311,6 +342,21 @@ def _flip(t3):
     return t3.transpose(1, 2).contiguous()
 
 
+class _ZeroGradParam(torch.autograd.Function):
+    """Ties a parameter whose effect on ``y`` cancels exactly (a convolution bias in front of an InstanceNorm) into the graph:
+    y passes through, the parameter's gradient is the exact value, zero."""
+
+    @staticmethod
+    def forward(ctx, y, p):
+        ctx.save_for_backward(p)
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        return g, torch.zeros_like(p)
+
+
 class _MapToTokens(torch.autograd.Function):
     """(B, C, H, W) -> contiguous token-major (B, H*W, C); the gradient comes back as a contiguous NCHW map.
     Both directions are REAL transposes: permute + reshape alone is a strided view, and every residual add,
@@ -401,7 +447,9 @@ class MedNeXtBlock(nn.Module):  # reference T:230-324
         # conv1 is depthwise 3x3 (stride 1, or 2 in the down block): K2n instead of MIOpen's naive fallback; the bias,
         # GELU and residual behind the two 1x1 convolutions are one K13 pass each
         x1 = ops.dwconv3x3_nchw(x, self.conv1.weight, self.conv1.bias, self.conv1.stride[0])
-        return self.conv3.fused(self.conv2.fused(self.norm(x1), act=ops.EPI_GELU), res=res)
+        # 16-bit modes: the maps between the norm and the two 1x1 convolutions are read only by 16-bit convolutions and stay 16-bit
+        ct = _chain_dtype(x1)
+        return self.conv3.fused(self.conv2.fused(self.norm(x1, ct), act=ops.EPI_GELU, dtype=ct), res=res)
 
     def forward(self, x):
         return self.body(x, x if self.do_res else None)
@@ -413,7 +461,8 @@ class MedNeXtDownBlock(MedNeXtBlock):  # reference T:327-366
         self.res_conv = Conv2d(cin, cout, 1, stride=2)
 
     def forward(self, x):
-        return self.body(x, self.res_conv(x))
+        # 16-bit modes: the strided 1x1 residual is read once, by conv3's epilogue: it may stay 16-bit
+        return self.body(x, self.res_conv.fused(x, dtype=ops.conv_dtype()) if x.is_cuda else self.res_conv(x))
 
 
 class PatchExpand(nn.Module):  # reference T:479-546
@@ -425,7 +474,9 @@ class PatchExpand(nn.Module):  # reference T:479-546
 
     def forward(self, x):
         # pad(a) + pad(b) = pad(a + b): one padded copy, and the sum rides in conv1's epilogue
-        return F.pad(self.conv1.fused(self.norm(x), res=self.res_conv(x)), (1, 0, 1, 0))
+        ct = _chain_dtype(x)
+        res = self.res_conv.fused(x, dtype=ops.conv_dtype()) if x.is_cuda else self.res_conv(x)
+        return F.pad(self.conv1.fused(self.norm(x, ct), res=res), (1, 0, 1, 0))
 
 
 class OutBlock(nn.Module):  # reference T:549-561
@@ -463,9 +514,17 @@ class UnetResBlock(nn.Module):
             self.norm3 = nn.InstanceNorm2d(cout)
 
     def forward(self, x):
-        out = _instance_norm_act(self.norm1, self.conv1(x), ops.ACT_LEAKY, 0.01)
-        res = _instance_norm_act(self.norm3, self.conv3(x)) if hasattr(self, "conv3") else x
-        return _instance_norm_act(self.norm2, self.conv2(out), ops.ACT_LEAKY, 0.01, res)       # act(norm2(.) + res)
+        # 16-bit modes: every map of the block is written by / read by 16-bit convolutions only (the block output feeds the
+        # transposed / 1x1 convolutions of decoder0 and the head): all of them stay 16-bit in memory, K10 converts on the fly
+        ct = _chain_dtype(x) if x.is_cuda else None
+        c1 = self.conv1.conv.raw(x) if x.is_cuda else self.conv1(x)
+        out = _instance_norm_act(self.norm1, c1, ops.ACT_LEAKY, 0.01, None, ct)
+        if hasattr(self, "conv3"):
+            res = _instance_norm_act(self.norm3, self.conv3.conv.raw(x) if x.is_cuda else self.conv3(x), out_dtype=ct)
+        else:
+            res = x
+        c2 = self.conv2.conv.raw(out) if x.is_cuda else self.conv2(out)
+        return _instance_norm_act(self.norm2, c2, ops.ACT_LEAKY, 0.01, res, ct)                 # act(norm2(.) + res)
 
 
 class UnetrBasicBlock(nn.Module):
@@ -484,7 +543,10 @@ class UnetrUpBlock(nn.Module):
         self.conv_block = UnetResBlock(2 * cout, cout)
 
     def forward(self, x, skip):
-        return self.conv_block(torch.cat([self.transp_conv(x), skip], dim=1))
+        up = self.transp_conv.conv.raw(x) if x.is_cuda else self.transp_conv(x)
+        if up.dtype != skip.dtype:                            # (a 16-bit chain met an fp32 map: plane size not a multiple of 4)
+            up, skip = up.float(), skip.float()
+        return self.conv_block(torch.cat([up, skip], dim=1))
 
 
 class MLLA_Enc(nn.Module):  # reference T:1046-1179
@@ -624,7 +686,14 @@ class VSS_Conv_Block(nn.Module):  # reference M:669-753
             mi = self.drop_path.residual(mi, self.mlps[i](mi, H, W))
             mi = _TokensToMap.apply(mi.contiguous(), H, W)      # real transpose: keeps the gradient token-major
             conv, norm = self.conv_branches[i][0], self.conv_branches[i][1]          # [2] is the SiLU fused into K10
-            outs.append(torch.cat([mi, _instance_norm_act(norm, conv(halves[i][1]), ops.ACT_SILU)], dim=1))
+            xc = halves[i][1]
+            if xc.is_cuda and _chain_dtype(xc) is not None:
+                # 16-bit modes: K10 reads the 16-bit convolution output; the convolution's bias cancels exactly in the
+                # InstanceNorm that follows (its gradient is exactly zero)
+                cv = _ZeroGradParam.apply(conv.raw(xc), conv.bias)
+            else:
+                cv = conv(xc)
+            outs.append(torch.cat([mi, _instance_norm_act(norm, cv, ops.ACT_SILU)], dim=1))
         return outs
 
 

@@ -26,7 +26,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .model import LayerNorm, Linear, _flip
+from .model import LayerNorm, Linear, _ZeroGradParam, _flip
 from .ss3d import SS3D
 
 
@@ -51,21 +51,6 @@ class _ToVolume(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return _flip(g.reshape(g.shape[0], g.shape[1], -1)), None
-
-
-class _ZeroGradParam(torch.autograd.Function):
-    """Ties a parameter whose effect on ``y`` cancels exactly (a convolution bias in front of an InstanceNorm) into the graph:
-    y passes through, the parameter's gradient is the exact value, zero."""
-
-    @staticmethod
-    def forward(ctx, y, p):
-        ctx.save_for_backward(p)
-        return y.view_as(y)
-
-    @staticmethod
-    def backward(ctx, g):
-        (p,) = ctx.saved_tensors
-        return g, torch.zeros_like(p)
 
 
 class Conv3d(nn.Conv3d):

@@ -64,6 +64,11 @@ import os as _os
 LP_CONV = _os.environ.get("MLAGG_LP_CONV", "1") == "1"
 
 
+# 16-bit modes: maps that only 16-bit library convolutions read or write stay bf16 / fp16 in memory; K10 / K13 convert on the fly
+# (MLAGG_LP_IO=0: the round-2 form, fp32 maps everywhere with a cast kernel on both sides of every convolution)
+LP_IO = _os.environ.get("MLAGG_LP_IO", "1") == "1"
+
+
 def conv_dtype():
     return compute_dtype() if LP_CONV else torch.float32
 
@@ -1208,22 +1213,39 @@ def column_sum(x2):
 ACT_NONE, ACT_LEAKY, ACT_SILU = 0, 1, 2
 
 
+_DT_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}            # MLAGG_DTYPE_* of include/mlagg_hip.h
+
+
+def _require_map(t, name, shape=None):
+    """A device map in fp32, bf16 or fp16 (the kernels of the convolutional chains take the element type as an argument)."""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype in _DT_CODE):
+        raise RuntimeError(f"{name}: expected an fp32 / bf16 / fp16 tensor on the MI355X device, got "
+                           f"{getattr(t, 'dtype', type(t))} on {getattr(t, 'device', '?')}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise RuntimeError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
 class PlaneNormFn(torch.autograd.Function):
     """K10: per-(batch, channel)-plane normalisation of an NCHW map fused with what follows it: y = act(norm(x) + res)
-    (GroupNorm(C, C); InstanceNorm2d + LeakyReLU; InstanceNorm2d(affine) + SiLU; the residual sum of the UnetResBlock)."""
+    (GroupNorm(C, C); InstanceNorm2d + LeakyReLU; InstanceNorm2d(affine) + SiLU; the residual sum of the UnetResBlock).
+    x, res and y may each be fp32, bf16 or fp16 IN MEMORY (16-bit modes: maps between the 16-bit library convolutions);
+    statistics and arithmetic are fp32."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, res, eps, act, slope):
-        x = _require(x.contiguous(), "x")
-        res = None if res is None else _require(res.contiguous(), "res", x.shape)
+    def forward(ctx, x, gamma, beta, res, eps, act, slope, out_dtype):
+        x = _require_map(x.contiguous(), "x")
+        res = None if res is None else _require_map(res.contiguous(), "res", x.shape)
         B, C = x.shape[:2]
         hw = x.numel() // (B * C)
-        y = torch.empty_like(x)
+        y = torch.empty(x.shape, device=x.device, dtype=out_dtype or x.dtype)
         stats = torch.empty(B * C, 2, device=x.device, dtype=torch.float32)
         nws = _lib.lib().mlagg_plane_norm_fwd_workspace_floats(B, C, hw)          # > 0: planes cut into segments (3-D volumes)
         ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
         _lib.check(_lib.lib().mlagg_plane_norm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(res), _ptr(y), _ptr(stats), _ptr(ws), B, C, hw,
-                                                   float(eps), int(act), float(slope), _stream()), "mlagg_plane_norm_fwd")
+                                                   float(eps), int(act), float(slope), _DT_CODE[x.dtype],
+                                                   0 if res is None else _DT_CODE[res.dtype], _DT_CODE[y.dtype], _stream()),
+                   "mlagg_plane_norm_fwd")
         ctx.save_for_backward(x, gamma, beta, res, stats)
         ctx.meta = (int(act), float(slope))
         return y
@@ -1232,24 +1254,70 @@ class PlaneNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, gamma, beta, res, stats = ctx.saved_tensors
         act, slope = ctx.meta
-        dy = _require(dy.contiguous(), "dy")
+        dy = _require_map(dy.contiguous(), "dy")
         B, C = x.shape[:2]
         hw = x.numel() // (B * C)
         lib = _lib.lib()
         dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if (res is not None and ctx.needs_input_grad[3]) else None
+        dres = torch.empty_like(res) if (res is not None and ctx.needs_input_grad[3]) else None
         dg = torch.empty_like(gamma) if gamma is not None else None
         db = torch.empty_like(beta) if beta is not None else None
         segmented = lib.mlagg_plane_norm_fwd_workspace_floats(B, C, hw) > 0
         ws = torch.empty(lib.mlagg_plane_norm_bwd_workspace_floats(B, C, hw), device=x.device, dtype=torch.float32) \
             if (dg is not None or db is not None or segmented) else None
         _lib.check(lib.mlagg_plane_norm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(res), _ptr(stats), _ptr(dx), _ptr(dres),
-                                            _ptr(dg), _ptr(db), _ptr(ws), B, C, hw, act, slope, _stream()), "mlagg_plane_norm_bwd")
-        return dx, dg, db, dres, None, None, None
+                                            _ptr(dg), _ptr(db), _ptr(ws), B, C, hw, act, slope, _DT_CODE[x.dtype], _DT_CODE[dy.dtype],
+                                            0 if res is None else _DT_CODE[res.dtype], _stream()), "mlagg_plane_norm_bwd")
+        return dx, dg, db, dres, None, None, None, None
 
 
-def plane_norm(x, gamma, beta, eps=1e-5, act=ACT_NONE, slope=0.0, res=None):
-    return PlaneNormFn.apply(x, gamma, beta, res, eps, act, slope)
+def plane_norm(x, gamma, beta, eps=1e-5, act=ACT_NONE, slope=0.0, res=None, out_dtype=None):
+    return PlaneNormFn.apply(x, gamma, beta, res, eps, act, slope, out_dtype)
+
+
+class ChannelEpilogueLpFn(torch.autograd.Function):
+    """K13 in the 16-bit modes: y = act(x + bias[c] + res) where x is the bf16 / fp16 output of a library convolution (left
+    untouched: backward recomputes the pre-activation from it), y in ``out_dtype``; dx comes back in x's type -- the convolution's
+    gradient operand -- with d(bias) from the same pass."""
+
+    @staticmethod
+    def forward(ctx, x, bias, res, act, out_dtype):
+        x = _require_map(x.contiguous(), "x")
+        res = None if res is None else _require_map(res.contiguous(), "res", x.shape)
+        B, C = x.shape[:2]
+        hw = x.numel() // (B * C)
+        y = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+        _lib.check(_lib.lib().mlagg_channel_epilogue_lp_fwd(_ptr(x), _DT_CODE[x.dtype], _ptr(bias), _ptr(res),
+                                                            0 if res is None else _DT_CODE[res.dtype], _ptr(y), _DT_CODE[y.dtype], B, C, hw,
+                                                            int(act), _stream()), "mlagg_channel_epilogue_lp_fwd")
+        ctx.save_for_backward(x if act == EPI_GELU else None, bias, res if act == EPI_GELU else None)
+        ctx.meta = (int(act), x.dtype, None if res is None else res.dtype, tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, bias, res = ctx.saved_tensors
+        act, xdt, rdt, shape = ctx.meta
+        dy = _require_map(dy.contiguous(), "dy", shape)
+        B, C = shape[:2]
+        hw = dy.numel() // (B * C)
+        lib = _lib.lib()
+        dx = torch.empty(shape, device=dy.device, dtype=xdt)
+        db = torch.empty(C, device=dy.device, dtype=torch.float32) if bias is not None else None
+        ws = torch.empty(lib.mlagg_channel_sum_workspace_floats(B, C), device=dy.device, dtype=torch.float32) if bias is not None else None
+        _lib.check(lib.mlagg_channel_epilogue_lp_bwd(_ptr(x), _DT_CODE[xdt], _ptr(bias), _ptr(res), 0 if res is None else _DT_CODE[res.dtype],
+                                                     _ptr(dy), _DT_CODE[dy.dtype], _ptr(dx), _DT_CODE[xdt], _ptr(db), _ptr(ws), B, C, hw,
+                                                     act, _stream()), "mlagg_channel_epilogue_lp_bwd")
+        dres = None
+        if rdt is not None and ctx.needs_input_grad[2]:
+            # d(res) = d(pre): dy itself without an activation, else the values of dx -- in res's own element type
+            src = dy if act == EPI_NONE else dx
+            dres = src if src.dtype == rdt else (dx if dx.dtype == rdt else src.to(rdt))
+        return dx, db, dres, None, None
+
+
+def channel_epilogue_lp(x, bias=None, res=None, act=EPI_NONE, out_dtype=torch.float32):
+    return ChannelEpilogueLpFn.apply(x, bias, res, act, out_dtype)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -647,3 +647,71 @@ def test_fused_loss_with_ignore_label_matches_reference_golden(batch_dice):
         assert float((z.grad.cpu() - want).abs().max()) < 1e-7
     assert float(zs[4].grad.abs().max()) == 0.0                    # the fully ignored level: no gradient at all
     assert float(zs[0].grad.cpu()[(tg[0] == 5).expand(-1, 5, -1, -1)].abs().max()) == 0.0
+
+
+@gpu
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hw", [(24, 20), (7, 9), (260, 260)])          # vector path, scalar path (odd plane), register-resident limit passed
+def test_plane_norm_16_bit_maps(dt, hw):
+    """K10 with 16-bit maps in memory (16-bit modes: convolution output in, next convolution's input out, residual in either type):
+    against float64 arithmetic on the SAME 16-bit inputs, outputs within one rounding of the output type; gradients come back in
+    the inputs' own types."""
+    from mlagg_unet_amd import ops
+    g = torch.Generator().manual_seed(hw[0])
+    B, C = 2, 5
+    x = (torch.randn(B, C, *hw, generator=g) * 2 + 0.5).to(dt)
+    r = torch.randn(B, C, *hw, generator=g)                              # fp32 residual
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    gy = torch.randn(B, C, *hw, generator=g).to(dt)
+    xb, rb = x.double().requires_grad_(True), r.double().requires_grad_(True)
+    gb, bb = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yb = F.silu(F.instance_norm(xb, weight=gb, bias=bb, eps=1e-5) + rb)
+    yb.backward(gy.double())
+    xa, ra = x.to(DEV).requires_grad_(True), r.to(DEV).requires_grad_(True)
+    ga, ba = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    ya = ops.plane_norm(xa, ga, ba, 1e-5, ops.ACT_SILU, 0.0, ra, out_dtype=dt)
+    assert ya.dtype == dt
+    ya.backward(gy.to(DEV))
+    eps16 = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    assert float((ya.detach().cpu().double() - yb.detach()).abs().max()) <= eps16 * float(yb.abs().max()) * 1.01 + 1e-6
+    assert xa.grad.dtype == dt and ra.grad.dtype == torch.float32
+    assert float((xa.grad.cpu().double() - xb.grad).abs().max()) <= 2 * eps16 * float(xb.grad.abs().max()) + 1e-6
+    assert float((ra.grad.cpu().double() - rb.grad).abs().max()) <= 1e-5 * float(rb.grad.abs().max()) + 1e-6
+    assert float((ga.grad.cpu().double() - gb.grad).abs().max()) <= 1e-4 * float(gb.grad.abs().max()) + 1e-5
+    assert float((ba.grad.cpu().double() - bb.grad).abs().max()) <= 1e-4 * float(bb.grad.abs().max()) + 1e-5
+
+
+@gpu
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("act", ["none", "gelu"])
+def test_channel_epilogue_16_bit_maps(dt, act):
+    """K13 in the 16-bit modes: y = act(x16 + bias + res) with x16 untouched, y in the requested type; backward dx in x's type,
+    d(bias), d(res) in res's type."""
+    from mlagg_unet_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W = 2, 6, 12, 20
+    x = torch.randn(B, C, H, W, generator=g).to(dt)
+    bias = torch.randn(C, generator=g)
+    r = torch.randn(B, C, H, W, generator=g) if act == "none" else None
+    out_dt = torch.float32 if act == "none" else dt
+    gy = torch.randn(B, C, H, W, generator=g).to(out_dt)
+    xb, bb = x.double().requires_grad_(True), bias.double().requires_grad_(True)
+    rb = None if r is None else r.double().requires_grad_(True)
+    pre = xb + bb.view(1, -1, 1, 1) + (0 if rb is None else rb)
+    yb = F.gelu(pre) if act == "gelu" else pre
+    yb.backward(gy.double())
+    xa, ba = x.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True)
+    ra = None if r is None else r.to(DEV).requires_grad_(True)
+    x_before = xa.detach().clone()
+    ya = ops.channel_epilogue_lp(xa, ba, ra, ops.EPI_GELU if act == "gelu" else ops.EPI_NONE, out_dt)
+    ya.backward(gy.to(DEV))
+    eps16 = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    out_eps = eps16 if out_dt == dt else 1e-6
+    assert ya.dtype == out_dt and torch.equal(xa.detach(), x_before)
+    assert float((ya.detach().cpu().double() - yb.detach()).abs().max()) <= out_eps * float(yb.abs().max()) * 1.01 + 1e-6
+    assert xa.grad.dtype == dt
+    assert float((xa.grad.cpu().double() - xb.grad).abs().max()) <= 2 * eps16 * float(xb.grad.abs().max()) + 1e-6
+    # the bias sum runs over the fp32 values BEFORE they are rounded to x's type
+    assert float((ba.grad.cpu().double() - bb.grad).abs().max()) <= 1e-4 * float(bb.grad.abs().max()) + 1e-4
+    if ra is not None:
+        assert ra.grad.dtype == torch.float32 and float((ra.grad.cpu().double() - rb.grad).abs().max()) < 1e-6
