@@ -429,14 +429,22 @@ int mlagg_pooled_attn_lp_bwd(const float *q, int q_stride, const float *kp, int 
  *   mlagg_volume_pad: src (B, C, D, H, W) -> dst (B, phases, C, 2 * guard + Dq * Hq * Wq): zero-padded copy (stride 1: one phase, data
  *       at origin 1) or the 8 parity phases of the zero-padded input (stride 2).  as_output = 1: an output-sized map (out_D, out_H,
  *       out_W) laid into the box of the input geometry (D, H, W) with a zero ring (origin 1 for stride 1, 0 for stride 2).
+ *   wide = 1 (stride 1, W % 4 == 0): the data starts at x = 4 (Wq = W + 8): aligned groups of 4 padded voxels are aligned groups of 4
+ *       data voxels -- the geometry mlagg_conv_taps needs; K15 works on either.
  *   mlagg_conv_wgrad_taps: dW (O, I, ntaps) (+)= sum_{b, q < Q} A[b][o][q] * B[b][i][q + tap_off[t]].  Q and the row strides are
  *       multiples of 4 floats (Q of 8), tap_off is a HOST array of ntaps <= 27 element offsets; workspace of
  *       mlagg_conv_wgrad_taps_workspace_floats() floats.  fp32 in, fp32 MFMA (exact products), fixed summation order.
  * ------------------------------------------------------------------------------------------ */
-int mlagg_conv_pad_geometry(int D, int H, int W, int stride, int *Dq, int *Hq, int *Wq, long *guard);
-int mlagg_volume_pad(const float *src, float *dst, int B, int C, int D, int H, int W, int stride, int as_output, int out_D,
+int mlagg_conv_pad_geometry(int D, int H, int W, int stride, int wide, int *Dq, int *Hq, int *Wq, long *guard);
+int mlagg_volume_pad(const float *src, float *dst, int B, int C, int D, int H, int W, int stride, int wide, int as_output, int out_D,
                      int out_H, int out_W, void *stream);
 size_t mlagg_conv_wgrad_taps_workspace_floats(int batch, long Q, int O, int I, int ntaps);
+/* K16: forward / data gradient of the same convolutions (stride 1; kernel 3 pad 1 or kernel 1) on the padded copy (wide form):
+ * y (B, O, D, H, W) = sum_t sum_i weight[o * w_so + i * w_si + t'] * xp[b][i][q + tap_off[t]], t' = t (flip 0) or ntaps - 1 - t (flip 1: the data
+ * gradient, with w_so / w_si exchanged by the caller).  Replaces MIOpen's Conv3d forward / backward-data behind BasicResBlock / BasicBlockD /
+ * UpsampleLayer / seg layers of the 3-D network (UMambaEnc_SS3D.py:49-66, 477-513, 589-637, 744-779).  fp32 MFMA, exact products. */
+int mlagg_conv_taps(const float *xp, long x_batch, long x_row, const float *weight, long w_so, long w_si, int flip, const long *tap_off,
+                    int ntaps, float *y, int B, int O, int I, int D, int H, int W, void *stream);
 int mlagg_conv_wgrad_taps(const float *A, long a_batch, long a_row, const float *B, long b_batch, long b_row, const long *tap_off,
                           int ntaps, long Q, int O, int I, int batch, float *dW, int accumulate, float *workspace, void *stream);
 

@@ -93,9 +93,11 @@ SIGNATURES = {
     "mlagg_index_scan": (_I, [_F, ctypes.c_long, _I, _F, _F, _I, _I, _I, _I, _S]),
     "mlagg_index_merge": (_I, [_F, _F, _F, ctypes.c_long, _I, _I, _I, _I, _I, _S]),
     "mlagg_block_sum": (_I, [_F, _F, ctypes.c_long, _I, _I, _S]),
-    "mlagg_conv_pad_geometry": (_I, [_I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I),
+    "mlagg_conv_pad_geometry": (_I, [_I, _I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I),
                                      ctypes.POINTER(ctypes.c_long)]),
-    "mlagg_volume_pad": (_I, [_F, _F] + [_I] * 10 + [_S]),
+    "mlagg_volume_pad": (_I, [_F, _F] + [_I] * 11 + [_S]),
+    "mlagg_conv_taps": (_I, [_F, ctypes.c_long, ctypes.c_long, _F, ctypes.c_long, ctypes.c_long, _I, ctypes.POINTER(ctypes.c_long), _I, _F,
+                             _I, _I, _I, _I, _I, _I, _S]),
     "mlagg_conv_wgrad_taps_workspace_floats": (_SZ, [_I, ctypes.c_long, _I, _I, _I]),
     "mlagg_conv_wgrad_taps": (_I, [_F, ctypes.c_long, ctypes.c_long, _F, ctypes.c_long, ctypes.c_long, ctypes.POINTER(ctypes.c_long),
                                    _I, ctypes.c_long, _I, _I, _I, _F, _I, _F, _S]),

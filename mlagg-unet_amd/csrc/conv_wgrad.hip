@@ -155,7 +155,7 @@ conv_wgrad_reduce_kernel(const float *__restrict__ part, int rows, int ntaps, in
 //             zero ring that makes the flat 1-D shifts exact.
 // One thread per 4 destination voxels of a row.
 struct PadGeom {
-    int C, D, H, W, Dq, Hq, Wq, stride, org, orgz, nphase;
+    int C, D, H, W, Dq, Hq, Wq, stride, org, orgx, orgz, nphase;
     long guard, row;                   // row = 2 * guard + Dq * Hq * Wq
 };
 
@@ -177,7 +177,7 @@ volume_pad_kernel(const float *__restrict__ src, float *__restrict__ dst, PadGeo
     for (int j = 0; j < 4; ++j) {
         int z, y, x;
         if (g.stride == 1 || g.nphase == 1) {
-            z = zq - g.orgz; y = yq - g.org; x = xq + j - g.org;
+            z = zq - g.orgz; y = yq - g.org; x = xq + j - g.orgx;
         } else {
             z = 2 * zq + ((ph >> 2) & 1) - 1; y = 2 * yq + ((ph >> 1) & 1) - 1; x = 2 * (xq + j) + (ph & 1) - 1;
         }
@@ -199,19 +199,22 @@ guard_zero_kernel(float *__restrict__ dst, long rows, long row, long guard)
 
 }  // namespace
 
-// geometry of the padded box for an input of (D, H, W) under a k = 3 (pad 1) or k = 1 (pad 0) convolution of stride 1 or 2
-extern "C" int mlagg_conv_pad_geometry(int D, int H, int W, int stride, int *Dq, int *Hq, int *Wq, long *guard)
+// geometry of the padded box for an input of (D, H, W) under a k = 3 (pad 1) or k = 1 (pad 0) convolution of stride 1 or 2.
+// wide (stride 1, W % 4 == 0): the data starts at x = 4 instead of 1 (Wq = W + 8), so that aligned groups of 4 padded voxels are
+// aligned groups of 4 data voxels -- the geometry of the forward / data-gradient tap kernels (conv_taps.hip), shared with K15.
+extern "C" int mlagg_conv_pad_geometry(int D, int H, int W, int stride, int wide, int *Dq, int *Hq, int *Wq, long *guard)
 {
     if (D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2) || !Dq || !Hq || !Wq || !guard) return MLAGG_E_UNSUPPORTED;
     if (stride == 2 && D == 1) return MLAGG_E_UNSUPPORTED;                  // 2-D maps (D = 1): stride 1 only
-    if (stride == 1) { *Dq = D == 1 ? 1 : D + 2; *Hq = H + 2; *Wq = (W + 2 + 3) & ~3; }      // a 2-D map gets no z ring
+    if (wide && (stride != 1 || (W & 3))) return MLAGG_E_UNSUPPORTED;
+    if (stride == 1) { *Dq = D == 1 ? 1 : D + 2; *Hq = H + 2; *Wq = wide ? W + 8 : (W + 2 + 3) & ~3; }      // a 2-D map gets no z ring
     else { *Dq = (D - 1) / 2 + 2; *Hq = (H - 1) / 2 + 2; *Wq = ((W - 1) / 2 + 2 + 3) & ~3; }
     // the box is walked in whole 8-voxel steps; shifts reach one plane + one row + one voxel either way
     *guard = (((long)*Hq * *Wq + *Wq + 1 + 8) + 7) & ~7L;
     return 0;
 }
 
-extern "C" int mlagg_volume_pad(const float *src, float *dst, int B, int C, int D, int H, int W, int stride, int as_output,
+extern "C" int mlagg_volume_pad(const float *src, float *dst, int B, int C, int D, int H, int W, int stride, int wide, int as_output,
                                 int out_D, int out_H, int out_W, void *stream)
 {
     if (!src || !dst) return MLAGG_E_NULLPTR;
@@ -219,7 +222,7 @@ extern "C" int mlagg_volume_pad(const float *src, float *dst, int B, int C, int 
     long guard;
     // `src` is either the convolution input (D, H, W) or, as_output, an output-sized map (out_D, out_H, out_W) laid into the box of
     // the input geometry (D, H, W)
-    if (int rc = mlagg_conv_pad_geometry(D, H, W, stride, &Dq, &Hq, &Wq, &guard)) return rc;
+    if (int rc = mlagg_conv_pad_geometry(D, H, W, stride, wide, &Dq, &Hq, &Wq, &guard)) return rc;
     if (B <= 0 || C <= 0) return MLAGG_E_UNSUPPORTED;
     PadGeom g;
     g.C = C; g.Dq = Dq; g.Hq = Hq; g.Wq = Wq; g.guard = guard;
@@ -227,10 +230,12 @@ extern "C" int mlagg_volume_pad(const float *src, float *dst, int B, int C, int 
     if (as_output) {
         g.D = out_D; g.H = out_H; g.W = out_W; g.stride = 1; g.nphase = 1; g.org = stride == 1 ? 1 : 0;
         g.orgz = (stride == 1 && D > 1) ? 1 : 0;
-        if (out_D + g.orgz > Dq || out_H + g.org > Hq || out_W + g.org > Wq) return MLAGG_E_UNSUPPORTED;
+        g.orgx = wide ? 4 : g.org;
+        if (out_D + g.orgz > Dq || out_H + g.org > Hq || out_W + g.orgx > Wq) return MLAGG_E_UNSUPPORTED;
     } else {
         g.D = D; g.H = H; g.W = W; g.stride = stride; g.nphase = stride == 1 ? 1 : 8; g.org = 1;
         g.orgz = D > 1 ? 1 : 0;
+        g.orgx = wide ? 4 : 1;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const long rows = (long)B * g.nphase * C, total4 = rows * Dq * Hq * (Wq >> 2);

@@ -1323,10 +1323,10 @@ def channel_epilogue_lp(x, bias=None, res=None, act=EPI_NONE, out_dtype=torch.fl
 # ------------------------------------------------------------------------------------------------
 # K15: full convolutions with the weight gradient on this package's tap-GEMM kernel
 # ------------------------------------------------------------------------------------------------
-def _pad_geometry(D, H, W, stride):
+def _pad_geometry(D, H, W, stride, wide=False):
     import ctypes
     Dq, Hq, Wq, guard = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_long()
-    _lib.check(_lib.lib().mlagg_conv_pad_geometry(D, H, W, stride, ctypes.byref(Dq), ctypes.byref(Hq), ctypes.byref(Wq),
+    _lib.check(_lib.lib().mlagg_conv_pad_geometry(D, H, W, stride, int(wide), ctypes.byref(Dq), ctypes.byref(Hq), ctypes.byref(Wq),
                                                   ctypes.byref(guard)), "mlagg_conv_pad_geometry")
     return Dq.value, Hq.value, Wq.value, guard.value
 
@@ -1336,6 +1336,8 @@ def _pad_geometry(D, H, W, stride):
 # (K15 incl. its two pad copies reaches 28-59 TFLOP/s there) and 4-7x on the 1x1 shapes (plain GEMMs); step 43.5 -> 56.2 ms with it
 # on.  It pays where MIOpen has no tuned solver: the 3-D convolutions (8.2 s -> 66 ms per step at 2 x 96x160x160 voxels).
 K15_2D = _os.environ.get("MLAGG_K15_2D", "0") == "1"
+# K16 (forward / data gradient of the 3-D stride-1 convolutions on the tap-GEMM kernel) -- MLAGG_K16=0: MIOpen
+K16 = _os.environ.get("MLAGG_K16", "1") == "1"
 
 
 def conv_wgrad_supported(x, weight, stride, padding):
@@ -1347,25 +1349,40 @@ def conv_wgrad_supported(x, weight, stride, padding):
             and (int(stride[0]) == 1 or (int(stride[0]) == 2 and nd == 3 and all(int(v) > 1 for v in x.shape[2:]))))
 
 
-def conv_weight_grad(x, dy, k, stride):
-    """dW (O, I, k^nd) of a convolution y = conv(x, W, stride, padding k // 2) from x (B, I, *dims) and dy (B, O, *out_dims)."""
-    import ctypes
-    lib = _lib.lib()
-    x = _require(x.contiguous(), "x")
-    dy = _require(dy.contiguous(), "dy")
-    B, I = x.shape[:2]
-    O = dy.shape[1]
-    dims = tuple(x.shape[2:]) if x.dim() == 5 else (1,) + tuple(x.shape[2:])
-    odims = tuple(dy.shape[2:]) if dy.dim() == 5 else (1,) + tuple(dy.shape[2:])
-    nd = x.dim() - 2
-    Dq, Hq, Wq, guard = _pad_geometry(*dims, stride)
-    Q = Dq * Hq * Wq
-    row = 2 * guard + Q
-    nph = 1 if stride == 1 else 8
-    xp = torch.empty(B, nph, I, row, device=x.device, dtype=torch.float32)
-    dyp = torch.empty(B, 1, O, row, device=x.device, dtype=torch.float32)
-    _lib.check(lib.mlagg_volume_pad(_ptr(x), _ptr(xp), B, I, *dims, stride, 0, 0, 0, 0, _stream()), "mlagg_volume_pad")
-    _lib.check(lib.mlagg_volume_pad(_ptr(dy), _ptr(dyp), B, O, *dims, stride, 1, *odims, _stream()), "mlagg_volume_pad")
+def conv_taps_supported(x, weight, stride, padding):
+    """K16: 3-D, stride 1, last extent a multiple of 4, at least 8 input channels (a 1-channel stem would waste 31 / 32 of the MFMAs)."""
+    return (K16 and x.dim() == 5 and conv_wgrad_supported(x, weight, stride, padding) and int(stride[0]) == 1 and x.shape[-1] % 4 == 0
+            and x.shape[1] >= 8)
+
+
+class _Padded:
+    """A channel-major map copied into the zero-padded box of the tap-GEMM kernels (csrc/conv_wgrad.hip mlagg_volume_pad)."""
+
+    def __init__(self, t, dims, stride, wide, as_output_of=None):
+        import ctypes  # noqa: F401
+        lib = _lib.lib()
+        t = _require(t.contiguous(), "map")
+        self.B, self.C = t.shape[:2]
+        self.dims = tuple(dims)                                    # geometry of the convolution INPUT
+        self.stride, self.wide = stride, wide
+        self.Dq, self.Hq, self.Wq, self.guard = _pad_geometry(*self.dims, stride, wide)
+        self.Q = self.Dq * self.Hq * self.Wq
+        self.row = 2 * self.guard + self.Q
+        self.nph = 1 if (stride == 1 or as_output_of is not None) else 8
+        self.buf = torch.empty(self.B, self.nph, self.C, self.row, device=t.device, dtype=torch.float32)
+        od = tuple(t.shape[2:]) if t.dim() == 5 else (1,) + tuple(t.shape[2:])
+        if as_output_of is None:
+            _lib.check(lib.mlagg_volume_pad(_ptr(t), _ptr(self.buf), self.B, self.C, *self.dims, stride, int(wide), 0, 0, 0, 0, _stream()),
+                       "mlagg_volume_pad")
+        else:
+            _lib.check(lib.mlagg_volume_pad(_ptr(t), _ptr(self.buf), self.B, self.C, *self.dims, stride, int(wide), 1, *od, _stream()),
+                       "mlagg_volume_pad")
+
+    def ptr(self):
+        return self.buf.data_ptr() + 4 * self.guard
+
+
+def _tap_offsets(k, nd, stride, Hq, Wq, I=0, row=0):
     taps = []
     kz_range = range(k) if nd == 3 else (k // 2,)
     for kz in kz_range:
@@ -1379,14 +1396,81 @@ def conv_weight_grad(x, dy, k, stride):
                     az, ay, ax = (kz, ky, kx) if k == 3 else (1, 1, 1)
                     ph = ((az & 1) << 2) | ((ay & 1) << 1) | (ax & 1)
                     taps.append(ph * I * row + (az >> 1) * Hq * Wq + (ay >> 1) * Wq + (ax >> 1))
+    return taps
+
+
+def _wgrad_from_padded(xp, dyp, k, nd):
+    """K15 on the padded copies of the input (xp) and of the output gradient (dyp, same box geometry): dW (O, I, k^nd)."""
+    import ctypes
+    lib = _lib.lib()
+    O, I, B = dyp.C, xp.C, xp.B
+    taps = _tap_offsets(k, nd, xp.stride, xp.Hq, xp.Wq, I, xp.row)
     ntaps = len(taps)
-    Q8 = (Q + 7) & ~7
+    Q8 = (xp.Q + 7) & ~7
     off = (ctypes.c_long * ntaps)(*taps)
-    dW = torch.empty(O, I, ntaps, device=x.device, dtype=torch.float32)
-    ws = torch.empty(lib.mlagg_conv_wgrad_taps_workspace_floats(B, Q8, O, I, ntaps), device=x.device, dtype=torch.float32)
-    _lib.check(lib.mlagg_conv_wgrad_taps(dyp.data_ptr() + 4 * guard, O * row, row, xp.data_ptr() + 4 * guard, nph * I * row, row, off,
-                                         ntaps, Q8, O, I, B, _ptr(dW), 0, _ptr(ws), _stream()), "mlagg_conv_wgrad_taps")
+    dW = torch.empty(O, I, ntaps, device=xp.buf.device, dtype=torch.float32)
+    ws = torch.empty(lib.mlagg_conv_wgrad_taps_workspace_floats(B, Q8, O, I, ntaps), device=xp.buf.device, dtype=torch.float32)
+    _lib.check(lib.mlagg_conv_wgrad_taps(dyp.ptr(), O * dyp.row, dyp.row, xp.ptr(), xp.nph * I * xp.row, xp.row, off, ntaps, Q8, O, I, B,
+                                         _ptr(dW), 0, _ptr(ws), _stream()), "mlagg_conv_wgrad_taps")
     return dW
+
+
+def conv_weight_grad(x, dy, k, stride):
+    """dW (O, I, k^nd) of a convolution y = conv(x, W, stride, padding k // 2) from x (B, I, *dims) and dy (B, O, *out_dims)."""
+    nd = x.dim() - 2
+    dims = tuple(x.shape[2:]) if nd == 3 else (1,) + tuple(x.shape[2:])
+    xp = _Padded(x, dims, stride, False)
+    dyp = _Padded(dy, dims, stride, False, as_output_of=xp)
+    return _wgrad_from_padded(xp, dyp, k, nd)
+
+
+def _conv_taps(src, weight, O, I, k, flip, dims):
+    """K16 on a padded copy `src` (wide stride-1 box): y (B, O, *dims) with weight (O', I', k^3) read as [o][i] (forward) or
+    transposed with flipped taps (data gradient: O = the convolution's input channels)."""
+    import ctypes
+    lib = _lib.lib()
+    ntaps = k ** 3
+    taps = _tap_offsets(k, 3, 1, src.Hq, src.Wq)
+    off = (ctypes.c_long * ntaps)(*taps)
+    y = torch.empty(src.B, O, *dims, device=src.buf.device, dtype=torch.float32)
+    w = _require(weight.contiguous(), "weight")
+    if flip:      # weight (Cout_conv = I here, Cin_conv = O here, taps): output channel o -> stride ntaps, contraction i -> stride O * ntaps
+        w_so, w_si = ntaps, O * ntaps
+    else:
+        w_so, w_si = I * ntaps, ntaps
+    _lib.check(lib.mlagg_conv_taps(src.ptr(), src.C * src.row, src.row, _ptr(w), w_so, w_si, int(flip), off, ntaps, _ptr(y), src.B, O, I,
+                                   *dims, _stream()), "mlagg_conv_taps")
+    return y
+
+
+class ConvTapsFn(torch.autograd.Function):
+    """y = conv3d(x, W) (stride 1; kernel 3 pad 1 or kernel 1; no bias) entirely on this package's tap-GEMM kernels: K16 forward on a
+    zero-padded copy of x (kept for backward), K16 data gradient on the padded copy of dy, K15 weight gradient on the two copies."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        dims = tuple(x.shape[2:])
+        k = int(weight.shape[2])
+        xp = _Padded(x, dims, 1, True)
+        y = _conv_taps(xp, weight, weight.shape[0], weight.shape[1], k, False, dims)
+        ctx.xp = xp
+        ctx.save_for_backward(weight)
+        ctx.meta = (dims, k)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (weight,) = ctx.saved_tensors
+        dims, k = ctx.meta
+        xp = ctx.xp
+        dyp = _Padded(dy, dims, 1, True, as_output_of=xp)
+        dx = dW = None
+        if ctx.needs_input_grad[0]:
+            dx = _conv_taps(dyp, weight, weight.shape[1], weight.shape[0], k, True, dims)
+        if ctx.needs_input_grad[1]:
+            dW = _wgrad_from_padded(xp, dyp, k, 3).view(weight.shape)
+        ctx.xp = None
+        return dx, dW
 
 
 class ConvNdFn(torch.autograd.Function):
@@ -1417,7 +1501,10 @@ class ConvNdFn(torch.autograd.Function):
 
 
 def conv_nd(x, weight, stride, padding):
-    """Bias-free convolution; the tap-GEMM weight gradient when the shape is one it is built for, plain torch otherwise."""
+    """Bias-free convolution; the tap-GEMM kernels when the shape is one they are built for (K16 + K15: 3-D stride 1; K15 weight
+    gradient behind MIOpen's forward / data gradient: 3-D stride 2), plain torch otherwise."""
+    if conv_taps_supported(x, weight, stride, padding):
+        return ConvTapsFn.apply(x, weight)
     if conv_wgrad_supported(x, weight, stride, padding):
         return ConvNdFn.apply(x, weight, tuple(stride), tuple(padding))
     conv = torch.nn.functional.conv3d if x.dim() == 5 else torch.nn.functional.conv2d

@@ -59,3 +59,35 @@ def test_conv_nd_forward_and_both_gradients():
     # anisotropic stride (the last pooling of the BTCV plan): not a K15 shape, plain library path, same numbers
     y2 = ops.conv_nd(xg, wg, (1, 2, 2), (1, 1, 1))
     assert float((y2.detach().cpu().double() - F.conv3d(xr, wr, None, (1, 2, 2), 1).detach()).abs().max()) < 1e-4
+
+
+K16_CASES = [
+    # (B, I, O, dims, k)              stride 1, last extent a multiple of 4, >= 8 input channels
+    (2, 8, 40, (5, 6, 8), 3),          # two tiles of output channels, partial chunk of input channels
+    (1, 40, 8, (4, 9, 12), 3),         # two chunks of input channels (32 + 8)
+    (2, 16, 6, (3, 5, 8), 1),          # 1x1x1
+    (1, 32, 32, (24, 40, 40), 3),      # a stage of BASELINE configs[3] at 1/64 of its voxels
+    (1, 9, 33, (2, 3, 4), 3),          # odd channel counts, a volume smaller than one workgroup's 512 voxels
+]
+
+
+@gpu
+@pytest.mark.parametrize("B,I,O,dims,k", K16_CASES)
+def test_conv_taps_forward_and_gradients_match_torch(B, I, O, dims, k):
+    """K16 (forward, data gradient) + K15 (weight gradient) behind ops.conv_nd against torch's conv3d in float64."""
+    from mlagg_unet_amd import ops
+    g = torch.Generator().manual_seed(I * 7 + O)
+    x = torch.randn(B, I, *dims, generator=g)
+    w = torch.randn(O, I, k, k, k, generator=g) * (I * k ** 3) ** -0.5
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv3d(xr, wr, None, 1, k // 2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    dev = torch.device("cuda:0")
+    xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    assert ops.conv_taps_supported(xg, wg, (1, 1, 1), (k // 2,) * 3)
+    y = ops.conv_nd(xg, wg, (1, 1, 1), (k // 2,) * 3)
+    y.backward(dy.to(dev))
+    for name, a, b in (("y", y.detach(), yr.detach()), ("dx", xg.grad, xr.grad), ("dW", wg.grad, wr.grad)):
+        err = float((a.cpu().double() - b).abs().max())
+        assert err <= 2e-5 * float(b.abs().max()) + 1e-5, (name, err)
