@@ -18,6 +18,11 @@ def family(n):
     if n.startswith("Cijk_"):
         return "GEMM (rocBLAS/hipBLASLt)"
     for key, lab in (("linear_lp", "HIP K5 projections (fwd, dx), 16-bit operands"), ("selscan", "HIP K1 selective scan"), ("sel1_", "HIP K1s one-state selective scan (3-D)"),
+                     ("conv_taps_kernel", "HIP K16 convolution forward / data gradient (tap GEMM)"),
+                     ("conv_wgrad_", "HIP K15 convolution weight gradient (tap GEMM)"), ("volume_pad_kernel", "HIP K15/K16 padded copies"),
+                     ("guard_zero_kernel", "HIP K15/K16 padded copies"), ("pooled_lp_", "HIP K4lp pooled diff-attention (16-bit MFMA)"),
+                     ("plane_split_", "HIP K10 plane norm + activation"), ("channel_epilogue", "HIP K13 convolution epilogue"),
+                     ("channel_gelu", "HIP K13 convolution epilogue"),
                      ("index_scan_kernel", "HIP K14 index scan / merge"), ("block_sum_kernel", "HIP K14 index scan / merge"), ("cross_scan_kernel", "HIP K1' cross-scan / merge"),
                      ("dwconv", "HIP K2 depthwise conv"),
                      ("local_attn", "HIP K3 local diff-attention"), ("pooled_attn", "HIP K4 pooled diff-attention"),
