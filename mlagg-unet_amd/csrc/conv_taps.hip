@@ -59,7 +59,9 @@ conv_taps_kernel(const float *__restrict__ xp, const float *__restrict__ Wt, flo
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const float *xb = xp + (long)b * g.x_batch + qw + 4 * col;
+    // lanes of the last workgroup that lie past the box load from its last group instead (their results are never stored): no read
+    // ever leaves [box start - guard, box end + guard)
+    const float *xb = xp + (long)b * g.x_batch + min(qw + 4 * col, g.Q - 4);
     for (int ic = 0; ic < g.I; ic += CCH) {
         __syncthreads();                                // the previous chunk's weight reads are done
         for (int e = threadIdx.x; e < g.ntaps * CCH * 32; e += 256) {
