@@ -253,8 +253,8 @@ int mlagg_cross_merge(const float *seq, float *tok, int tok_stride, int blk_stri
  * ------------------------------------------------------------------------------------------ */
 int mlagg_gate_fwd(const float *a0, const float *a1, const float *act, int act_stride, float *out, long rows, int h,
                    void *stream);
-int mlagg_gate_bwd(const float *dout, int dout_stride, const float *a0, const float *a1, const float *act,
-                   int act_stride, float *da0, float *da1, float *dact, long rows, int h, void *stream);
+int mlagg_gate_bwd(const float *dout, int dout_stride, const float *a0, const float *a1, const float *act, int act_stride,
+                   float *da0, float *da1, float *dact, int dact_stride, long rows, int h, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K8: small fused ops.

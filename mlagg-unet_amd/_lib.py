@@ -78,7 +78,7 @@ SIGNATURES = {
     "mlagg_adamw_clip_step": (_I, [_F, _F, _I, _F] + [ctypes.c_float] * 6 + [_I, _S]),
     "mlagg_transpose_2d": (_I, [_F, ctypes.c_long, _F, _I, _I, _I, _S]),
     "mlagg_gate_fwd": (_I, [_F, _F, _F, _I, _F, ctypes.c_long, _I, _S]),
-    "mlagg_gate_bwd": (_I, [_F, _I, _F, _F, _F, _I, _F, _F, _F, ctypes.c_long, _I, _S]),
+    "mlagg_gate_bwd": (_I, [_F, _I, _F, _F, _F, _I, _F, _F, _F, _I, ctypes.c_long, _I, _S]),
     "mlagg_linear_fwd": (_I, [_F, _I, _F, _F, _F, _I, _I, _I, _I, _S]),
     "mlagg_linear_dgrad": (_I, [_F, _I, _F, _F, _I, _I, _I, _I, _S]),
     "mlagg_linear_lp_fwd": (_I, [_F, _I, _F, _F, _F, _I, _I, _I, _I, _I, _S]),

@@ -36,7 +36,7 @@ gate_fwd_kernel(const float *__restrict__ a0, const float *__restrict__ a1, cons
 __global__ void __launch_bounds__(256)
 gate_bwd_kernel(const float *__restrict__ dout, int dout_stride, const float *__restrict__ a0,
                 const float *__restrict__ a1, const float *__restrict__ act, int act_stride, float *__restrict__ da0,
-                float *__restrict__ da1, float *__restrict__ dact, long rows, int h)
+                float *__restrict__ da1, float *__restrict__ dact, int dact_stride, long rows, int h)
 {
     const int q = h >> 2;
     const long n = rows * 2 * q;
@@ -61,7 +61,7 @@ gate_bwd_kernel(const float *__restrict__ dout, int dout_stride, const float *__
         dg = make_float4(rg[0], rg[1], rg[2], rg[3]);
         if (lo) *reinterpret_cast<float4 *>(da0 + r * h + 4 * c4) = da;
         else *reinterpret_cast<float4 *>(da1 + r * h + 4 * (c4 - q)) = da;
-        *reinterpret_cast<float4 *>(dact + r * 2 * h + 4 * c4) = dg;
+        *reinterpret_cast<float4 *>(dact + r * dact_stride + 4 * c4) = dg;
     }
 }
 
@@ -86,15 +86,15 @@ extern "C" int mlagg_gate_fwd(const float *a0, const float *a1, const float *act
 }
 
 extern "C" int mlagg_gate_bwd(const float *dout, int dout_stride, const float *a0, const float *a1, const float *act,
-                              int act_stride, float *da0, float *da1, float *dact, long rows, int h, void *stream)
+                              int act_stride, float *da0, float *da1, float *dact, int dact_stride, long rows, int h, void *stream)
 {
     if (!dout || !a0 || !a1 || !act || !da0 || !da1 || !dact) return MLAGG_E_NULLPTR;
     if (rows <= 0 || h <= 0 || (h & 3) || act_stride < 2 * h || (act_stride & 3) || dout_stride < 2 * h ||
-        (dout_stride & 3))
+        (dout_stride & 3) || dact_stride < 2 * h || (dact_stride & 3))
         return MLAGG_E_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     MLAGG_TIMED(K_GATE_BWD, st);
     hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for(rows * (h / 2))), dim3(256), 0, st, dout, dout_stride, a0, a1, act,
-                       act_stride, da0, da1, dact, rows, h);
+                       act_stride, da0, da1, dact, dact_stride, rows, h);
     return (int)hipGetLastError();
 }

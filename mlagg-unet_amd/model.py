@@ -265,8 +265,8 @@ class AggregatedAttention(nn.Module):
             # q and kv in ONE GEMM over stacked weights (one read of x, one gradient into x); the kernel
             # takes the q / kv column blocks of the (B, N, 3d) result as strided views
             qkv = ops.linear(x, torch.cat([self.q.weight, self.kv.weight]), torch.cat([self.q.bias, self.kv.bias]))
-            # split (not slicing): its backward is ONE concatenation instead of a zero-fill + copy per slice + adds
-            q, kv = qkv.split([d, 2 * d], dim=-1)
+            # split_cols: the q / kv backward kernels write into one (B, N, 3d) gradient buffer (no concatenation)
+            q, kv = ops.split_cols(qkv, (d, 2 * d))
             return ops.local_diff_attn(q, kv, lam, self.subln.weight, self.lepe.weight, self.lepe.bias,
                                        self.H, self.W, self.num_heads, self.scale)
         # q, the value half of kv (LePE input; k is discarded at full resolution, T:719) and the 1x1 `sr`
@@ -274,7 +274,7 @@ class AggregatedAttention(nn.Module):
         w3 = torch.cat([self.q.weight, self.kv.weight[d:], self.sr.weight.view(d, d)])
         b3 = torch.cat([self.q.bias, self.kv.bias[d:], self.sr.bias])
         qvs = ops.linear(x, w3, b3)
-        q, v_full, s_pre = qvs.split([d, d, d], dim=-1)
+        q, v_full, s_pre = ops.split_cols(qvs, (d, d, d))
         s = F.gelu(s_pre)
         if self.H % self.sr_ratio == 0 and self.W % self.sr_ratio == 0:
             r = self.sr_ratio
@@ -314,7 +314,7 @@ class MLLABlock(nn.Module):
         ai = ops.linear(xn, torch.cat([self.act_proj.weight, self.in_proj.weight]),
                         torch.cat([self.act_proj.bias, self.in_proj.bias]))
         h = C // 2
-        act_pre, xa_in, za_in = ai.split([C, h, h], dim=-1)
+        act_pre, xa_in, za_in = ops.split_cols(ai, (C, h, h))
         # depthwise conv per channel half: the halves come out contiguous for the branch projections
         # (a channel slice of a (B, N, C) row would be copied by every Linear that consumes it)
         wa, wz = self.dwc.weight.split([h, h], dim=0)

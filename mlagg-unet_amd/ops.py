@@ -203,11 +203,96 @@ def _rows(t, name):
     return t, t.stride(1)
 
 
+class _GradSlot:
+    """Column block [col0, col0 + width) of the gradient buffer of one ``split_cols`` call.  The FIRST kernel wrapper that consumes the
+    piece claims the slot; its backward kernel then writes d(piece) straight into the shared (B, N, total) buffer (row stride =
+    total), so the split's backward hands that buffer on as it is instead of concatenating the pieces
+    (``CatArrayBatchedCopy``: 40 launches, 0.79 ms of the 256 x 256 step in profiles/round2_d_kernel_trace_timed_region.md)."""
+
+    __slots__ = ("arena", "col0", "width", "claimed")
+
+    def __init__(self, arena, col0, width):
+        self.arena, self.col0, self.width, self.claimed = arena, col0, width, False
+
+    def view(self):
+        return self.arena.buffer()[..., self.col0:self.col0 + self.width]
+
+
+class _GradArena:
+    def __init__(self, shape, device):
+        self.shape, self.device, self.buf = tuple(shape), device, None
+
+    def buffer(self):
+        if self.buf is None:
+            self.buf = torch.empty(self.shape, device=self.device, dtype=torch.float32)
+        return self.buf
+
+
+def _claim(t):
+    """The gradient slot of a ``split_cols`` piece, if it has one nobody claimed yet (a piece feeding two kernels: the second takes
+    the ordinary path and autograd's sum of the two gradients is copied into the slot)."""
+    slot = getattr(t, "_mlagg_slot", None)
+    if slot is None or slot.claimed or not torch.is_grad_enabled():
+        return None
+    slot.claimed = True
+    return slot
+
+
+def _grad_out(slot, shape, device):
+    """(tensor, row stride) a backward kernel writes d(input) into: the claimed arena slot or a fresh contiguous tensor."""
+    if slot is not None:
+        v = slot.view()
+        return v, v.stride(-2)
+    t = torch.empty(shape, device=device, dtype=torch.float32)
+    return t, shape[-1]
+
+
+class SplitColsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, arena, *sizes):
+        ctx.arena, ctx.sizes = arena, sizes
+        return t.split(list(sizes), dim=-1)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        arena, sizes = ctx.arena, ctx.sizes
+        buf = arena.buffer()
+        col0 = 0
+        for g, w in zip(grads, sizes):
+            dst = buf[..., col0:col0 + w]
+            if g is None:
+                dst.zero_()
+            elif g.data_ptr() != dst.data_ptr() or g.stride() != dst.stride():
+                dst.copy_(g)
+            col0 += w
+        arena.buf = None
+        return (buf, None) + (None,) * len(sizes)
+
+
+GRAD_ARENA = _os.environ.get("MLAGG_GRAD_ARENA", "1") == "1"
+
+
+def split_cols(t, sizes):
+    """``t.split(sizes, dim=-1)`` of a fresh (B, N, total) projection output whose pieces feed this package's kernels: the pieces are
+    the same strided views, and the kernels' backward passes write into ONE gradient buffer (see _GradSlot)."""
+    if not (GRAD_ARENA and t.is_cuda and t.requires_grad and torch.is_grad_enabled() and t.dim() == 3 and t.is_contiguous()
+            and all(w % 4 == 0 for w in sizes)):
+        return t.split(list(sizes), dim=-1)
+    arena = _GradArena(t.shape, t.device)
+    pieces = SplitColsFn.apply(t, arena, *sizes)
+    col0 = 0
+    for p_, w in zip(pieces, sizes):
+        p_._mlagg_slot = _GradSlot(arena, col0, w)
+        col0 += w
+    return pieces
+
+
 class DWConv3x3Fn(torch.autograd.Function):
     """K2: depthwise 3x3 (+bias, optional SiLU) on token-major maps."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, H, W, silu):
+    def forward(ctx, x, weight, bias, H, W, silu, slot=None):
+        ctx.slot = slot
         x, xs = _rows(x, "x")
         B, N, C = x.shape
         if N != H * W:
@@ -227,19 +312,19 @@ class DWConv3x3Fn(torch.autograd.Function):
         H, W, silu, has_bias, wshape = ctx.geom
         B, N, C = x.shape
         dy, dys = _rows(dy, "dy")
-        dx = torch.empty(B, N, C, device=x.device, dtype=torch.float32)
+        dx, dxs = _grad_out(ctx.slot, (B, N, C), x.device)
         dw = torch.empty(C, 9, device=x.device, dtype=torch.float32)
         db = torch.empty(C, device=x.device, dtype=torch.float32) if has_bias else None
         lib = _lib.lib()
         ws = torch.empty(lib.mlagg_dwconv3x3_bwd_workspace_floats(B, H, W, C), device=x.device, dtype=torch.float32)
-        _lib.check(lib.mlagg_dwconv3x3_bwd(_ptr(x), x.stride(1), _ptr(w), _ptr(dy), dys, _ptr(pre), _ptr(dx), C,
+        _lib.check(lib.mlagg_dwconv3x3_bwd(_ptr(x), x.stride(1), _ptr(w), _ptr(dy), dys, _ptr(pre), _ptr(dx), dxs,
                                            _ptr(dw), _ptr(db), _ptr(ws), B, H, W, C, int(silu), _stream()),
                    "mlagg_dwconv3x3_bwd")
-        return dx, dw.reshape(wshape), db, None, None, None
+        return dx, dw.reshape(wshape), db, None, None, None, None
 
 
 def dwconv3x3_nlc(x, weight, bias, H, W, silu=False):
-    return DWConv3x3Fn.apply(x, weight, bias, H, W, silu)
+    return DWConv3x3Fn.apply(x, weight, bias, H, W, silu, _claim(x))
 
 
 class DWConv3dFn(torch.autograd.Function):
@@ -337,7 +422,8 @@ class LocalDiffAttnFn(torch.autograd.Function):
     """K3: fused 3x3-window differential attention + RMSNorm + LePE (AggregatedAttention local branch)."""
 
     @staticmethod
-    def forward(ctx, q, kv, lam, subln_w, lepe_w, lepe_b, H, W, nh, scale):
+    def forward(ctx, q, kv, lam, subln_w, lepe_w, lepe_b, H, W, nh, scale, q_slot=None, kv_slot=None):
+        ctx.slots = (q_slot, kv_slot)
         q, qs = _rows(q, "q")
         kv, kvs = _rows(kv, "kv")
         B, N, d = q.shape
@@ -362,23 +448,24 @@ class LocalDiffAttnFn(torch.autograd.Function):
         B, N, d = q.shape
         dout, dos = _rows(dout, "dout")
         lib = _lib.lib()
-        dq = torch.empty(B, N, d, device=q.device, dtype=torch.float32)
-        dkv = torch.empty(B, N, 2 * d, device=q.device, dtype=torch.float32)
+        dq, dqs = _grad_out(ctx.slots[0], (B, N, d), q.device)
+        dkv, dkvs = _grad_out(ctx.slots[1], (B, N, 2 * d), q.device)
         small = torch.zeros(1 + 48 + d * 9 + d, device=q.device, dtype=torch.float32)
         dlam, dsub, dlw, dlb = small[:1], small[1:49], small[49:49 + d * 9], small[49 + d * 9:]
         ws = torch.empty(lib.mlagg_local_attn_bwd_workspace_floats(B, H, W, nh), device=q.device, dtype=torch.float32)
         _lib.check(lib.mlagg_local_attn_bwd(_ptr(q), q.stride(1), _ptr(kv), kv.stride(1), _ptr(lam), _ptr(subln_w),
-                                            _ptr(lw), _ptr(dout), dos, _ptr(dq), d, _ptr(dkv), 2 * d, _ptr(dlam),
+                                            _ptr(lw), _ptr(dout), dos, _ptr(dq), dqs, _ptr(dkv), dkvs, _ptr(dlam),
                                             _ptr(dsub), _ptr(dlw), _ptr(dlb), _ptr(ws), B, H, W, nh, scale, _stream()),
                    "mlagg_local_attn_bwd")
-        return dq, dkv, dlam.reshape(()), dsub, dlw.reshape(lwshape), dlb, None, None, None, None
+        return dq, dkv, dlam.reshape(()), dsub, dlw.reshape(lwshape), dlb, None, None, None, None, None, None
 
 
 class PooledDiffAttnFn(torch.autograd.Function):
     """K4: fused pooled differential attention + RMSNorm (AggregatedAttention global branch)."""
 
     @staticmethod
-    def forward(ctx, q, kp, vp, lam, subln_w, nh, scale):
+    def forward(ctx, q, kp, vp, lam, subln_w, nh, scale, q_slot=None):
+        ctx.slot = q_slot
         q, qs = _rows(q, "q")
         kp, kps = _rows(kp, "k_pool")
         vp, vps = _rows(vp, "v_pool")
@@ -407,16 +494,16 @@ class PooledDiffAttnFn(torch.autograd.Function):
         P = kp.shape[1]
         dout, dos = _rows(dout, "dout")
         lib = _lib.lib()
-        dq = torch.empty(B, N, d, device=q.device, dtype=torch.float32)
+        dq, dqs = _grad_out(ctx.slot, (B, N, d), q.device)
         dkp = torch.empty(B, P, d, device=q.device, dtype=torch.float32)
         dvp = torch.empty(B, P, d, device=q.device, dtype=torch.float32)
         small = torch.zeros(1 + 48, device=q.device, dtype=torch.float32)
         ws = torch.empty(lib.mlagg_pooled_attn_bwd_workspace_floats(B, N, P, nh), device=q.device, dtype=torch.float32)
         _lib.check(lib.mlagg_pooled_attn_bwd(_ptr(q), q.stride(1), _ptr(kp), kp.stride(1), _ptr(vp), vp.stride(1),
                                              _ptr(lam), _ptr(subln_w), _ptr(dout), dos, _ptr(lse), _ptr(o_pre),
-                                             _ptr(dq), d, _ptr(dkp), d, _ptr(dvp), d, _ptr(small[:1]), _ptr(small[1:]),
+                                             _ptr(dq), dqs, _ptr(dkp), d, _ptr(dvp), d, _ptr(small[:1]), _ptr(small[1:]),
                                              _ptr(ws), B, N, P, nh, scale, _stream()), "mlagg_pooled_attn_bwd")
-        return dq, dkp, dvp, small[0].reshape(()), small[1:], None, None
+        return dq, dkp, dvp, small[0].reshape(()), small[1:], None, None, None, None
 
 
 class PooledDiffAttnLpFn(torch.autograd.Function):
@@ -425,7 +512,8 @@ class PooledDiffAttnLpFn(torch.autograd.Function):
     nnUNetTrainer_MLAgg_2D_dt_MS.py:733-751), sums / softmax / RMSNorm and every tensor in memory fp32."""
 
     @staticmethod
-    def forward(ctx, q, kp, vp, lam, subln_w, nh, scale, cdt):
+    def forward(ctx, q, kp, vp, lam, subln_w, nh, scale, cdt, q_slot=None):
+        ctx.slot = q_slot
         q, qs = _rows(q, "q")
         kp, kps = _rows(kp, "k_pool")
         vp, vps = _rows(vp, "v_pool")
@@ -454,16 +542,16 @@ class PooledDiffAttnLpFn(torch.autograd.Function):
         P = kp.shape[1]
         dout, dos = _rows(dout, "dout")
         lib = _lib.lib()
-        dq = torch.empty(B, N, d, device=q.device, dtype=torch.float32)
+        dq, dqs = _grad_out(ctx.slot, (B, N, d), q.device)
         dkp = torch.empty(B, P, d, device=q.device, dtype=torch.float32)
         dvp = torch.empty(B, P, d, device=q.device, dtype=torch.float32)
         small = torch.empty(1 + 48, device=q.device, dtype=torch.float32)
         ws = torch.empty(lib.mlagg_pooled_attn_lp_bwd_workspace_floats(B, N, P, nh), device=q.device, dtype=torch.float32)
         _lib.check(lib.mlagg_pooled_attn_lp_bwd(_ptr(q), q.stride(1), _ptr(kp), kp.stride(1), _ptr(vp), vp.stride(1), _ptr(lam),
-                                                _ptr(subln_w), _ptr(dout), dos, _ptr(lse), _ptr(o12[0]), _ptr(o12[1]), _ptr(dq), d,
+                                                _ptr(subln_w), _ptr(dout), dos, _ptr(lse), _ptr(o12[0]), _ptr(o12[1]), _ptr(dq), dqs,
                                                 _ptr(dkp), d, _ptr(dvp), d, _ptr(small[:1]), _ptr(small[1:]), _ptr(ws), B, N, P, nh, scale,
                                                 _LP_CODE[cdt], _stream()), "mlagg_pooled_attn_lp_bwd")
-        return dq, dkp, dvp, small[0].reshape(()), small[1:], None, None, None
+        return dq, dkp, dvp, small[0].reshape(()), small[1:], None, None, None, None
 
 
 class FlashAttnFn(torch.autograd.Function):
@@ -508,7 +596,7 @@ def flash_attn(q, k, v, softmax_scale=None):
 
 
 def local_diff_attn(q, kv, lam, subln_w, lepe_w, lepe_b, H, W, nh, scale):
-    return LocalDiffAttnFn.apply(q, kv, lam, subln_w, lepe_w, lepe_b, H, W, nh, scale)
+    return LocalDiffAttnFn.apply(q, kv, lam, subln_w, lepe_w, lepe_b, H, W, nh, scale, _claim(q), _claim(kv))
 
 
 K4_LP = _os.environ.get("MLAGG_K4_LP", "1") == "1"
@@ -517,8 +605,8 @@ K4_LP = _os.environ.get("MLAGG_K4_LP", "1") == "1"
 def pooled_diff_attn(q, k_pool, v_pool, lam, subln_w, nh, scale):
     cdt = compute_dtype()
     if cdt != torch.float32 and K4_LP and k_pool.shape[1] <= 320:
-        return PooledDiffAttnLpFn.apply(q, k_pool, v_pool, lam, subln_w, nh, scale, cdt)
-    return PooledDiffAttnFn.apply(q, k_pool, v_pool, lam, subln_w, nh, scale)
+        return PooledDiffAttnLpFn.apply(q, k_pool, v_pool, lam, subln_w, nh, scale, cdt, _claim(q))
+    return PooledDiffAttnFn.apply(q, k_pool, v_pool, lam, subln_w, nh, scale, _claim(q))
 
 
 WGRAD_MIN_ROWS = 8192      # below this many tokens the library GEMM is no longer the split-K corner case
@@ -947,7 +1035,8 @@ class GateFn(torch.autograd.Function):
     """K7: concat(a0, a1) * SiLU(act) (the MLLA block's gate) in one pass each way."""
 
     @staticmethod
-    def forward(ctx, a0, a1, act):
+    def forward(ctx, a0, a1, act, slot=None):
+        ctx.slot = slot
         a0 = _require(a0.contiguous(), "a0")
         a1 = _require(a1.contiguous(), "a1")
         act2, acts = _rows2d(act, "act")
@@ -974,14 +1063,14 @@ class GateFn(torch.autograd.Function):
             d2 = d2.contiguous()
             ds = 2 * h
         da0, da1 = torch.empty_like(a0), torch.empty_like(a1)
-        dact = torch.empty(a0.shape[:-1] + (2 * h,), device=a0.device, dtype=torch.float32)
+        dact, dacts = _grad_out(ctx.slot, a0.shape[:-1] + (2 * h,), a0.device)
         _lib.check(_lib.lib().mlagg_gate_bwd(_ptr(d2), ds, _ptr(a0), _ptr(a1), _ptr(act2), act2.stride(0), _ptr(da0),
-                                             _ptr(da1), _ptr(dact), rows, h, _stream()), "mlagg_gate_bwd")
-        return da0, da1, dact
+                                             _ptr(da1), _ptr(dact), dacts, rows, h, _stream()), "mlagg_gate_bwd")
+        return da0, da1, dact, None
 
 
 def gate(a0, a1, act):
-    return GateFn.apply(a0, a1, act)
+    return GateFn.apply(a0, a1, act, _claim(act))
 
 
 class DiffLambdaFn(torch.autograd.Function):

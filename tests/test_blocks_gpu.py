@@ -715,3 +715,34 @@ def test_channel_epilogue_16_bit_maps(dt, act):
     assert float((ba.grad.cpu().double() - bb.grad).abs().max()) <= 1e-4 * float(bb.grad.abs().max()) + 1e-4
     if ra is not None:
         assert ra.grad.dtype == torch.float32 and float((ra.grad.cpu().double() - rb.grad).abs().max()) < 1e-6
+
+
+@gpu
+def test_split_cols_gradient_buffer_equals_concatenated_gradients():
+    """ops.split_cols: kernels that claim a piece write its gradient into the shared buffer; a piece used twice, a piece that feeds a
+    plain torch op and a piece nobody uses all end with the gradient torch's own split + cat produce."""
+    from mlagg_unet_amd import ops
+    torch.manual_seed(5)
+    B, H, W, C = 2, 16, 16, 96
+    h = C // 2
+    base = torch.randn(B, H * W, 2 * C + 48, device=DEV)
+    w_dw = torch.randn(h, 1, 3, 3, device=DEV) * 0.3
+    b_dw = torch.randn(h, device=DEV) * 0.1
+    a0, a1 = torch.randn(B, H * W, h, device=DEV), torch.randn(B, H * W, h, device=DEV)
+
+    def run(splitter):
+        t = base.clone().requires_grad_(True)
+        t2 = t * 1.0                                    # a non-leaf, like a projection output
+        act, xa, za, _unused = splitter(t2, (C, h, h, 48))
+        g = ops.gate(a0, a1, act)                       # claims `act`
+        d1 = ops.dwconv3x3_nlc(xa, w_dw, b_dw, H, W, silu=True)         # claims `xa`
+        d2 = ops.dwconv3x3_nlc(xa, w_dw, b_dw, H, W, silu=False)        # second consumer of the same piece
+        e = F.gelu(za)                                  # torch op: gradient copied into the buffer
+        loss = (g * g).sum() + (d1 * 0.5).sum() + (d2 * d2).sum() + (e * 1.5).sum()
+        loss.backward()
+        return t.grad
+
+    g_arena = run(ops.split_cols)
+    g_plain = run(lambda t, sizes: t.split(list(sizes), dim=-1))
+    assert torch.equal(g_arena, g_plain)
+    assert float(g_arena[..., 2 * C:].abs().max()) == 0.0
