@@ -143,8 +143,9 @@ int mlagg_pooled_attn_bwd(const float *q, int q_stride, const float *kp, int kp_
  * the pooled branch), MambaSkip.py:521-523 (conv2d + SiLU) and M:553 (ConvolutionalGLU.dwconv).
  *   pre: (batch, H*W, C) contiguous pre-activation saved for backward when silu (NULL otherwise /
  *        inference).  Backward WRITES dw (C, 9) and dbias (C) (no zero-fill needed).
+ *   res: NULL, or (batch, H*W, C) contiguous, added to the output (silu == 0 only): x + lepe(v) of T:782 in the same pass.
  * ------------------------------------------------------------------------------------------ */
-int mlagg_dwconv3x3_fwd(const float *x, int x_stride, const float *w, const float *bias, float *y,
+int mlagg_dwconv3x3_fwd(const float *x, int x_stride, const float *w, const float *bias, const float *res, float *y,
                         int y_stride, float *pre, int batch, int H, int W, int C, int silu, void *stream);
 size_t mlagg_dwconv3x3_bwd_workspace_floats(int batch, int H, int W, int C);
 int mlagg_dwconv3x3_bwd(const float *x, int x_stride, const float *w, const float *dy, int dy_stride,
@@ -207,6 +208,17 @@ size_t mlagg_layernorm_bwd_workspace_floats(int rows, int C);
 int mlagg_layernorm_bwd(const float *x, int x_stride, const float *dy, int dy_stride, const float *gamma,
                         const float *stats, float *dx, float *dgamma, float *dbeta, float *workspace,
                         int rows, int C, void *stream);
+/* K6 with the residual junction in front of the norm in the same pass (nnUNetTrainer_MLAgg_2D_dt_MS.py:905-907: x = shortcut +
+ * drop_path(out_proj(..)); x = x + drop_path(mlp(norm2(x))) -- and norm1 of the next block of the stage, T:887):
+ *   xsum = skip + branch * scale[row / rows_per_sample],   y = LayerNorm(xsum) * gamma + beta
+ * skip, branch, xsum, y (rows, C) contiguous; scale: one stochastic-depth factor per sample (rows_per_sample rows each), NULL = 1.
+ * Backward: dskip = LayerNorm'(dy) + dres (dres: gradient reaching xsum from its other consumers, NULL = none), dbranch = dskip *
+ * scale (NULL exactly when scale is: the two gradients coincide); workspace: mlagg_layernorm_bwd_workspace_floats(rows, C). */
+int mlagg_residual_layernorm_fwd(const float *skip, const float *branch, const float *scale, const float *gamma, const float *beta,
+                                 float *xsum, float *y, float *stats, int rows, int rows_per_sample, int C, float eps, void *stream);
+int mlagg_residual_layernorm_bwd(const float *xsum, const float *dy, int dy_stride, const float *dres, const float *scale,
+                                 const float *gamma, const float *stats, float *dskip, float *dbranch, float *dgamma, float *dbeta,
+                                 float *workspace, int rows, int rows_per_sample, int C, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K2v: depthwise 3x3x3 convolution (zero padding 1, stride 1) + bias (+ SiLU when `silu`) on token-major volumes:
@@ -247,6 +259,16 @@ int mlagg_cross_merge(const float *seq, float *tok, int tok_stride, int blk_stri
                       const int *H, const int *W, int CB, int nblk, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K17: key / value reduction of the pooled attention branch, pooled (B, (H/r)(W/r), d) = r x r window mean of GELU(s), s (B, H W, d)
+ * token-major at row stride s_stride (a column block of the stacked q | v | sr projection).  Replaces nn.GELU + nn.AdaptiveAvgPool2d
+ * at nnUNetTrainer_MLAgg_2D_dt_MS.py:722 (modules at :668, :671) for H % r == W % r == 0 (other sizes: MLAGG_E_UNSUPPORTED, the
+ * caller keeps the library's adaptive pooling).  Backward overwrites ds (B, H W, d) at row stride ds_stride.
+ * ------------------------------------------------------------------------------------------ */
+int mlagg_gelu_pool_fwd(const float *s, int s_stride, float *pooled, int batch, int H, int W, int d, int r, void *stream);
+int mlagg_gelu_pool_bwd(const float *s, int s_stride, const float *dpooled, float *ds, int ds_stride, int batch, int H, int W, int d,
+                        int r, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * K7: gate of the MLLA block, out (rows, 2h) = concat(a0, a1) * SiLU(act) with a0, a1 (rows, h) contiguous and
  * act (rows, 2h) at row stride act_stride.  Replaces SiLU + torch.cat + product at
  * nnUNetTrainer_MLAgg_2D_dt_MS.py:888, 899, 902.  Backward overwrites da0, da1 (rows, h) and dact (rows, 2h).
@@ -278,10 +300,12 @@ int mlagg_transpose_2d(const float *src, long src_batch_stride, float *dst, int 
 /* Bias gradients.  channel_sum: out[c] = sum over batch and pixels of an NCHW gradient map g (B, C, HW) -- the bias gradient of
  * the convolutions around the path (torch computes it with a generic reduction inside convolution_backward); workspace:
  * mlagg_channel_sum_workspace_floats(B, C) floats.  column_sum: out[c] = sum_r x[r][c], x (rows, cols) at row stride x_stride --
- * the bias gradient of the Linear layers whose GEMMs go to the library (few tokens). */
+ * the bias gradient of the Linear layers whose GEMMs go to the library (few tokens); workspace: mlagg_column_sum_workspace_floats(rows,
+ * cols) floats (0 for short matrices; NULL: single launch, one workgroup per 64 columns). */
 size_t mlagg_channel_sum_workspace_floats(int B, int C);
 int mlagg_channel_sum(const float *g, float *out, float *workspace, int B, int C, long HW, void *stream);
-int mlagg_column_sum(const float *x, int x_stride, float *out, int rows, int cols, void *stream);
+size_t mlagg_column_sum_workspace_floats(int rows, int cols);
+int mlagg_column_sum(const float *x, int x_stride, float *out, float *workspace, int rows, int cols, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K1' for volumes: cross-scan / cross-merge by permutation table, the re-ordering of the 3-D selective scan

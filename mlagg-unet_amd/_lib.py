@@ -43,7 +43,7 @@ SIGNATURES = {
     "mlagg_pooled_attn_lp_bwd_workspace_floats": (_SZ, [_I, _I, _I, _I]),
     "mlagg_pooled_attn_lp_bwd": (_I, [_F, _I, _F, _I, _F, _I, _F, _F, _F, _I, _F, _F, _F, _F, _I, _F, _I, _F, _I, _F, _F, _F,
                                       _I, _I, _I, _I, _FL, _I, _S]),
-    "mlagg_dwconv3x3_fwd": (_I, [_F, _I, _F, _F, _F, _I, _F, _I, _I, _I, _I, _I, _S]),
+    "mlagg_dwconv3x3_fwd": (_I, [_F, _I, _F, _F, _F, _F, _I, _F, _I, _I, _I, _I, _I, _S]),
     "mlagg_dwconv3x3_bwd_workspace_floats": (_SZ, [_I, _I, _I, _I]),
     "mlagg_dwconv3x3_bwd": (_I, [_F, _I, _F, _F, _I, _F, _F, _I, _F, _F, _F, _I, _I, _I, _I, _I, _S]),
     "mlagg_dwconv3d_fwd": (_I, [_F, _I, _F, _F, _F, _I, _F, _I, _I, _I, _I, _I, _I, _S]),
@@ -55,6 +55,8 @@ SIGNATURES = {
     "mlagg_layernorm_fwd": (_I, [_F, _I, _F, _F, _F, _F, _I, _I, _FL, _S]),
     "mlagg_layernorm_bwd_workspace_floats": (_SZ, [_I, _I]),
     "mlagg_layernorm_bwd": (_I, [_F, _I, _F, _I, _F, _F, _F, _F, _F, _F, _I, _I, _S]),
+    "mlagg_residual_layernorm_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, ctypes.c_float, _S]),
+    "mlagg_residual_layernorm_bwd": (_I, [_F, _F, _I, _F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _S]),
     "mlagg_dwconv3x3_nchw_fwd": (_I, [_F, _F, _F, _F, _I, _I, _I, _I, _I, _S]),
     "mlagg_dwconv3x3_nchw_bwd_workspace_floats": (_SZ, [_I, _I, _I, _I, _I]),
     "mlagg_dwconv3x3_nchw_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _S]),
@@ -69,7 +71,8 @@ SIGNATURES = {
     "mlagg_dice_ce_grad": (_I, [_F, _F, _F, _F, _F, _I, _I, ctypes.c_long, _I, _S]),
     "mlagg_channel_sum_workspace_floats": (_SZ, [_I, _I]),
     "mlagg_channel_sum": (_I, [_F, _F, _F, _I, _I, ctypes.c_long, _S]),
-    "mlagg_column_sum": (_I, [_F, _I, _F, _I, _I, _S]),
+    "mlagg_column_sum_workspace_floats": (ctypes.c_size_t, [_I, _I]),
+    "mlagg_column_sum": (_I, [_F, _I, _F, _F, _I, _I, _S]),
     "mlagg_plane_norm_fwd_workspace_floats": (_SZ, [_I, _I, ctypes.c_long]),
     "mlagg_plane_norm_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _I, _I, ctypes.c_long, ctypes.c_float, _I, ctypes.c_float, _I, _I, _I, _S]),
     "mlagg_plane_norm_bwd_workspace_floats": (_SZ, [_I, _I, ctypes.c_long]),
@@ -77,6 +80,8 @@ SIGNATURES = {
     "mlagg_adamw_chunk_elements": (_I, []),
     "mlagg_adamw_clip_step": (_I, [_F, _F, _I, _F] + [ctypes.c_float] * 6 + [_I, _S]),
     "mlagg_transpose_2d": (_I, [_F, ctypes.c_long, _F, _I, _I, _I, _S]),
+    "mlagg_gelu_pool_fwd": (_I, [_F, _I, _F, _I, _I, _I, _I, _I, _S]),
+    "mlagg_gelu_pool_bwd": (_I, [_F, _I, _F, _F, _I, _I, _I, _I, _I, _I, _S]),
     "mlagg_gate_fwd": (_I, [_F, _F, _F, _I, _F, ctypes.c_long, _I, _S]),
     "mlagg_gate_bwd": (_I, [_F, _I, _F, _F, _F, _I, _F, _F, _F, _I, ctypes.c_long, _I, _S]),
     "mlagg_linear_fwd": (_I, [_F, _I, _F, _F, _F, _I, _I, _I, _I, _S]),

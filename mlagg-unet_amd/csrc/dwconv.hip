@@ -38,7 +38,7 @@ constexpr int HY = TY + 2, HX = TX + 2;
 template <bool SILU, bool FLIP>
 __global__ void __launch_bounds__(256)
 dwconv_tiled_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-                    float *__restrict__ y, float *__restrict__ pre, Geom g)
+                    const float *__restrict__ res, float *__restrict__ y, float *__restrict__ pre, Geom g)
 {
     __shared__ float4 tile[HY * HX * (CCH / 4)];
     const int tiles_x = (g.W + TX - 1) / TX;
@@ -88,6 +88,10 @@ dwconv_tiled_kernel(const float *__restrict__ x, const float *__restrict__ w, co
             acc.x += wr[0][j] * v.x; acc.y += wr[1][j] * v.y; acc.z += wr[2][j] * v.z; acc.w += wr[3][j] * v.w;
         }
         const size_t t = (size_t)b * N + (size_t)yy * g.W + xx;
+        if (!SILU && !FLIP && res) {          // y = conv(x) + bias + res: the sum with the attention output (T:782)
+            const float4 rv = *reinterpret_cast<const float4 *>(res + t * g.C + c);
+            acc.x += rv.x; acc.y += rv.y; acc.z += rv.z; acc.w += rv.w;
+        }
         if (SILU) {
             if (pre) *reinterpret_cast<float4 *>(pre + t * g.C + c) = acc;
             acc = make_float4(silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w));
@@ -270,21 +274,22 @@ extern "C" size_t mlagg_dwconv3x3_bwd_workspace_floats(int batch, int H, int W, 
     return mlagg_internal::dwconv_wgrad_workspace_floats(batch, H, W, C) + (size_t)batch * H * W * C;
 }
 
-extern "C" int mlagg_dwconv3x3_fwd(const float *x, int x_stride, const float *w, const float *bias, float *y,
+extern "C" int mlagg_dwconv3x3_fwd(const float *x, int x_stride, const float *w, const float *bias, const float *res, float *y,
                                    int y_stride, float *pre, int batch, int H, int W, int C, int silu,
                                    void *stream)
 {
     if (!x || !w || !y) return MLAGG_E_NULLPTR;
     Geom g;
     if (int rc = make_geom(g, batch, H, W, C, x_stride, y_stride)) return rc;
+    if (res && silu) return MLAGG_E_UNSUPPORTED;
     const dim3 grid(((W + TX - 1) / TX) * ((H + TY - 1) / TY), (C + CCH - 1) / CCH, batch), block(256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     {
         MLAGG_TIMED(K_DWCONV_FWD, st);
         if (silu)
-            hipLaunchKernelGGL((dwconv_tiled_kernel<true, false>), grid, block, 0, st, x, w, bias, y, pre, g);
+            hipLaunchKernelGGL((dwconv_tiled_kernel<true, false>), grid, block, 0, st, x, w, bias, nullptr, y, pre, g);
         else
-            hipLaunchKernelGGL((dwconv_tiled_kernel<false, false>), grid, block, 0, st, x, w, bias, y, pre, g);
+            hipLaunchKernelGGL((dwconv_tiled_kernel<false, false>), grid, block, 0, st, x, w, bias, res, y, pre, g);
     }
     return (int)hipGetLastError();
 }
@@ -309,8 +314,8 @@ extern "C" int mlagg_dwconv3x3_bwd(const float *x, int x_stride, const float *w,
         Geom gd = g;                       // source = g (or dy when no SiLU), destination = dx
         gd.x_stride = silu ? C : dy_stride;
         gd.y_stride = dx_stride;
-        hipLaunchKernelGGL((dwconv_tiled_kernel<false, true>), grid, block, 0, st, silu ? gbuf : dy, w, nullptr, dx, nullptr,
-                           gd);
+        hipLaunchKernelGGL((dwconv_tiled_kernel<false, true>), grid, block, 0, st, silu ? gbuf : dy, w, nullptr, nullptr, dx,
+                           nullptr, gd);
     }
     return (int)hipGetLastError();
 }

@@ -29,11 +29,15 @@ __device__ __forceinline__ float group_sum(float v)
     return v;
 }
 
-template <int LPR, int F4>
+// RES: the residual junction in front of the norm rides in the same pass -- the row normalised is
+//   xsum = x + branch * scale[row / rows_per_sample]      (scale: per-sample stochastic-depth factor, NULL = 1)
+// and xsum is written next to y (x = skip; T:905-907: x = x + drop_path(...); x = x + drop_path(mlp(norm2(x)))).
+template <int LPR, int F4, bool RES>
 __global__ void __launch_bounds__(BLOCK)
 layernorm_fwd_kernel(const float *__restrict__ x, int x_stride, const float *__restrict__ gamma,
                      const float *__restrict__ beta, float *__restrict__ y, float *__restrict__ stats, int rows,
-                     float eps)
+                     float eps, const float *__restrict__ branch, const float *__restrict__ scale, float *__restrict__ xsum,
+                     int rows_per_sample)
 {
     constexpr int C = LPR * F4 * 4;
     constexpr int RPB = BLOCK / LPR;                   // rows per workgroup iteration
@@ -50,6 +54,12 @@ layernorm_fwd_kernel(const float *__restrict__ x, int x_stride, const float *__r
 #pragma unroll
         for (int i = 0; i < F4; ++i) {
             v[i] = *reinterpret_cast<const float4 *>(x + row * x_stride + 4 * (sub + LPR * i));
+            if (RES) {
+                const float sc = scale ? scale[row / rows_per_sample] : 1.f;
+                const float4 br = *reinterpret_cast<const float4 *>(branch + row * C + 4 * (sub + LPR * i));
+                v[i].x += br.x * sc; v[i].y += br.y * sc; v[i].z += br.z * sc; v[i].w += br.w * sc;
+                *reinterpret_cast<float4 *>(xsum + row * C + 4 * (sub + LPR * i)) = v[i];
+            }
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
         const float mean = group_sum<LPR>(s) * (1.f / C);
@@ -71,11 +81,14 @@ layernorm_fwd_kernel(const float *__restrict__ x, int x_stride, const float *__r
     }
 }
 
-template <int LPR, int F4>
+// RES: dx = LayerNorm'(dy) + dres (the gradient reaching xsum from its other consumers, NULL = none) is the gradient of the skip
+// input; dbranch = dx * scale[sample] (NULL when scale is: the two gradients are then the same tensor).
+template <int LPR, int F4, bool RES>
 __global__ void __launch_bounds__(BLOCK)
 layernorm_bwd_kernel(const float *__restrict__ x, int x_stride, const float *__restrict__ dy, int dy_stride,
                      const float *__restrict__ gamma, const float *__restrict__ stats, float *__restrict__ dx,
-                     float *__restrict__ part, int rows)
+                     float *__restrict__ part, int rows, const float *__restrict__ dres, const float *__restrict__ scale,
+                     float *__restrict__ dbranch, int rows_per_sample)
 {
     constexpr int C = LPR * F4 * 4;
     constexpr int RPB = BLOCK / LPR;
@@ -108,6 +121,16 @@ layernorm_bwd_kernel(const float *__restrict__ x, int x_stride, const float *__r
             float4 o;
             o.x = rstd * (gy[i].x - m1 - xh[i].x * m2); o.y = rstd * (gy[i].y - m1 - xh[i].y * m2);
             o.z = rstd * (gy[i].z - m1 - xh[i].z * m2); o.w = rstd * (gy[i].w - m1 - xh[i].w * m2);
+            if (RES) {
+                if (dres) {
+                    const float4 dr = *reinterpret_cast<const float4 *>(dres + row * C + 4 * (sub + LPR * i));
+                    o.x += dr.x; o.y += dr.y; o.z += dr.z; o.w += dr.w;
+                }
+                if (dbranch) {
+                    const float sc = scale[row / rows_per_sample];
+                    *reinterpret_cast<float4 *>(dbranch + row * C + 4 * (sub + LPR * i)) = make_float4(o.x * sc, o.y * sc, o.z * sc, o.w * sc);
+                }
+            }
             *reinterpret_cast<float4 *>(dx + row * C + 4 * (sub + LPR * i)) = o;
         }
     }
@@ -193,7 +216,7 @@ extern "C" int mlagg_layernorm_fwd(const float *x, int x_stride, const float *ga
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(grid_blocks(rows, lpr)), block(BLOCK);
     MLAGG_TIMED(K_LAYERNORM_FWD, st);
-#define MLAGG_LN_FWD(LPR, F4) hipLaunchKernelGGL((layernorm_fwd_kernel<LPR, F4>), grid, block, 0, st, x, x_stride, gamma, beta, y, stats, rows, eps)
+#define MLAGG_LN_FWD(LPR, F4) hipLaunchKernelGGL((layernorm_fwd_kernel<LPR, F4, false>), grid, block, 0, st, x, x_stride, gamma, beta, y, stats, rows, eps, nullptr, nullptr, nullptr, 1)
     MLAGG_LN_DISPATCH(C, MLAGG_LN_FWD)
 #undef MLAGG_LN_FWD
     return (int)hipGetLastError();
@@ -212,11 +235,50 @@ extern "C" int mlagg_layernorm_bwd(const float *x, int x_stride, const float *dy
     const dim3 grid(nb), block(BLOCK);
     {
         MLAGG_TIMED(K_LAYERNORM_BWD, st);
-#define MLAGG_LN_BWD(LPR, F4) hipLaunchKernelGGL((layernorm_bwd_kernel<LPR, F4>), grid, block, 0, st, x, x_stride, dy, dy_stride, gamma, stats, dx, workspace, rows)
+#define MLAGG_LN_BWD(LPR, F4) hipLaunchKernelGGL((layernorm_bwd_kernel<LPR, F4, false>), grid, block, 0, st, x, x_stride, dy, dy_stride, gamma, stats, dx, workspace, rows, nullptr, nullptr, nullptr, 1)
         MLAGG_LN_DISPATCH(C, MLAGG_LN_BWD)
 #undef MLAGG_LN_BWD
     }
     // partial rows are [d(gamma) | d(beta)]: column sums of an (nb x 2C) matrix
+    hipLaunchKernelGGL(mlagg_internal::column_sum_split_kernel<0>, dim3((2 * C + 63) / 64), dim3(1024), 0, st, workspace, nb,
+                       2 * C, dbeta ? 2 * C : C, C, dgamma, dbeta);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mlagg_residual_layernorm_fwd(const float *skip, const float *branch, const float *scale, const float *gamma,
+                                            const float *beta, float *xsum, float *y, float *stats, int rows, int rows_per_sample,
+                                            int C, float eps, void *stream)
+{
+    if (!skip || !branch || !gamma || !xsum || !y) return MLAGG_E_NULLPTR;
+    const int lpr = lanes_per_row(C);
+    if (!lpr || rows <= 0 || rows_per_sample <= 0 || rows % rows_per_sample) return MLAGG_E_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(grid_blocks(rows, lpr)), block(BLOCK);
+    MLAGG_TIMED(K_LAYERNORM_FWD, st);
+#define MLAGG_LN_FWD(LPR, F4) hipLaunchKernelGGL((layernorm_fwd_kernel<LPR, F4, true>), grid, block, 0, st, skip, C, gamma, beta, y, stats, rows, eps, branch, scale, xsum, rows_per_sample)
+    MLAGG_LN_DISPATCH(C, MLAGG_LN_FWD)
+#undef MLAGG_LN_FWD
+    return (int)hipGetLastError();
+}
+
+extern "C" int mlagg_residual_layernorm_bwd(const float *xsum, const float *dy, int dy_stride, const float *dres, const float *scale,
+                                            const float *gamma, const float *stats, float *dskip, float *dbranch, float *dgamma,
+                                            float *dbeta, float *workspace, int rows, int rows_per_sample, int C, void *stream)
+{
+    if (!xsum || !dy || !gamma || !stats || !dskip || !dgamma || !workspace) return MLAGG_E_NULLPTR;
+    if ((scale == nullptr) != (dbranch == nullptr)) return MLAGG_E_NULLPTR;
+    const int lpr = lanes_per_row(C);
+    if (!lpr || rows <= 0 || rows_per_sample <= 0 || rows % rows_per_sample || dy_stride < C || (dy_stride & 3))
+        return MLAGG_E_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nb = grid_blocks(rows, lpr);
+    const dim3 grid(nb), block(BLOCK);
+    {
+        MLAGG_TIMED(K_LAYERNORM_BWD, st);
+#define MLAGG_LN_BWD(LPR, F4) hipLaunchKernelGGL((layernorm_bwd_kernel<LPR, F4, true>), grid, block, 0, st, xsum, C, dy, dy_stride, gamma, stats, dskip, workspace, rows, dres, scale, dbranch, rows_per_sample)
+        MLAGG_LN_DISPATCH(C, MLAGG_LN_BWD)
+#undef MLAGG_LN_BWD
+    }
     hipLaunchKernelGGL(mlagg_internal::column_sum_split_kernel<0>, dim3((2 * C + 63) / 64), dim3(1024), 0, st, workspace, nb,
                        2 * C, dbeta ? 2 * C : C, C, dgamma, dbeta);
     return (int)hipGetLastError();

@@ -85,6 +85,13 @@ class DropPath(nn.Module):
         m = self.scale_mask(x)
         return x if m is None else x * m.view((-1,) + (1,) * (x.dim() - 1))
 
+    def residual_norm(self, skip, branch, norm):
+        """(x, norm(x)) with x = skip + drop_path(branch): the junction and the LayerNorm that follows it in one K6 pass."""
+        if branch.is_cuda and ops.FUSED_RESIDUAL_NORM:
+            return ops.residual_layer_norm(skip, branch, self.scale_mask(branch), norm.weight, norm.bias, norm.eps)
+        x = self.residual(skip, branch)
+        return x, norm(x)
+
     def residual(self, skip, branch):
         """skip + drop_path(branch) in one pass (K8)."""
         m = self.scale_mask(branch)
@@ -93,6 +100,9 @@ class DropPath(nn.Module):
         if branch.is_cuda and (branch.numel() // branch.shape[0]) % 4 == 0:
             return ops.scaled_residual(skip, branch, m)
         return torch.addcmul(skip, branch, m.view((-1,) + (1,) * (branch.dim() - 1)))
+
+
+_NO_DROP = DropPath(0.0)
 
 
 class _ConvMixin:
@@ -275,17 +285,19 @@ class AggregatedAttention(nn.Module):
         b3 = torch.cat([self.q.bias, self.kv.bias[d:], self.sr.bias])
         qvs = ops.linear(x, w3, b3)
         q, v_full, s_pre = ops.split_cols(qvs, (d, d, d))
-        s = F.gelu(s_pre)
         if self.H % self.sr_ratio == 0 and self.W % self.sr_ratio == 0:
             r = self.sr_ratio
-            pooled = s.view(B, self.pool_H, r, self.pool_W, r, d).mean(dim=(2, 4)).reshape(B, -1, d)
+            if s_pre.is_cuda:
+                pooled = ops.gelu_pool(s_pre, self.H, self.W, r)             # K17: GELU + window mean, one pass
+            else:
+                pooled = F.gelu(s_pre).view(B, self.pool_H, r, self.pool_W, r, d).mean(dim=(2, 4)).reshape(B, -1, d)
         else:
-            img = s.view(B, self.H, self.W, d).permute(0, 3, 1, 2)
+            img = F.gelu(s_pre).view(B, self.H, self.W, d).permute(0, 3, 1, 2)
             pooled = F.adaptive_avg_pool2d(img, (self.pool_H, self.pool_W)).flatten(2).transpose(1, 2)
         k_pool, v_pool = self.kv(self.norm(pooled)).split([d, d], dim=-1)
         scale = self.scale if self.variant == "B" else self.scale * self.scale
         o = ops.pooled_diff_attn(q, k_pool, v_pool, lam, self.subln.weight, self.num_heads, scale)
-        return o + ops.dwconv3x3_nlc(v_full, self.lepe.weight, self.lepe.bias, self.H, self.W, silu=False)
+        return ops.dwconv3x3_nlc(v_full, self.lepe.weight, self.lepe.bias, self.H, self.W, silu=False, res=o)      # o + lepe(v), T:782
 
 
 class MLLABlock(nn.Module):
@@ -306,10 +318,14 @@ class MLLABlock(nn.Module):
         self.norm2 = LayerNorm(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
-    def forward_tokens(self, x):
+    def forward_tokens(self, x, xn=None, next_norm=None):
+        """x -> block(x).  ``xn``: norm1(x) when the caller already has it; ``next_norm``: the LayerNorm the caller applies to the
+        result next (norm1 of the following block) -- the block then returns (x_out, next_norm(x_out)), formed in the pass of its last
+        residual junction."""
         H, W = self.input_resolution
         C = self.dim
-        xn = self.norm1(x)
+        if xn is None:
+            xn = self.norm1(x)
         # act_proj and in_proj in ONE GEMM over stacked weights: (B, N, 2C) = [act | in]
         ai = ops.linear(xn, torch.cat([self.act_proj.weight, self.in_proj.weight]),
                         torch.cat([self.act_proj.bias, self.in_proj.bias]))
@@ -322,11 +338,12 @@ class MLLABlock(nn.Module):
         xa = ops.dwconv3x3_nlc(xa_in, wa, ba, H, W, silu=True)
         za = ops.dwconv3x3_nlc(za_in, wz, bz, H, W, silu=True)
         gated = ops.gate(self.attn[0](xa), self.attn[1](za), act_pre)       # K7: cat(.) * SiLU(act_proj(.))
-        dp = self.drop_path if isinstance(self.drop_path, DropPath) else None
-        y = self.out_proj(gated)
-        x = dp.residual(x, y) if dp is not None else x + y
-        y = self.mlp(self.norm2(x))
-        return dp.residual(x, y) if dp is not None else x + y
+        dp = self.drop_path if isinstance(self.drop_path, DropPath) else _NO_DROP
+        x, n2 = dp.residual_norm(x, self.out_proj(gated), self.norm2)
+        y = self.mlp(n2)
+        if next_norm is not None:
+            return dp.residual_norm(x, y, next_norm)
+        return dp.residual(x, y)
 
     def forward(self, x):
         B, C, h, w = x.shape
@@ -400,8 +417,12 @@ class BasicLayer(nn.Module):
         # (Keeping the convolutional parts in torch.channels_last, which would make both free views, was
         # measured 2x slower end to end: MIOpen's fp32 NHWC kernels and the NHWC Group/InstanceNorms.)
         t = _MapToTokens.apply(x)
-        for blk in self.blocks:
-            t = blk.forward_tokens(t)
+        tn = None
+        for i, blk in enumerate(self.blocks):
+            if i + 1 < len(self.blocks):
+                t, tn = blk.forward_tokens(t, tn, self.blocks[i + 1].norm1)
+            else:
+                t = blk.forward_tokens(t, tn)
         return _TokensToMap.apply(t, h, w)
 
 

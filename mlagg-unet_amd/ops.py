@@ -270,6 +270,7 @@ class SplitColsFn(torch.autograd.Function):
 
 
 GRAD_ARENA = _os.environ.get("MLAGG_GRAD_ARENA", "1") == "1"
+FUSED_RESIDUAL_NORM = _os.environ.get("MLAGG_FUSED_RESIDUAL_NORM", "1") == "1"
 
 
 def split_cols(t, sizes):
@@ -291,19 +292,24 @@ class DWConv3x3Fn(torch.autograd.Function):
     """K2: depthwise 3x3 (+bias, optional SiLU) on token-major maps."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, H, W, silu, slot=None):
+    def forward(ctx, x, weight, bias, H, W, silu, slot=None, res=None):
         ctx.slot = slot
         x, xs = _rows(x, "x")
         B, N, C = x.shape
         if N != H * W:
             raise RuntimeError(f"dwconv3x3: {N} tokens != {H}x{W}")
+        if res is not None:
+            if silu or tuple(res.shape) != (B, N, C):
+                raise RuntimeError("dwconv3x3: the residual is added to the plain convolution, same shape as the output")
+            res = _require(res.contiguous(), "res")
         w = _require(weight.reshape(C, 9).contiguous(), "weight")
         y = torch.empty(B, N, C, device=x.device, dtype=torch.float32)
         pre = torch.empty_like(y) if silu else None      # pre-activation, needed by SiLU's backward
-        _lib.check(_lib.lib().mlagg_dwconv3x3_fwd(_ptr(x), xs, _ptr(w), _ptr(bias), _ptr(y), C, _ptr(pre), B, H, W, C,
+        _lib.check(_lib.lib().mlagg_dwconv3x3_fwd(_ptr(x), xs, _ptr(w), _ptr(bias), _ptr(res), _ptr(y), C, _ptr(pre), B, H, W, C,
                                                   int(silu), _stream()), "mlagg_dwconv3x3_fwd")
         ctx.save_for_backward(x, w, pre)
         ctx.geom = (H, W, bool(silu), bias is not None, weight.shape)
+        ctx.has_res = res is not None
         return y
 
     @staticmethod
@@ -320,11 +326,12 @@ class DWConv3x3Fn(torch.autograd.Function):
         _lib.check(lib.mlagg_dwconv3x3_bwd(_ptr(x), x.stride(1), _ptr(w), _ptr(dy), dys, _ptr(pre), _ptr(dx), dxs,
                                            _ptr(dw), _ptr(db), _ptr(ws), B, H, W, C, int(silu), _stream()),
                    "mlagg_dwconv3x3_bwd")
-        return dx, dw.reshape(wshape), db, None, None, None, None
+        return dx, dw.reshape(wshape), db, None, None, None, None, (dy if ctx.has_res else None)
 
 
-def dwconv3x3_nlc(x, weight, bias, H, W, silu=False):
-    return DWConv3x3Fn.apply(x, weight, bias, H, W, silu, _claim(x))
+def dwconv3x3_nlc(x, weight, bias, H, W, silu=False, res=None):
+    """Depthwise 3x3 on a token-major map; `res` (same shape as the output) is added in the same pass."""
+    return DWConv3x3Fn.apply(x, weight, bias, H, W, silu, _claim(x), res)
 
 
 class DWConv3dFn(torch.autograd.Function):
@@ -750,6 +757,65 @@ def layer_norm(x, weight, bias, eps=1e-5):
     return torch.nn.functional.layer_norm(x, (x.shape[-1],), weight, bias, eps)
 
 
+class ResidualLayerNormFn(torch.autograd.Function):
+    """K6 with the residual junction in front: (xsum, y) = (skip + branch * scale[sample], LayerNorm(xsum)); backward adds the
+    gradient reaching xsum from its other consumers inside the LayerNorm-backward kernel (no separate add / scale kernels)."""
+
+    @staticmethod
+    def forward(ctx, skip, branch, scale, weight, bias, eps):
+        skip = _require(skip.contiguous(), "skip")
+        branch = _require(branch.contiguous(), "branch")
+        if skip.shape != branch.shape:
+            raise RuntimeError("residual_layer_norm: skip and branch differ in shape")
+        C = skip.shape[-1]
+        rows = skip.numel() // C
+        B = skip.shape[0]
+        if scale is not None:
+            scale = _require(scale.reshape(-1).contiguous(), "scale", (B,))
+        xsum = torch.empty_like(skip)
+        y = torch.empty_like(skip)
+        stats = torch.empty(rows, 2, device=skip.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mlagg_residual_layernorm_fwd(_ptr(skip), _ptr(branch), _ptr(scale), _ptr(weight), _ptr(bias), _ptr(xsum),
+                                                           _ptr(y), _ptr(stats), rows, rows // B, C, float(eps), _stream()),
+                   "mlagg_residual_layernorm_fwd")
+        ctx.save_for_backward(xsum, weight, stats, scale)
+        ctx.has_bias = bias is not None
+        return xsum, y
+
+    @staticmethod
+    def backward(ctx, dxsum, dy):
+        xsum, weight, stats, scale = ctx.saved_tensors
+        C = xsum.shape[-1]
+        rows = xsum.numel() // C
+        B = xsum.shape[0]
+        lib = _lib.lib()
+        if dy is None:                  # the norm's output went nowhere: a plain residual junction
+            dres = _require(dxsum.contiguous(), "dxsum")
+            dbranch = dres if scale is None else dres * scale.view((-1,) + (1,) * (dres.dim() - 1))
+            return dres, dbranch, None, torch.zeros_like(weight), (torch.zeros_like(weight) if ctx.has_bias else None), None
+        dy2, dys = _rows2d(dy, "dy")
+        if dys % 4 or dy2.data_ptr() % 16:
+            dy2 = dy2.contiguous()
+            dys = C
+        dres = None if dxsum is None else _require(dxsum.contiguous(), "dxsum")
+        dskip = torch.empty_like(xsum)
+        dbranch = torch.empty_like(xsum) if scale is not None else None
+        dg = torch.empty(C, device=dy.device, dtype=torch.float32)
+        db = torch.empty(C, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
+        ws = torch.empty(lib.mlagg_layernorm_bwd_workspace_floats(rows, C), device=dy.device, dtype=torch.float32)
+        _lib.check(lib.mlagg_residual_layernorm_bwd(_ptr(xsum), _ptr(dy2), dys, _ptr(dres), _ptr(scale), _ptr(weight), _ptr(stats),
+                                                    _ptr(dskip), _ptr(dbranch), _ptr(dg), _ptr(db), _ptr(ws), rows, rows // B, C,
+                                                    _stream()), "mlagg_residual_layernorm_bwd")
+        return dskip, (dskip if dbranch is None else dbranch), None, dg, db, None
+
+
+def residual_layer_norm(skip, branch, scale, weight, bias, eps=1e-5):
+    """(skip + branch * scale[sample], LayerNorm of that sum) in one pass each way; scale None: plain sum."""
+    if not _lib.lib().mlagg_layernorm_supported(int(skip.shape[-1])):
+        raise RuntimeError(f"residual_layer_norm: {skip.shape[-1]} channels are outside K6's row shapes")
+    return ResidualLayerNormFn.apply(skip, branch, scale, weight, bias, eps)
+
+
 class DWConv3x3NCHWFn(torch.autograd.Function):
     """K2n: depthwise 3x3 (stride 1 or 2, padding 1) + bias on NCHW maps."""
 
@@ -1073,6 +1139,38 @@ def gate(a0, a1, act):
     return GateFn.apply(a0, a1, act, _claim(act))
 
 
+class GeluPoolFn(torch.autograd.Function):
+    """K17: r x r window mean of GELU(s) on a token-major map (the pooled branch's key / value reduction, T:722)."""
+
+    @staticmethod
+    def forward(ctx, s, H, W, r, slot=None):
+        ctx.slot = slot
+        s, ss = _rows(s, "s")
+        B, N, d = s.shape
+        if N != H * W or H % r or W % r:
+            raise RuntimeError(f"gelu_pool: {N} tokens, map {H}x{W}, window {r}")
+        pooled = torch.empty(B, (H // r) * (W // r), d, device=s.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mlagg_gelu_pool_fwd(_ptr(s), ss, _ptr(pooled), B, H, W, d, r, _stream()), "mlagg_gelu_pool_fwd")
+        ctx.save_for_backward(s)
+        ctx.geom = (H, W, r)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        (s,) = ctx.saved_tensors
+        H, W, r = ctx.geom
+        B, N, d = s.shape
+        dp = _require(dpooled.contiguous(), "dpooled")
+        ds, dss = _grad_out(ctx.slot, (B, N, d), s.device)
+        _lib.check(_lib.lib().mlagg_gelu_pool_bwd(_ptr(s), s.stride(1), _ptr(dp), _ptr(ds), dss, B, H, W, d, r, _stream()),
+                   "mlagg_gelu_pool_bwd")
+        return ds, None, None, None, None
+
+
+def gelu_pool(s, H, W, r):
+    return GeluPoolFn.apply(s, H, W, r, _claim(s))
+
+
 class DiffLambdaFn(torch.autograd.Function):
     """K8: lambda = exp(<q1, k1>) - exp(<q2, k2>) + lambda_init of the differential attention, one launch each way."""
 
@@ -1295,7 +1393,10 @@ def column_sum(x2):
     _require(x2, "x")
     rows, cols = x2.shape
     out = torch.empty(cols, device=x2.device, dtype=torch.float32)
-    _lib.check(_lib.lib().mlagg_column_sum(_ptr(x2), x2.stride(0), _ptr(out), rows, cols, _stream()), "mlagg_column_sum")
+    lib = _lib.lib()
+    n = lib.mlagg_column_sum_workspace_floats(rows, cols)
+    ws = torch.empty(n, device=x2.device, dtype=torch.float32) if n else None
+    _lib.check(lib.mlagg_column_sum(_ptr(x2), x2.stride(0), _ptr(out), _ptr(ws), rows, cols, _stream()), "mlagg_column_sum")
     return out
 
 

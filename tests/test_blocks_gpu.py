@@ -51,6 +51,50 @@ def test_dwconv3x3_matches_conv2d(C, H, W, silu):
     _close(bg.grad, br.grad, 1e-5, 1e-4, "db")
 
 
+@gpu
+def test_dwconv3x3_adds_the_residual_in_the_same_pass():
+    """res of ops.dwconv3x3_nlc (x + lepe(v), T:782): output and all four gradients equal conv + add."""
+    from mlagg_unet_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, H, W, C = 2, 9, 12, 96
+    x, r = torch.randn(B, H * W, C, generator=g).to(DEV), torch.randn(B, H * W, C, generator=g).to(DEV)
+    w, b = (torch.randn(C, 1, 3, 3, generator=g) * 0.3).to(DEV), (torch.randn(C, generator=g) * 0.1).to(DEV)
+    gy = torch.randn(B, H * W, C, generator=g).to(DEV)
+    outs = []
+    for fused in (True, False):
+        xs, rs, ws, bs = [t.clone().requires_grad_(True) for t in (x, r, w, b)]
+        y = ops.dwconv3x3_nlc(xs, ws, bs, H, W, silu=False, res=rs) if fused else rs + ops.dwconv3x3_nlc(xs, ws, bs, H, W, silu=False)
+        y.backward(gy)
+        outs.append((y, xs.grad, rs.grad, ws.grad, bs.grad))
+    for a, bb in zip(*outs):
+        _close(a, bb, 1e-6, 1e-6)
+    with pytest.raises(RuntimeError):
+        ops.dwconv3x3_nlc(x, w, b, H, W, silu=True, res=r)
+
+
+@gpu
+@pytest.mark.parametrize("H,W,d,r", [(16, 16, 48, 8), (8, 12, 96, 4), (6, 10, 192, 2), (4, 4, 384, 1)])
+def test_gelu_pool_matches_torch(H, W, d, r):
+    """K17 against nn.GELU + nn.AdaptiveAvgPool2d (T:722) in float64, on a column block of a wider row (as in the model)."""
+    from mlagg_unet_amd import ops
+    g = torch.Generator().manual_seed(H * W + d)
+    B = 3
+    wide = torch.randn(B, H * W, 3 * d, generator=g) * 2.0
+    gy = torch.randn(B, (H // r) * (W // r), d, generator=g)
+    ref_in = wide[..., 2 * d:].double().requires_grad_(True)
+    img = F.gelu(ref_in).view(B, H, W, d).permute(0, 3, 1, 2)
+    ref = torch.nn.AdaptiveAvgPool2d((H // r, W // r))(img).flatten(2).transpose(1, 2)
+    ref.backward(gy.double())
+    wg = wide.to(DEV).requires_grad_(True)
+    out = ops.gelu_pool((wg * 1.0)[..., 2 * d:], H, W, r)
+    out.backward(gy.to(DEV))
+    _close(out, ref.float(), 2e-6, 1e-5, "pooled")
+    _close(wg.grad[..., 2 * d:], ref_in.grad.float(), 2e-6, 1e-5, "ds")
+    assert float(wg.grad[..., :2 * d].abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        ops.gelu_pool(wg[..., 2 * d:], H, W, r + 7)
+
+
 def _attn_pair(local, dim, res, nh, sr, variant, seed):
     from mlagg_unet_amd import model as PM
     torch.manual_seed(seed)
@@ -380,6 +424,9 @@ def test_channel_bias_and_column_sum(shape):
     assert float((ops.column_sum(m) - m.sum(0)).abs().max()) < 1e-4
     wide = torch.randn(100, 3 * C, generator=g).to(DEV)
     assert float((ops.column_sum(wide[:, C:2 * C]) - wide[:, C:2 * C].sum(0)).abs().max()) < 1e-4
+    tall = torch.randn(7840 + C, 3 * C, generator=g).to(DEV)         # row slabs + a second launch (ragged last slab)
+    got, want = ops.column_sum(tall[:, C:2 * C]), tall[:, C:2 * C].double().sum(0)
+    assert float((got.double() - want).abs().max()) < 2e-3 and torch.equal(got, ops.column_sum(tall[:, C:2 * C]))
 
 
 @gpu
@@ -746,3 +793,29 @@ def test_split_cols_gradient_buffer_equals_concatenated_gradients():
     g_plain = run(lambda t, sizes: t.split(list(sizes), dim=-1))
     assert torch.equal(g_arena, g_plain)
     assert float(g_arena[..., 2 * C:].abs().max()) == 0.0
+
+
+@gpu
+@pytest.mark.parametrize("C,N,with_scale,use_sum", [(96, 60, True, True), (192, 33, False, True), (768, 7, True, False), (48, 128, False, False)])
+def test_residual_layer_norm_matches_torch(C, N, with_scale, use_sum):
+    """ops.residual_layer_norm = (skip + branch * scale[sample], LayerNorm of it); every gradient against float64 torch, with and
+    without a second consumer of the sum."""
+    from mlagg_unet_amd import ops
+    g = torch.Generator().manual_seed(C + N)
+    B = 3
+    skip, branch = torch.randn(B, N, C, generator=g), torch.randn(B, N, C, generator=g)
+    scale = torch.tensor([0.0, 1.25, 1.25]) if with_scale else None
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    gy, gx = torch.randn(B, N, C, generator=g), torch.randn(B, N, C, generator=g)
+    rs, rb, rw, rbias = [t.double().requires_grad_(True) for t in (skip, branch, w, b)]
+    xs = rs + (rb * scale.double().view(-1, 1, 1) if with_scale else rb)
+    yr = F.layer_norm(xs, (C,), rw, rbias, 1e-5)
+    ((yr * gy.double()).sum() + ((xs * gx.double()).sum() if use_sum else 0.0)).backward()
+    ps, pb, pw, pbias = [t.to(DEV).requires_grad_(True) for t in (skip, branch, w, b)]
+    xp, yp = ops.residual_layer_norm(ps, pb, None if scale is None else scale.to(DEV), pw, pbias, 1e-5)
+    ((yp * gy.to(DEV)).sum() + ((xp * gx.to(DEV)).sum() if use_sum else 0.0)).backward()
+    _close(xp, xs.float(), 1e-6, 1e-6, "xsum")
+    _close(yp, yr.float(), 2e-6, 1e-5, "y")
+    for name, got, want in (("dskip", ps.grad, rs.grad), ("dbranch", pb.grad, rb.grad), ("dgamma", pw.grad, rw.grad),
+                            ("dbeta", pbias.grad, rbias.grad)):
+        _close(got, want.float(), 5e-6, 1e-4, name)
