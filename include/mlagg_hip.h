@@ -29,6 +29,7 @@ extern "C" {
 #define MLAGG_DTYPE_F32  0
 #define MLAGG_DTYPE_BF16 1
 #define MLAGG_DTYPE_F16  2
+#define MLAGG_DTYPE_BF16X3 3 /* GEMM arithmetic only: fp32 operands as three bf16 pieces each, six partial products (fp32-accurate) */
 
 const char *mlagg_version(void);
 const char *mlagg_error_string(int code);
@@ -167,7 +168,9 @@ int mlagg_linear_dgrad(const float *dy, int dy_stride, const float *w, float *dx
 /* Mixed precision: the same two products with the operands rounded to bf16 / fp16 (dtype = MLAGG_DTYPE_BF16 / _F16) on
  * their way into the matrix cores and fp32 accumulation -- what torch.autocast makes of nn.Linear in the reference's
  * default train step (mlagg/nnunetv2/training/nnUNetTrainer/nnUNetTrainer.py:848-851; fp16 + GradScaler :152, bf16 in
- * BASELINE configs[2]).  x, w, y / dy, dx stay fp32 in memory, same layouts and strides as above. */
+ * BASELINE configs[2]).  x, w, y / dy, dx stay fp32 in memory, same layouts and strides as above.
+ * dtype = MLAGG_DTYPE_BF16X3: the fp32 layers on the 16-bit matrix instructions -- each fp32 operand as three bf16 pieces, six
+ * partial products accumulated in fp32 (error 2^-24 of a product: as accurate as the fp32 instruction, 2.7x its rate). */
 int mlagg_linear_lp_fwd(const float *x, int x_stride, const float *w, const float *bias, float *y, int y_stride,
                         int M, int N, int K, int dtype, void *stream);
 int mlagg_linear_lp_dgrad(const float *dy, int dy_stride, const float *w, float *dx, int dx_stride, int M, int O, int I,

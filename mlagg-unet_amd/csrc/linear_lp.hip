@@ -8,6 +8,14 @@
 // OUTPUT to 16 bits, which this path does not do.  With the matrix pipe 16x faster the kernel is a pure stream of
 // x and y rows: HBM-bound by 4 (K + N) bytes per token.
 //
+// MODE 2 (MLAGG_DTYPE_BF16X3) is the fp32 layers' form of the same kernel: every fp32 operand is split on its way into LDS into three
+// bf16 pieces x = hi + mid + lo (8 + 8 + 8 significand bits: the split is exact up to 2^-24 |x|), and the product is the six
+// partial products whose weight is >= 2^-16: hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi -- each bf16 x bf16 product is exact in
+// fp32, the matrix core accumulates in fp32.  The dropped terms (mid.lo, lo.mid, lo.lo) are 2^-24 of the product, below the
+// rounding of an fp32 FMA chain: against float64 the result is as close as rocBLAS's / K5's fp32 GEMM (tests/test_blocks_gpu.py
+// holds both to the same bound).  Six 32x32x16 bf16 MFMAs replace the eight 32x32x2 f32 MFMAs of a 16-deep k block at 1/16 of
+// their cost each: the matrix-pipe time of K5 drops 2.7x, and the fp32 projections stop being matrix-bound.
+//
 // Tiling (wave64): workgroup = 4 waves, output tile 128 rows x 96 columns, one wave per 32 rows, 3 MFMA column tiles
 // per wave (48 accumulator VGPRs); K in chunks of 32: A tile [128][32] and B tile [96][32] as 16-bit, k contiguous,
 // row pitch 80 bytes (the 16-byte operand fetch of 16 consecutive rows then covers 64 distinct banks).  A lane's MFMA
@@ -53,13 +61,25 @@ __device__ __forceinline__ f32x16 mfma16(const uint4 &a, const uint4 &b, f32x16 
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(&a), *reinterpret_cast<const f16x8 *>(&b), c, 0, 0, 0);
 }
 
-template <bool W_NK, bool BF16>
+// x = hi + mid + lo in bf16 (round to nearest at every level); two values per call, packed like pack2
+__device__ __forceinline__ void split3(float a, float b, unsigned &hi, unsigned &mid, unsigned &lo)
+{
+    hi = pack2<true>(a, b);
+    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+    mid = pack2<true>(ra, rb);
+    lo = pack2<true>(ra - __uint_as_float(mid << 16), rb - __uint_as_float(mid & 0xffff0000u));
+}
+
+// MODE: 0 fp16, 1 bf16 (operands rounded once: the 16-bit modes), 2 bf16 x 3 (fp32-accurate, see the header)
+template <bool W_NK, int MODE>
 __global__ void __launch_bounds__(256)
 linear_lp_kernel(const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias,
                  float *__restrict__ Y, LGeom g)
 {
-    __shared__ unsigned short sA[BM * PITCH];
-    __shared__ unsigned short sB[BN * PITCH];
+    constexpr bool BF16 = MODE != 0;
+    constexpr int NP = MODE == 2 ? 3 : 1;                   // operand images per tile
+    __shared__ unsigned short sA[NP * BM * PITCH];
+    __shared__ unsigned short sB[NP * BN * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, kh = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -86,19 +106,18 @@ linear_lp_kernel(const float *__restrict__ X, const float *__restrict__ W, const
                 const int n = n0 + (idx >> 3), k = kc + 4 * (idx & 7);
                 rb[i] = (n < g.N && k < g.K) ? *reinterpret_cast<const float4 *>(W + (size_t)n * g.w_stride + k)
                                              : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {                                        // W[k][n]: 32 rows x 24 float4 along n
-                const int k = kc + idx / 24, n = n0 + 4 * (idx % 24);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < g.K) {
-                    const float *p = W + (size_t)k * g.w_stride + n;
-                    if (n + 3 < g.N) v = *reinterpret_cast<const float4 *>(p);
-                    else {
-                        if (n < g.N) v.x = p[0];
-                        if (n + 1 < g.N) v.y = p[1];
-                        if (n + 2 < g.N) v.z = p[2];
-                    }
-                }
-                rb[i] = v;
+            } else {
+                // W[k][n]: the image wanted in LDS is [n][k] with k contiguous, so a lane takes FOUR k of ONE column n (4 scalar
+                // loads, each coalesced across the lanes' consecutive n) and writes them as one 8-byte LDS store, like the W_NK
+                // case -- a float4 along n would have to be scattered as four 2-byte stores per operand image
+                const int n = n0 + idx % BN, k = kc + 4 * (idx / BN);
+                const int nn = min(n, g.N - 1);             // clamped, unconditional loads; the value is dropped below
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = W[(size_t)min(k + j, g.K - 1) * g.w_stride + nn];
+                const bool nok = n < g.N;
+                rb[i] = make_float4(nok && k < g.K ? e[0] : 0.f, nok && k + 1 < g.K ? e[1] : 0.f, nok && k + 2 < g.K ? e[2] : 0.f,
+                                    nok && k + 3 < g.K ? e[3] : 0.f);
             }
         }
     };
@@ -106,19 +125,34 @@ linear_lp_kernel(const float *__restrict__ X, const float *__restrict__ W, const
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             unsigned short *d = sA + ((tid >> 3) + 32 * i) * PITCH + 4 * (tid & 7);
-            *reinterpret_cast<uint2 *>(d) = make_uint2(pack2<BF16>(ra[i].x, ra[i].y), pack2<BF16>(ra[i].z, ra[i].w));
+            if (MODE == 2) {
+                unsigned h0, m0_, l0, h1, m1, l1;
+                split3(ra[i].x, ra[i].y, h0, m0_, l0);
+                split3(ra[i].z, ra[i].w, h1, m1, l1);
+                *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2 *>(d + BM * PITCH) = make_uint2(m0_, m1);
+                *reinterpret_cast<uint2 *>(d + 2 * BM * PITCH) = make_uint2(l0, l1);
+            } else {
+                *reinterpret_cast<uint2 *>(d) = make_uint2(pack2<BF16>(ra[i].x, ra[i].y), pack2<BF16>(ra[i].z, ra[i].w));
+            }
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int idx = tid + 256 * i;
-            if (W_NK) {                                     // rows n, k contiguous: as loaded
-                unsigned short *d = sB + (idx >> 3) * PITCH + 4 * (idx & 7);
-                *reinterpret_cast<uint2 *>(d) = make_uint2(pack2<BF16>(rb[i].x, rb[i].y), pack2<BF16>(rb[i].z, rb[i].w));
-            } else {                                        // loaded along n: scatter into the [n][k] image
-                const unsigned lo = pack2<BF16>(rb[i].x, rb[i].y), hi = pack2<BF16>(rb[i].z, rb[i].w);
-                unsigned short *d = sB + (4 * (idx % 24)) * PITCH + idx / 24;
-                d[0] = (unsigned short)(lo & 0xffff); d[PITCH] = (unsigned short)(lo >> 16);
-                d[2 * PITCH] = (unsigned short)(hi & 0xffff); d[3 * PITCH] = (unsigned short)(hi >> 16);
+            unsigned pl[NP], ph[NP];                        // per image: values (x, y) and (z, w) of the float4
+            if (MODE == 2) {
+                split3(rb[i].x, rb[i].y, pl[0], pl[NP > 1 ? 1 : 0], pl[NP > 2 ? 2 : 0]);
+                split3(rb[i].z, rb[i].w, ph[0], ph[NP > 1 ? 1 : 0], ph[NP > 2 ? 2 : 0]);
+            } else {
+                pl[0] = pack2<BF16>(rb[i].x, rb[i].y);
+                ph[0] = pack2<BF16>(rb[i].z, rb[i].w);
+            }
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                // rows n, k contiguous (W_NK: as loaded; otherwise the lane's four k of column idx % BN)
+                unsigned short *d = W_NK ? sB + q * BN * PITCH + (idx >> 3) * PITCH + 4 * (idx & 7)
+                                         : sB + q * BN * PITCH + (idx % BN) * PITCH + 4 * (idx / BN);
+                *reinterpret_cast<uint2 *>(d) = make_uint2(pl[q], ph[q]);
             }
         }
     };
@@ -132,11 +166,26 @@ linear_lp_kernel(const float *__restrict__ X, const float *__restrict__ W, const
 #pragma unroll
         for (int p = 0; p < KC / 16; ++p) {
             // lane (col, kh): row 32 wave + col of A / column 32 t + col of B, k = 16 p + 8 kh .. + 8
-            const uint4 a = *reinterpret_cast<const uint4 *>(sA + (32 * wave + col) * PITCH + 16 * p + 8 * kh);
+            uint4 a[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                a[q] = *reinterpret_cast<const uint4 *>(sA + q * BM * PITCH + (32 * wave + col) * PITCH + 16 * p + 8 * kh);
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
-                const uint4 b = *reinterpret_cast<const uint4 *>(sB + (32 * t + col) * PITCH + 16 * p + 8 * kh);
-                acc[t] = mfma16<BF16>(a, b, acc[t]);
+                uint4 b[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    b[q] = *reinterpret_cast<const uint4 *>(sB + q * BN * PITCH + (32 * t + col) * PITCH + 16 * p + 8 * kh);
+                if (MODE == 2) {                             // smallest terms first
+                    acc[t] = mfma16<true>(a[NP - 1], b[0], acc[t]);          // lo . hi
+                    acc[t] = mfma16<true>(a[0], b[NP - 1], acc[t]);          // hi . lo
+                    acc[t] = mfma16<true>(a[NP > 1 ? 1 : 0], b[NP > 1 ? 1 : 0], acc[t]);      // mid . mid
+                    acc[t] = mfma16<true>(a[NP > 1 ? 1 : 0], b[0], acc[t]);  // mid . hi
+                    acc[t] = mfma16<true>(a[0], b[NP > 1 ? 1 : 0], acc[t]);  // hi . mid
+                    acc[t] = mfma16<true>(a[0], b[0], acc[t]);               // hi . hi
+                } else {
+                    acc[t] = mfma16<BF16>(a[0], b[0], acc[t]);
+                }
             }
         }
     }
@@ -180,9 +229,11 @@ int launch(const float *x, const float *w, const float *bias, float *y, const LG
 {
     const dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN), block(256);
     if (dtype == MLAGG_DTYPE_BF16)
-        hipLaunchKernelGGL((linear_lp_kernel<W_NK, true>), grid, block, 0, st, x, w, bias, y, g);
+        hipLaunchKernelGGL((linear_lp_kernel<W_NK, 1>), grid, block, 0, st, x, w, bias, y, g);
     else if (dtype == MLAGG_DTYPE_F16)
-        hipLaunchKernelGGL((linear_lp_kernel<W_NK, false>), grid, block, 0, st, x, w, bias, y, g);
+        hipLaunchKernelGGL((linear_lp_kernel<W_NK, 0>), grid, block, 0, st, x, w, bias, y, g);
+    else if (dtype == MLAGG_DTYPE_BF16X3)
+        hipLaunchKernelGGL((linear_lp_kernel<W_NK, 2>), grid, block, 0, st, x, w, bias, y, g);
     else
         return MLAGG_E_UNSUPPORTED;
     return (int)hipGetLastError();

@@ -616,6 +616,11 @@ def pooled_diff_attn(q, k_pool, v_pool, lam, subln_w, nh, scale):
     return PooledDiffAttnFn.apply(q, k_pool, v_pool, lam, subln_w, nh, scale, _claim(q))
 
 
+# fp32 projections on the 16-bit matrix instructions (csrc/linear_lp.hip MODE 2: each fp32 operand as three bf16 pieces, six partial
+# products, fp32 accumulation -- as accurate against float64 as the fp32 instruction, tools/bench_linear.py).  MLAGG_K5_X3=0: K5 on
+# v_mfma_f32_32x32x2_f32.
+K5_X3 = _os.environ.get("MLAGG_K5_X3", "1") == "1"
+_DTYPE_BF16X3 = 3
 WGRAD_MIN_ROWS = 8192      # below this many tokens the library GEMM is no longer the split-K corner case
 K5_MIN_ROWS = int(_os.environ.get("MLAGG_K5_MIN_ROWS", "16384"))     # fp32 forward / dx: K5 from this many tokens on (at 10240 tokens the
 #                            library's split-K kernels win: 80-320 K5 workgroups do not fill 256 CUs evenly; A/B on the step: +0.9 %)
@@ -655,7 +660,10 @@ class LinearFn(torch.autograd.Function):
             x2, xs = _mfma_rows(x, "x")
             w = _require(weight.contiguous(), "weight")
             y = torch.empty(x.shape[:-1] + (O,), device=x.device, dtype=torch.float32)
-            if cdt == torch.float32:
+            if cdt == torch.float32 and K5_X3:
+                _lib.check(_lib.lib().mlagg_linear_lp_fwd(_ptr(x2), xs, _ptr(w), _ptr(bias), _ptr(y), O, M, O, I, _DTYPE_BF16X3,
+                                                          _stream()), "mlagg_linear_lp_fwd")
+            elif cdt == torch.float32:
                 _lib.check(_lib.lib().mlagg_linear_fwd(_ptr(x2), xs, _ptr(w), _ptr(bias), _ptr(y), O, M, O, I, _stream()),
                            "mlagg_linear_fwd")
             else:
@@ -680,7 +688,13 @@ class LinearFn(torch.autograd.Function):
             if big and (M >= K5_MIN_ROWS or cdt != torch.float32) and O % 4 == 0 and I % 4 == 0:
                 w = _require(weight.contiguous(), "weight")
                 dx = torch.empty(x.shape, device=dy.device, dtype=torch.float32)
-                if cdt == torch.float32:
+                if cdt == torch.float32 and K5_X3:
+                    # dx = dy . W as the forward form of the kernel on W^T (I, O): its weight tile is then read along the
+                    # contraction, the fast staging path (the transpose is a (O, I) copy of a few hundred KB)
+                    wt = transpose_2d(w.unsqueeze(0))[0]
+                    _lib.check(lib.mlagg_linear_lp_fwd(_ptr(dy2), dys, _ptr(wt), None, _ptr(dx), I, M, I, O, _DTYPE_BF16X3, _stream()),
+                               "mlagg_linear_lp_fwd")
+                elif cdt == torch.float32:
                     _lib.check(lib.mlagg_linear_dgrad(_ptr(dy2), dys, _ptr(w), _ptr(dx), I, M, O, I, _stream()),
                                "mlagg_linear_dgrad")
                 else:

@@ -819,3 +819,32 @@ def test_residual_layer_norm_matches_torch(C, N, with_scale, use_sum):
     for name, got, want in (("dskip", ps.grad, rs.grad), ("dbranch", pb.grad, rb.grad), ("dgamma", pw.grad, rw.grad),
                             ("dbeta", pbias.grad, rbias.grad)):
         _close(got, want.float(), 5e-6, 1e-4, name)
+
+
+@gpu
+@pytest.mark.parametrize("M,N,K", [(16384, 192, 96), (20000, 140, 96), (16500, 96, 140), (16384, 48, 1536), (130, 100, 52)])
+def test_linear_bf16x3_is_as_accurate_as_the_fp32_instruction(M, N, K):
+    """K5 on the 16-bit matrix instructions (MLAGG_DTYPE_BF16X3: fp32 operands as three bf16 pieces, six partial products): forward
+    and, on the transposed weight, the data gradient -- against float64, with the error bound of the fp32-MFMA kernel (and within
+    1.5x of the error that kernel makes on the same inputs).  Ragged M, N and a K that is not a multiple of the 16-deep instruction."""
+    from mlagg_unet_amd import _lib
+    lib = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).to(DEV)        # rows of very different scale
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    y3, y1 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    _lib.check(lib.mlagg_linear_lp_fwd(x.data_ptr(), K, w.data_ptr(), b.data_ptr(), y3.data_ptr(), N, M, N, K, 3, st), "x3")
+    _lib.check(lib.mlagg_linear_fwd(x.data_ptr(), K, w.data_ptr(), b.data_ptr(), y1.data_ptr(), N, M, N, K, st), "fp32")
+    ref = torch.addmm(b.double(), x.double(), w.double().t())
+    scale = ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)             # per row: the rows differ by orders of magnitude
+    e3, e1 = float(((y3.double() - ref).abs() / scale).max()), float(((y1.double() - ref).abs() / scale).max())
+    assert e3 < 3e-6 and e3 < 1.5 * e1 + 1e-7, (e3, e1)
+    from mlagg_unet_amd import ops
+    assert ops.K5_X3
+    xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    gy = torch.randn(M, N, generator=g).to(DEV)
+    ops.LinearFn.apply(xg, wg, b).backward(gy)                # M >= 16384: x3 forward and x3 data gradient on W^T; else the library
+    dref = gy.double() @ w.double()
+    assert float((xg.grad.double() - dref).abs().max() / dref.abs().max()) < 3e-6

@@ -36,8 +36,9 @@ def main():
     lib = _lib.lib()
     st = torch.cuda.current_stream().cuda_stream
     p = lambda t: t.data_ptr()
-    print(f"{'shape':34s} {'fwd us':>8s} {'TF/s':>6s} {'blas':>7s} | {'dgrad':>7s} {'TF/s':>6s} {'blas':>7s} | {'wgrad':>7s} {'TF/s':>6s} {'blas':>7s}")
-    tot = [0.0] * 6
+    print(f"{'shape':34s} {'fwd us':>8s} {'TF/s':>6s} {'blas':>7s} {'x3':>7s} {'TF/s':>6s} | {'dgrad':>7s} {'TF/s':>6s} {'blas':>7s} {'x3':>7s} | {'wgrad':>7s} {'TF/s':>6s} {'blas':>7s}"
+          "   max |err| vs float64 / max |y|: K5, x3, blas (fwd)")
+    tot = [0.0] * 8
     only = os.environ.get("MLAGG_BENCH_ONLY")
     for M, K, N, where in SHAPES:
         if only and only not in where:
@@ -55,17 +56,26 @@ def main():
         if not os.environ.get("MLAGG_K5_DEBUG"):
             assert float((y - torch.addmm(b, x, w.t())).abs().max()) < 1e-2 * K ** 0.5
         fb = timeit(lambda: torch.addmm(b, x, w.t()))
+        # the same product with the fp32 operands as three bf16 pieces each (MLAGG_DTYPE_BF16X3 = 3)
+        y3 = torch.empty_like(y)
+        f3 = timeit(lambda: _lib.check(lib.mlagg_linear_lp_fwd(p(x), K, p(w), p(b), p(y3), N, M, N, K, 3, st), "fwd x3"))
+        rows = slice(0, 4096)
+        ref = torch.addmm(b.double(), x[rows].double(), w.double().t())
+        errs = [float((t[rows].double() - ref).abs().max() / ref.abs().max()) for t in (y, y3, torch.addmm(b, x, w.t()))]
         d = timeit(lambda: _lib.check(lib.mlagg_linear_dgrad(p(dy), N, p(w), p(dx), K, M, N, K, st), "dgrad"))
         if not os.environ.get("MLAGG_K5_DEBUG"):
             assert float((dx - dy @ w).abs().max()) < 1e-2 * N ** 0.5
         dbl = timeit(lambda: torch.mm(dy, w))
+        dx3 = torch.empty_like(dx)
+        d3 = timeit(lambda: _lib.check(lib.mlagg_linear_lp_dgrad(p(dy), N, p(w), p(dx3), K, M, N, K, 3, st), "dgrad x3"))
+        assert float((dx3 - dx).abs().max()) < 1e-4 * N ** 0.5
         g = timeit(lambda: _lib.check(lib.mlagg_linear_wgrad(p(dy), N, p(x), K, p(dW), p(db), p(ws), M, N, K, st), "wgrad"))
         gb = timeit(lambda: (torch.mm(dy.t(), x), dy.sum(0)))
-        for i, v in enumerate((f, fb, d, dbl, g, gb)):
+        for i, v in enumerate((f, fb, d, dbl, g, gb, f3, d3)):
             tot[i] += v
-        print(f"{str((M, K, N)) + ' ' + where:34s} {f:8.1f} {fl / f / 1e6:6.1f} {fb:7.1f} | {d:7.1f} {fl / d / 1e6:6.1f} {dbl:7.1f} | "
-              f"{g:7.1f} {fl / g / 1e6:6.1f} {gb:7.1f}", flush=True)
-    print("totals us: fwd %.0f (blas %.0f)  dgrad %.0f (blas %.0f)  wgrad %.0f (blas %.0f)" % tuple(tot))
+        print(f"{str((M, K, N)) + ' ' + where:34s} {f:8.1f} {fl / f / 1e6:6.1f} {fb:7.1f} {f3:7.1f} {fl / f3 / 1e6:6.1f} | {d:7.1f} {fl / d / 1e6:6.1f} {dbl:7.1f} {d3:7.1f} | "
+              f"{g:7.1f} {fl / g / 1e6:6.1f} {gb:7.1f}   {errs[0]:.1e} {errs[1]:.1e} {errs[2]:.1e}", flush=True)
+    print("totals us: fwd %.0f (blas %.0f)  dgrad %.0f (blas %.0f)  wgrad %.0f (blas %.0f)  x3: fwd %.0f dgrad %.0f" % tuple(tot))
 
 
 if __name__ == "__main__":

@@ -19,6 +19,7 @@ def family(n):
         return "GEMM (rocBLAS/hipBLASLt)"
     for key, lab in (("linear_lp", "HIP K5 projections (fwd, dx), 16-bit operands"), ("selscan", "HIP K1 selective scan"), ("sel1_", "HIP K1s one-state selective scan (3-D)"),
                      ("conv_taps_kernel", "HIP K16 convolution forward / data gradient (tap GEMM)"),
+                     ("dwconv", "HIP K2 depthwise conv"), ("gelu_pool", "HIP K17 GELU + window mean"),
                      ("conv_wgrad_", "HIP K15 convolution weight gradient (tap GEMM)"), ("volume_pad_kernel", "HIP K15/K16 padded copies"),
                      ("guard_zero_kernel", "HIP K15/K16 padded copies"), ("pooled_lp_", "HIP K4lp pooled diff-attention (16-bit MFMA)"),
                      ("plane_split_", "HIP K10 plane norm + activation"), ("channel_epilogue", "HIP K13 convolution epilogue"),
@@ -56,6 +57,7 @@ def main():
     ap.add_argument("trace")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--aten", action="store_true", help="append every at::native / MIOpen helper kernel of the step (the library tail)")
     ap.add_argument("--mark", default=r"selscan_bwd_(group_)?kernel",
                     help="regex of the kernel dispatched exactly once per step (3-D network: 'sel1_bwd_kernel<2>')")
     a = ap.parse_args()
@@ -85,6 +87,19 @@ def main():
         name = re.sub(r"\s+", " ", k)[:110]
         print(f"| `{name}` | {len(v) / a.steps:.1f} | {sum(v) / len(v):.1f} | {min(v):.1f} | {max(v):.1f} | "
               f"{sum(v) / 1e3 / a.steps:.3f} |")
+    if a.aten:
+        print("\n## Library tail (at::native kernels and MIOpen's helper kernels), every kernel\n")
+        print("| kernel | calls / step | avg us | ms / step |\n|---|---|---|---|")
+        tot = 0.0
+        for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            if not re.search(r"at::native|at::cuda|SubTensorOp|batched_transpose", k):
+                continue
+            m = re.search(r"(\w+Functor\w*|\w+_kernel_cuda|\w+KernelImpl|CatArrayBatchedCopy\w*|reduce_kernel|SubTensorOp\w*|batched_transpose\w*"
+                          r"|MeanOps|sum_functor|bernoulli\w*|uniform\w*|where_kernel\w*|clamp\w*|compare\w*)", k)
+            lab = (m.group(1) if m else k[:60]) + (" [strided]" if "elementwise_kernel_manual_unroll" in k or "unrolled_elementwise" in k else "")
+            tot += sum(v) / 1e3 / a.steps
+            print(f"| `{lab}` | {len(v) / a.steps:.1f} | {sum(v) / len(v):.1f} | {sum(v) / 1e3 / a.steps:.3f} |")
+        print(f"\ntotal: {tot:.2f} ms / step")
 
 
 if __name__ == "__main__":
