@@ -178,6 +178,10 @@ int mlagg_linear_lp_dgrad(const float *dy, int dy_stride, const float *w, float 
 size_t mlagg_linear_wgrad_workspace_floats(int M, int O, int I);
 int mlagg_linear_wgrad(const float *dy, int dy_stride, const float *x, int x_stride, float *dW, float *db,
                        float *workspace, int M, int O, int I, void *stream);
+/* The same gradient with every fp32 operand as three bf16 pieces on v_mfma_f32_32x32x16_bf16 (six partial products, fp32
+ * accumulation: the error of the fp32 instruction at 2.7x less matrix-pipe time; same workspace, same layouts). */
+int mlagg_linear_wgrad_x3(const float *dy, int dy_stride, const float *x, int x_stride, float *dW, float *db, float *workspace,
+                          int M, int O, int I, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Boundary #3: `flash_attn.flash_attn_func(q, k, v, causal=False)` as called four times per pooled AggregatedAttention

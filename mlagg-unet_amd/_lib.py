@@ -51,6 +51,7 @@ SIGNATURES = {
     "mlagg_dwconv3d_bwd": (_I, [_F, _I, _F, _F, _I, _F, _F, _I, _F, _F, _F, _I, _I, _I, _I, _I, _I, _S]),
     "mlagg_linear_wgrad_workspace_floats": (_SZ, [_I, _I, _I]),
     "mlagg_linear_wgrad": (_I, [_F, _I, _F, _I, _F, _F, _F, _I, _I, _I, _S]),
+    "mlagg_linear_wgrad_x3": (_I, [_F, _I, _F, _I, _F, _F, _F, _I, _I, _I, _S]),
     "mlagg_layernorm_supported": (_I, [_I]),
     "mlagg_layernorm_fwd": (_I, [_F, _I, _F, _F, _F, _F, _I, _I, _FL, _S]),
     "mlagg_layernorm_bwd_workspace_floats": (_SZ, [_I, _I]),

@@ -26,6 +26,7 @@
 
 #include "mlagg_hip.h"
 #include "prof.h"
+#include "bf16x3.h"
 
 namespace {
 
@@ -61,14 +62,7 @@ __device__ __forceinline__ f32x16 mfma16(const uint4 &a, const uint4 &b, f32x16 
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(&a), *reinterpret_cast<const f16x8 *>(&b), c, 0, 0, 0);
 }
 
-// x = hi + mid + lo in bf16 (round to nearest at every level); two values per call, packed like pack2
-__device__ __forceinline__ void split3(float a, float b, unsigned &hi, unsigned &mid, unsigned &lo)
-{
-    hi = pack2<true>(a, b);
-    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
-    mid = pack2<true>(ra, rb);
-    lo = pack2<true>(ra - __uint_as_float(mid << 16), rb - __uint_as_float(mid & 0xffff0000u));
-}
+using bf16x3::split3;
 
 // MODE: 0 fp16, 1 bf16 (operands rounded once: the 16-bit modes), 2 bf16 x 3 (fp32-accurate, see the header)
 template <bool W_NK, int MODE>

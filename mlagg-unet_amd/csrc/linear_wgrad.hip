@@ -20,6 +20,7 @@
 
 #include "mlagg_hip.h"
 #include "prof.h"
+#include "bf16x3.h"
 
 namespace {
 
@@ -155,6 +156,143 @@ linear_wgrad_kernel(const float *__restrict__ dy, const float *__restrict__ x, f
     }
 }
 
+// The same product on v_mfma_f32_32x32x16_bf16 with every fp32 operand as three bf16 pieces (bf16x3.h): as accurate as the fp32
+// instruction, 2.7x less matrix-pipe time.  The token is still the contraction: a lane's operand is now EIGHT consecutive tokens of
+// its column -- values of loads it issues itself, no LDS and no transpose here either.  Column mapping: tile j of a T-tile group
+// takes the columns base + T * lane + j, so ONE T-float load per token row feeds all T tiles (T = 3: global_load_dwordx3, the
+// half-wave reads the row's 384 bytes in one instruction) and one T-float store per accumulator row writes them back contiguously.
+// 16 loads per 16-token block instead of 48: two blocks in flight stay under the 63-entry vmcnt counter (with scalar loads the
+// compiler had to wait for the older block before it could issue the rest of the next).  Per block and 3 x 3 tiles: 16 loads, 264
+// VALU instructions of splitting (filler under the matrix pipe: one wave per SIMD), 54 MFMAs of 8 passes instead of 72 of 16.
+template <int T>
+struct __attribute__((packed, aligned(4))) FVec {
+    float v[T];
+};
+
+template <int TO, int TI>
+__global__ void __launch_bounds__(64)
+linear_wgrad_x3_kernel(const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ part, WGeom g)
+{
+    const int lane = threadIdx.x, col = lane & 31, kh = lane >> 5;
+    const int slab = blockIdx.x, og = blockIdx.y, ig = blockIdx.z;
+    const int o0 = og * TMAX * 32, i0 = ig * TMAX * 32;
+    f32x16 acc[TO][TI];
+#pragma unroll
+    for (int a = 0; a < TO; ++a)
+#pragma unroll
+        for (int b = 0; b < TI; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum[TO];
+#pragma unroll
+    for (int a = 0; a < TO; ++a) bsum[a] = 0.f;
+
+    const int m_begin = slab * g.slab, m_end = min(m_begin + g.slab, g.M);
+    // the lane's first column, clamped so that its T-float load stays inside the row (columns past O / I feed accumulator rows /
+    // columns that are never stored); uniform row base + per-lane 32-bit byte offset
+    const int oc = min(o0 + TO * col, g.O - TO), ic = min(i0 + TI * col, g.I - TI);
+    const float *dyb = dy + (size_t)m_begin * g.dy_stride;
+    const float *xb = x + (size_t)m_begin * g.x_stride;
+    const unsigned offa = 4u * (unsigned)(8 * kh * g.dy_stride + oc), offb = 4u * (unsigned)(8 * kh * g.x_stride + ic);
+    // Three operand buffers: the loads of blocks j + 1 and j + 2 are in flight while block j is consumed -- with one wave per SIMD
+    // nothing else covers the HBM round trip (longer than one block's ~1900 cycles of matrix work).  Every fetch is unconditional
+    // (block index clamped to the last full block: at most two redundant fetches per slab).
+    FVec<TO> av[3][8];
+    FVec<TI> bv[3][8];
+    const int nfull = (m_end - m_begin) / 16;              // blocks with all 16 tokens in range
+    auto fetch = [&](FVec<TO> (&A)[8], FVec<TI> (&Bv)[8], int blk) {
+        const size_t row = (size_t)16 * (size_t)min(blk, nfull - 1);
+        const char *da = reinterpret_cast<const char *>(dyb + row * g.dy_stride);
+        const char *db = reinterpret_cast<const char *>(xb + row * g.x_stride);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            A[t] = *reinterpret_cast<const FVec<TO> *>(da + (size_t)t * 4u * g.dy_stride + (size_t)offa);
+            Bv[t] = *reinterpret_cast<const FVec<TI> *>(db + (size_t)t * 4u * g.x_stride + (size_t)offb);
+        }
+    };
+    auto consume = [&](const FVec<TO> (&A)[8], const FVec<TI> (&Bv)[8]) {
+        uint4 bq[TI][3];
+#pragma unroll
+        for (int b = 0; b < TI; ++b) {
+            bf16x3::split3(Bv[0].v[b], Bv[1].v[b], bq[b][0].x, bq[b][1].x, bq[b][2].x);
+            bf16x3::split3(Bv[2].v[b], Bv[3].v[b], bq[b][0].y, bq[b][1].y, bq[b][2].y);
+            bf16x3::split3(Bv[4].v[b], Bv[5].v[b], bq[b][0].z, bq[b][1].z, bq[b][2].z);
+            bf16x3::split3(Bv[6].v[b], Bv[7].v[b], bq[b][0].w, bq[b][1].w, bq[b][2].w);
+        }
+#pragma unroll
+        for (int a = 0; a < TO; ++a) {
+            uint4 aq[3];
+            bf16x3::split3(A[0].v[a], A[1].v[a], aq[0].x, aq[1].x, aq[2].x);
+            bf16x3::split3(A[2].v[a], A[3].v[a], aq[0].y, aq[1].y, aq[2].y);
+            bf16x3::split3(A[4].v[a], A[5].v[a], aq[0].z, aq[1].z, aq[2].z);
+            bf16x3::split3(A[6].v[a], A[7].v[a], aq[0].w, aq[1].w, aq[2].w);
+            bsum[a] += ((A[0].v[a] + A[1].v[a]) + (A[2].v[a] + A[3].v[a])) + ((A[4].v[a] + A[5].v[a]) + (A[6].v[a] + A[7].v[a]));
+#pragma unroll
+            for (int b = 0; b < TI; ++b) acc[a][b] = bf16x3::mfma6(aq, bq[b], acc[a][b]);
+        }
+    };
+    if (nfull > 0) {
+        fetch(av[0], bv[0], 0);
+        fetch(av[1], bv[1], 1);
+        int it = 0;
+        for (; it + 3 <= nfull; it += 3) {                 // buffers 0, 1 hold blocks it, it + 1
+            fetch(av[2], bv[2], it + 2);
+            consume(av[0], bv[0]);
+            fetch(av[0], bv[0], it + 3);
+            consume(av[1], bv[1]);
+            fetch(av[1], bv[1], it + 4);
+            consume(av[2], bv[2]);
+        }
+        if (it < nfull) consume(av[0], bv[0]);
+        if (it + 1 < nfull) consume(av[1], bv[1]);
+    }
+    if (m_begin + nfull * 16 < m_end) {                    // last, partial block: clamped rows, values beyond the slab dropped
+        const int mb = m_begin + nfull * 16;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int m = mb + 8 * kh + t;
+            const bool ok = m < m_end;
+            const size_t mr = (size_t)min(m, g.M - 1);
+            const FVec<TO> va = *reinterpret_cast<const FVec<TO> *>(dy + mr * g.dy_stride + oc);
+            const FVec<TI> vb = *reinterpret_cast<const FVec<TI> *>(x + mr * g.x_stride + ic);
+#pragma unroll
+            for (int a = 0; a < TO; ++a) av[0][t].v[a] = ok ? va.v[a] : 0.f;
+#pragma unroll
+            for (int b = 0; b < TI; ++b) bv[0][t].v[b] = ok ? vb.v[b] : 0.f;
+        }
+        consume(av[0], bv[0]);
+    }
+    // partial block of this slab: part[slab][O*I + O].  D layout of tile (a, b): column = lane & 31, row R = (r&3) + 8*(r>>2) +
+    // 4*kh, i.e. dW[base_o(R) + a][base_i(col) + b] with base(.) the (clamped) first column of that lane: the TI tiles of a row
+    // leave as one store.  A clamped lane repeats columns of its left neighbours below its natural base: those are skipped.
+    float *prow = part + (size_t)slab * ((size_t)g.O * g.I + g.O);
+    const int ib = i0 + TI * col;
+#pragma unroll
+    for (int a = 0; a < TO; ++a) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nat = o0 + TO * ((r & 3) + 8 * (r >> 2) + 4 * kh);
+            const int o = min(nat, g.O - TO) + a;
+            if (o < nat) continue;
+            float *dst = prow + (size_t)o * g.I + ic;
+            if (ic == ib) {
+                FVec<TI> v;
+#pragma unroll
+                for (int b = 0; b < TI; ++b) v.v[b] = acc[a][b][r];
+                *reinterpret_cast<FVec<TI> *>(dst) = v;
+            } else {
+#pragma unroll
+                for (int b = 0; b < TI; ++b)
+                    if (ic + b >= ib) dst[b] = acc[a][b][r];
+            }
+        }
+        if (ig == 0) {
+            const float sacc = bsum[a] + __shfl_down(bsum[a], 32, 64);
+            if (kh == 0 && oc + a >= o0 + TO * col) prow[(size_t)g.O * g.I + oc + a] = sacc;
+        }
+    }
+}
+
 // dW[O*I] (+ db[O]) = sum over slabs of part rows.  A workgroup owns 64 consecutive columns (256-byte row segments) and
 // splits the slabs over RGROUPS row-groups, finished through LDS: every output is written once -- no pre-zeroing of dW / db
 // (the first version added 16 partial sums per output with float atomics behind a hipMemsetAsync: 96 fills per step).
@@ -200,7 +338,7 @@ int make_geom(WGeom &g, int M, int O, int I, int dys, int xs)
     // over the 15 shapes of tools/bench_linear.py (512: 1603, 1536: 1345 -- uneven -- 4096: 1522).  MLAGG_K5W_WAVES overrides.
     static const int target = [] { const char *e = getenv("MLAGG_K5W_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
     int slab = (int)(((long long)M * g.ogroups * g.igroups + target - 1) / target);
-    slab = ((slab + 7) / 8) * 8;
+    slab = ((slab + 15) / 16) * 16;       // whole 16-token blocks of the 16-deep instruction (and 8 pairs of the fp32 one)
     if (slab < 64) slab = 64;
     g.slab = slab;
     g.nslabs = (M + slab - 1) / slab;
@@ -209,10 +347,12 @@ int make_geom(WGeom &g, int M, int O, int I, int dys, int xs)
 }
 
 template <int TO, int TI>
-void launch(const float *dy, const float *x, float *part, const WGeom &g, hipStream_t st)
+void launch(const float *dy, const float *x, float *part, const WGeom &g, hipStream_t st, bool x3)
 {
-    hipLaunchKernelGGL((linear_wgrad_kernel<TO, TI>), dim3(g.nslabs, g.ogroups, g.igroups), dim3(64), 0, st, dy, x,
-                       part, g);
+    if (x3)
+        hipLaunchKernelGGL((linear_wgrad_x3_kernel<TO, TI>), dim3(g.nslabs, g.ogroups, g.igroups), dim3(64), 0, st, dy, x, part, g);
+    else
+        hipLaunchKernelGGL((linear_wgrad_kernel<TO, TI>), dim3(g.nslabs, g.ogroups, g.igroups), dim3(64), 0, st, dy, x, part, g);
 }
 
 }  // namespace
@@ -224,8 +364,9 @@ extern "C" size_t mlagg_linear_wgrad_workspace_floats(int M, int O, int I)
     return (size_t)g.nslabs * ((size_t)O * I + O);
 }
 
-extern "C" int mlagg_linear_wgrad(const float *dy, int dy_stride, const float *x, int x_stride, float *dW, float *db,
-                                  float *workspace, int M, int O, int I, void *stream)
+namespace {
+int wgrad(const float *dy, int dy_stride, const float *x, int x_stride, float *dW, float *db, float *workspace, int M, int O, int I,
+          bool x3, void *stream)
 {
     if (!dy || !x || !dW || !workspace) return MLAGG_E_NULLPTR;
     WGeom g;
@@ -237,19 +378,32 @@ extern "C" int mlagg_linear_wgrad(const float *dy, int dy_stride, const float *x
     {
         MLAGG_TIMED(K_LINEAR_WGRAD, st);
         switch (to * 4 + ti) {
-        case 1 * 4 + 1: launch<1, 1>(dy, x, workspace, g, st); break;
-        case 1 * 4 + 2: launch<1, 2>(dy, x, workspace, g, st); break;
-        case 1 * 4 + 3: launch<1, 3>(dy, x, workspace, g, st); break;
-        case 2 * 4 + 1: launch<2, 1>(dy, x, workspace, g, st); break;
-        case 2 * 4 + 2: launch<2, 2>(dy, x, workspace, g, st); break;
-        case 2 * 4 + 3: launch<2, 3>(dy, x, workspace, g, st); break;
-        case 3 * 4 + 1: launch<3, 1>(dy, x, workspace, g, st); break;
-        case 3 * 4 + 2: launch<3, 2>(dy, x, workspace, g, st); break;
-        default: launch<3, 3>(dy, x, workspace, g, st); break;
+        case 1 * 4 + 1: launch<1, 1>(dy, x, workspace, g, st, x3); break;
+        case 1 * 4 + 2: launch<1, 2>(dy, x, workspace, g, st, x3); break;
+        case 1 * 4 + 3: launch<1, 3>(dy, x, workspace, g, st, x3); break;
+        case 2 * 4 + 1: launch<2, 1>(dy, x, workspace, g, st, x3); break;
+        case 2 * 4 + 2: launch<2, 2>(dy, x, workspace, g, st, x3); break;
+        case 2 * 4 + 3: launch<2, 3>(dy, x, workspace, g, st, x3); break;
+        case 3 * 4 + 1: launch<3, 1>(dy, x, workspace, g, st, x3); break;
+        case 3 * 4 + 2: launch<3, 2>(dy, x, workspace, g, st, x3); break;
+        default: launch<3, 3>(dy, x, workspace, g, st, x3); break;
         }
     }
     const int n = O * I + O;
     hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(64 * RGROUPS), 0, st, workspace,
                        g.nslabs, O * I, O, dW, db);
     return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int mlagg_linear_wgrad(const float *dy, int dy_stride, const float *x, int x_stride, float *dW, float *db,
+                                  float *workspace, int M, int O, int I, void *stream)
+{
+    return wgrad(dy, dy_stride, x, x_stride, dW, db, workspace, M, O, I, false, stream);
+}
+
+extern "C" int mlagg_linear_wgrad_x3(const float *dy, int dy_stride, const float *x, int x_stride, float *dW, float *db,
+                                     float *workspace, int M, int O, int I, void *stream)
+{
+    return wgrad(dy, dy_stride, x, x_stride, dW, db, workspace, M, O, I, true, stream);
 }

@@ -714,8 +714,8 @@ class LinearFn(torch.autograd.Function):
                 db = buf[O * I:] if ctx.has_bias else None
                 ws = torch.empty(lib.mlagg_linear_wgrad_workspace_floats(M, O, I), device=dy.device,
                                  dtype=torch.float32)
-                _lib.check(lib.mlagg_linear_wgrad(_ptr(dy2), dys, _ptr(x2), xs, _ptr(dW), _ptr(db), _ptr(ws), M, O, I,
-                                                  _stream()), "mlagg_linear_wgrad")
+                wgrad = lib.mlagg_linear_wgrad_x3 if K5_X3 else lib.mlagg_linear_wgrad
+                _lib.check(wgrad(_ptr(dy2), dys, _ptr(x2), xs, _ptr(dW), _ptr(db), _ptr(ws), M, O, I, _stream()), "mlagg_linear_wgrad")
             else:
                 dW = dy2.t().matmul(x2)
                 db = (column_sum(dy2) if dy2.is_cuda else dy2.sum(0)) if ctx.has_bias else None

@@ -848,3 +848,30 @@ def test_linear_bf16x3_is_as_accurate_as_the_fp32_instruction(M, N, K):
     ops.LinearFn.apply(xg, wg, b).backward(gy)                # M >= 16384: x3 forward and x3 data gradient on W^T; else the library
     dref = gy.double() @ w.double()
     assert float((xg.grad.double() - dref).abs().max() / dref.abs().max()) < 3e-6
+
+
+@gpu
+@pytest.mark.parametrize("M,O,I", [(16384, 192, 96), (9000, 140, 96), (8195, 48, 144), (8192, 100, 52), (40000, 96, 140), (8200, 36, 256)])
+def test_linear_wgrad_bf16x3_matches_float64(M, O, I):
+    """K5w on the 16-bit matrix instructions (mlagg_linear_wgrad_x3): dW and db against float64 with the fp32 kernel's bound, on
+    widths that are not multiples of the 96-column groups (clamped lanes), ragged token counts and strided operands."""
+    from mlagg_unet_amd import _lib
+    lib = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(M + O + I)
+    dyw = torch.randn(M, O + 8, generator=g).to(DEV)
+    xw = (torch.randn(M, I + 4, generator=g) * torch.exp(0.5 * torch.randn(M, 1, generator=g))).to(DEV)
+    dy, x = dyw[:, 4:4 + O], xw[:, :I]
+    ws = torch.empty(lib.mlagg_linear_wgrad_workspace_floats(M, O, I), device=DEV)
+    out = {}
+    for name, fn in (("x3", lib.mlagg_linear_wgrad_x3), ("fp32", lib.mlagg_linear_wgrad)):
+        dW, db = torch.full((O, I), float("nan"), device=DEV), torch.full((O,), float("nan"), device=DEV)
+        _lib.check(fn(dy.data_ptr(), dyw.stride(0), x.data_ptr(), xw.stride(0), dW.data_ptr(), db.data_ptr(), ws.data_ptr(), M, O, I, st),
+                   name)
+        out[name] = (dW, db)
+    ref = dy.double().t() @ x.double()
+    e3 = float((out["x3"][0].double() - ref).abs().max() / ref.abs().max())
+    e1 = float((out["fp32"][0].double() - ref).abs().max() / ref.abs().max())
+    assert e3 < 2e-6 and e3 < 1.5 * e1 + 1e-7, (e3, e1)
+    bref = dy.double().sum(0)
+    assert float((out["x3"][1].double() - bref).abs().max()) < 1e-3 * max(1.0, float(bref.abs().max()))

@@ -36,9 +36,9 @@ def main():
     lib = _lib.lib()
     st = torch.cuda.current_stream().cuda_stream
     p = lambda t: t.data_ptr()
-    print(f"{'shape':34s} {'fwd us':>8s} {'TF/s':>6s} {'blas':>7s} {'x3':>7s} {'TF/s':>6s} | {'dgrad':>7s} {'TF/s':>6s} {'blas':>7s} {'x3':>7s} | {'wgrad':>7s} {'TF/s':>6s} {'blas':>7s}"
-          "   max |err| vs float64 / max |y|: K5, x3, blas (fwd)")
-    tot = [0.0] * 8
+    print(f"{'shape':34s} {'fwd us':>8s} {'TF/s':>6s} {'blas':>7s} {'x3':>7s} {'TF/s':>6s} | {'dgrad':>7s} {'TF/s':>6s} {'blas':>7s} {'x3':>7s} | {'wgrad':>7s} {'TF/s':>6s} {'blas':>7s} {'x3':>7s} {'TF/s':>6s}"
+          "   max |err| vs float64 / max: fwd K5, x3, blas; wgrad K5w, x3")
+    tot = [0.0] * 9
     only = os.environ.get("MLAGG_BENCH_ONLY")
     for M, K, N, where in SHAPES:
         if only and only not in where:
@@ -71,11 +71,20 @@ def main():
         assert float((dx3 - dx).abs().max()) < 1e-4 * N ** 0.5
         g = timeit(lambda: _lib.check(lib.mlagg_linear_wgrad(p(dy), N, p(x), K, p(dW), p(db), p(ws), M, N, K, st), "wgrad"))
         gb = timeit(lambda: (torch.mm(dy.t(), x), dy.sum(0)))
-        for i, v in enumerate((f, fb, d, dbl, g, gb, f3, d3)):
+        dW3, db3 = torch.empty_like(dW), torch.empty_like(db)
+        g3 = timeit(lambda: _lib.check(lib.mlagg_linear_wgrad_x3(p(dy), N, p(x), K, p(dW3), p(db3), p(ws), M, N, K, st), "wgrad x3"))
+        wref = dy[:32768].double().t() @ x[:32768].double()
+        lib.mlagg_linear_wgrad(p(dy), N, p(x), K, p(dW), p(db), p(ws), min(M, 32768), N, K, st)
+        e1 = float((dW.double() - wref).abs().max() / wref.abs().max())
+        lib.mlagg_linear_wgrad_x3(p(dy), N, p(x), K, p(dW3), p(db3), p(ws), min(M, 32768), N, K, st)
+        e3 = float((dW3.double() - wref).abs().max() / wref.abs().max())
+        assert float((db3 - db).abs().max()) < 1e-3 * float(db.abs().max() + 1)
+        for i, v in enumerate((f, fb, d, dbl, g, gb, f3, d3, g3)):
             tot[i] += v
         print(f"{str((M, K, N)) + ' ' + where:34s} {f:8.1f} {fl / f / 1e6:6.1f} {fb:7.1f} {f3:7.1f} {fl / f3 / 1e6:6.1f} | {d:7.1f} {fl / d / 1e6:6.1f} {dbl:7.1f} {d3:7.1f} | "
-              f"{g:7.1f} {fl / g / 1e6:6.1f} {gb:7.1f}   {errs[0]:.1e} {errs[1]:.1e} {errs[2]:.1e}", flush=True)
-    print("totals us: fwd %.0f (blas %.0f)  dgrad %.0f (blas %.0f)  wgrad %.0f (blas %.0f)  x3: fwd %.0f dgrad %.0f" % tuple(tot))
+              f"{g:7.1f} {fl / g / 1e6:6.1f} {gb:7.1f} {g3:7.1f} {fl / g3 / 1e6:6.1f}   {errs[0]:.1e} {errs[1]:.1e} {errs[2]:.1e}; {e1:.1e} {e3:.1e}",
+              flush=True)
+    print("totals us: fwd %.0f (blas %.0f)  dgrad %.0f (blas %.0f)  wgrad %.0f (blas %.0f)  x3: fwd %.0f dgrad %.0f wgrad %.0f" % tuple(tot))
 
 
 if __name__ == "__main__":
