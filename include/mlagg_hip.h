@@ -266,6 +266,24 @@ int mlagg_cross_merge(const float *seq, float *tok, int tok_stride, int blk_stri
                       const int *H, const int *W, int CB, int nblk, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K18: 1 x 1 convolutions (stride 1, no padding, groups 1) on channel-major maps, fp32 operands as three bf16 pieces on the 16-bit
+ * matrix instructions (six partial products, fp32 accumulation: the accuracy of the fp32 instruction).  Replaces the library
+ * convolution behind nn.Conv2d(kernel_size=1) at nnUNetTrainer_MLAgg_2D_dt_MS.py:279-316 (MedNeXtBlock conv2 / conv3), :319-367
+ * (down / up blocks) and :972-1001 (Project).
+ *   fwd:   y (B, O, P) = w (O, I) . x (B, I, P) (+ bias[o], NULL: none); P = H * W pixels; x_batch / y_batch: floats between
+ *          samples (a channel slice of a wider map is a valid operand).  The data gradient is the same call on w^T (I, O) and dy.
+ *   wgrad: dW (O, I) = sum_b dy (B, O, P) . x (B, I, P)^T, overwritten; workspace: mlagg_conv1x1_wgrad_workspace_floats floats.
+ * Supported (mlagg_conv1x1_supported): contraction I % 16 == 0, P % 16 == 0, P >= 96; anything else MLAGG_E_UNSUPPORTED (the
+ * caller keeps the library convolution).
+ * ------------------------------------------------------------------------------------------ */
+int mlagg_conv1x1_supported(int O, int I, long P);
+int mlagg_conv1x1_fwd(const float *x, long x_batch, const float *w, const float *bias, float *y, long y_batch, int B, int O, int I,
+                      long P, void *stream);
+size_t mlagg_conv1x1_wgrad_workspace_floats(int B, int O, int I, long P);
+int mlagg_conv1x1_wgrad(const float *dy, long dy_batch, const float *x, long x_batch, float *dW, float *workspace, int B, int O,
+                        int I, long P, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * K17: key / value reduction of the pooled attention branch, pooled (B, (H/r)(W/r), d) = r x r window mean of GELU(s), s (B, H W, d)
  * token-major at row stride s_stride (a column block of the stacked q | v | sr projection).  Replaces nn.GELU + nn.AdaptiveAvgPool2d
  * at nnUNetTrainer_MLAgg_2D_dt_MS.py:722 (modules at :668, :671) for H % r == W % r == 0 (other sizes: MLAGG_E_UNSUPPORTED, the

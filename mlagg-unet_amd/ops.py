@@ -1527,6 +1527,96 @@ def channel_epilogue_lp(x, bias=None, res=None, act=EPI_NONE, out_dtype=torch.fl
 # ------------------------------------------------------------------------------------------------
 # K15: full convolutions with the weight gradient on this package's tap-GEMM kernel
 # ------------------------------------------------------------------------------------------------
+def _planes(t, name):
+    """(B, C, *spatial) map whose samples are contiguous (C, P) blocks -- a channel slice of a wider NCHW map qualifies; anything else
+    is copied.  Returns (tensor, floats between samples, P)."""
+    _require(t, name)
+    inner, want = 1, []
+    for v in reversed(t.shape[1:]):
+        want.append(inner)
+        inner *= int(v)
+    want.reverse()
+    if tuple(t.stride()[1:]) != tuple(want) or t.stride(0) < inner or t.stride(0) % 4 or t.data_ptr() % 16:
+        t = t.contiguous()
+    return t, t.stride(0), inner // int(t.shape[1])
+
+
+# K18 against MIOpen's tuned fp32 GEMM kernels on the 1 x 1 shapes of the 256 x 256 step (tools/bench_conv1x1.py,
+# profiles/round3_g_conv1x1_*.log): the forward / data-gradient kernel wins where the pixel count is large and the contraction
+# short-to-medium (128 x 128 and 256 x 256 maps: 70 vs 110, 64 vs 93, 98 vs 215 us), ties at 64 x 64 and loses on the small maps
+# (few, long-K tiles); the weight gradient wins from 64 x 64 up (80 vs 142, 70 vs 88, 150 vs 252 us).  Each of the three products
+# of a layer goes to the faster side.
+K18 = _os.environ.get("MLAGG_K18", "1") == "1"
+K18_FWD_MIN_PIXELS, K18_FWD_MIN_K, K18_WGRAD_MIN_PIXELS = 16384, 96, 4096
+
+
+def _k18_product(O, I, P):
+    """forward-form product y (O) = w (O, I) . x (I) on K18?  (the data gradient asks with O and I exchanged)"""
+    return P >= K18_FWD_MIN_PIXELS and I >= K18_FWD_MIN_K and bool(_lib.lib().mlagg_conv1x1_supported(O, I, P))
+
+
+class Conv1x1Fn(torch.autograd.Function):
+    """y = conv2d(x, W) for a 1 x 1 kernel (stride 1, no bias): each of the three products on K18 (this package's split-bf16 GEMM
+    kernels: forward, data gradient = the forward kernel on W^T, weight gradient with the pixels as the contraction) or on the
+    library, whichever is faster at the shape (see K18_* above)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x, xb, P = _planes(x, "x")
+        B, I = x.shape[:2]
+        O = weight.shape[0]
+        w = _require(weight.reshape(O, I).contiguous(), "weight")
+        if _k18_product(O, I, P):
+            y = torch.empty((B, O) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
+            _lib.check(_lib.lib().mlagg_conv1x1_fwd(_ptr(x), xb, _ptr(w), None, _ptr(y), O * P, B, O, I, P, _stream()),
+                       "mlagg_conv1x1_fwd")
+        else:
+            y = torch.nn.functional.conv2d(x, weight)
+        ctx.save_for_backward(x, w)
+        ctx.wshape = weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, I = x.shape[:2]
+        O = w.shape[0]
+        dy, dyb, P = _planes(dy, "dy")
+        lib = _lib.lib()
+        dx = dW = None
+        if ctx.needs_input_grad[0]:
+            if _k18_product(I, O, P):
+                wt = transpose_2d(w.unsqueeze(0))[0]                                   # (I, O): the contraction runs along its rows
+                dx = torch.empty((B, I) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
+                _lib.check(lib.mlagg_conv1x1_fwd(_ptr(dy), dyb, _ptr(wt), None, _ptr(dx), I * P, B, I, O, P, _stream()),
+                           "mlagg_conv1x1_fwd")
+            else:
+                dx = torch.ops.aten.convolution_backward(dy, x, w.view(ctx.wshape), None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1,
+                                                         (True, False, False))[0]
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty(O, I, device=x.device, dtype=torch.float32)
+            ws = torch.empty(lib.mlagg_conv1x1_wgrad_workspace_floats(B, O, I, P), device=x.device, dtype=torch.float32)
+            _lib.check(lib.mlagg_conv1x1_wgrad(_ptr(dy), dyb, _ptr(x), x.stride(0), _ptr(dW), _ptr(ws), B, O, I, P, _stream()),
+                       "mlagg_conv1x1_wgrad")
+            dW = dW.view(ctx.wshape)
+        return dx, dW
+
+
+def conv1x1_supported(x, weight, stride, padding, dilation, groups):
+    """A 1 x 1, stride-1, dense fp32 convolution on the device whose weight gradient (at least) runs on K18."""
+    if not (K18 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and groups == 1):
+        return False
+    if tuple(weight.shape[2:]) != (1, 1) or any(int(v) != 1 for v in stride) or any(int(v) != 0 for v in padding) or \
+            any(int(v) != 1 for v in dilation):
+        return False
+    P = int(x.shape[2] * x.shape[3])
+    return P >= K18_WGRAD_MIN_PIXELS and P % 16 == 0
+
+
+def conv1x1(x, weight):
+    return Conv1x1Fn.apply(x, weight)
+
+
 def _pad_geometry(D, H, W, stride, wide=False):
     import ctypes
     Dq, Hq, Wq, guard = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_long()

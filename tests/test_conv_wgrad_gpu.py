@@ -5,6 +5,7 @@ import torch
 import torch.nn.functional as F
 
 gpu = pytest.mark.gpu
+DEV = "cuda:0"
 
 CASES = [
     # (B, I, O, dims, k, stride)
@@ -91,3 +92,54 @@ def test_conv_taps_forward_and_gradients_match_torch(B, I, O, dims, k):
     for name, a, b in (("y", y.detach(), yr.detach()), ("dx", xg.grad, xr.grad), ("dW", wg.grad, wr.grad)):
         err = float((a.cpu().double() - b).abs().max())
         assert err <= 2e-5 * float(b.abs().max()) + 1e-5, (name, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,I,O,H,W,sliced", [(2, 96, 192, 32, 32, False), (3, 192, 96, 16, 24, True), (2, 48, 96, 24, 20, False),
+                                              (1, 384, 768, 8, 12, False), (2, 96, 14, 16, 16, False), (2, 768, 384, 16, 7 * 16, True),
+                                              (2, 48, 40, 10, 16, False)])
+def test_conv1x1_matches_float64(monkeypatch, B, I, O, H, W, sliced):
+    """K18 (1 x 1 convolution on the 16-bit matrix instructions, fp32 operands as three bf16 pieces): output, data gradient and
+    weight gradient against float64 conv2d, at the error of an fp32 GEMM.  Cases: channel counts off the 96-wide groups, pixel
+    counts that are not multiples of 96 (clamped lanes), a channel-slice input (sample stride > C * P), and an output width (14,
+    40) whose data gradient has a contraction that is not a multiple of 16 (library fallback for that gradient only)."""
+    from mlagg_unet_amd import ops
+    for name, v in (("K18_FWD_MIN_PIXELS", 0), ("K18_FWD_MIN_K", 16), ("K18_WGRAD_MIN_PIXELS", 0)):      # every product on K18
+        monkeypatch.setattr(ops, name, v)
+    g = torch.Generator().manual_seed(B * I + O)
+    wide = torch.randn(B, I + 16, H, W, generator=g).to(DEV)
+    x = (wide[:, 8:8 + I] if sliced else wide[:, :I].contiguous()).detach()
+    w = (torch.randn(O, I, 1, 1, generator=g) * I ** -0.5).to(DEV)
+    gy = torch.randn(B, O, H, W, generator=g).to(DEV)
+    assert ops.conv1x1_supported(x, w, (1, 1), (0, 0), (1, 1), 1) and ops._k18_product(O, I, H * W)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr)
+    yr.backward(gy.double())
+    xp, wp = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yp = ops.conv1x1(xp, wp)
+    yp.backward(gy)
+    for name, got, want in (("y", yp, yr), ("dx", xp.grad, xr.grad), ("dW", wp.grad, wr.grad)):
+        err = float((got.detach().double() - want.detach()).abs().max() / want.detach().abs().max())
+        assert err < 2e-6, (name, err)
+
+
+@pytest.mark.gpu
+def test_conv1x1_dispatch_rules_and_large_map():
+    """ops.conv1x1_supported / Conv1x1Fn: which convolutions take K18, and a 128 x 128 map where all three products run on it."""
+    from mlagg_unet_amd import ops
+    x = torch.randn(2, 96, 128, 128, device=DEV)
+    w = torch.randn(192, 96, 1, 1, device=DEV) * 0.1
+    assert ops.conv1x1_supported(x, w, (1, 1), (0, 0), (1, 1), 1) and ops._k18_product(192, 96, 128 * 128) and ops._k18_product(96, 192, 128 * 128)
+    assert not ops.conv1x1_supported(x, w, (2, 2), (0, 0), (1, 1), 1)                   # strided
+    assert not ops.conv1x1_supported(x[:, :, :32, :32], w, (1, 1), (0, 0), (1, 1), 1)    # 1024 pixels: the library is faster
+    assert not ops._k18_product(48, 24, 128 * 128)                                      # contraction 24: not a multiple of 16
+    gy = torch.randn(2, 192, 128, 128, device=DEV)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr)
+    yr.backward(gy.double())
+    xp, wp = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yp = ops.conv1x1(xp, wp)
+    yp.backward(gy)
+    for name, got, want in (("y", yp, yr), ("dx", xp.grad, xr.grad), ("dW", wp.grad, wr.grad)):
+        err = float((got.detach().double() - want.detach()).abs().max() / want.detach().abs().max())
+        assert err < 2e-6, (name, err)
