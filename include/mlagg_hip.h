@@ -284,6 +284,21 @@ int mlagg_conv1x1_wgrad(const float *dy, long dy_batch, const float *x, long x_b
                         int I, long P, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K19: dense 3 x 3 convolutions (stride 1, zero padding 1, groups 1) on channel-major maps as nine shifted GEMMs on the 16-bit matrix
+ * instructions (fp32 operands as three bf16 pieces, six partial products, fp32 accumulation).  Replaces the library convolution
+ * behind nn.Conv2d(kernel_size=3, padding=1) in UnetResBlock conv1 / conv2 (nnUNetTrainer_MLAgg_2D_dt_MS.py:1340-1368 via
+ * UnetrBasicBlock / UnetrUpBlock), Project (T:972-1001) and the MSMM conv branches (MambaSkip.py:706-712): forward, and -- with
+ * `transposed`, on the layer's forward weight (I_layer = O here) and its output gradient -- the data gradient.
+ *   y (B, O, H, W) = conv3x3(x (B, I, H, W), w) (+ bias[o], NULL: none); x_batch / y_batch: floats between samples;
+ *   workspace: mlagg_conv3x3_workspace_bytes(O, I) bytes, 16-byte aligned (the pre-split weight image, rebuilt by every call).
+ * Supported (mlagg_conv3x3_supported): contraction I % 16 == 0, H * W >= 96.
+ * ------------------------------------------------------------------------------------------ */
+int mlagg_conv3x3_supported(int O, int I, int H, int W);
+size_t mlagg_conv3x3_workspace_bytes(int O, int I);
+int mlagg_conv3x3_fwd(const float *x, long x_batch, const float *w, int transposed, const float *bias, float *y, long y_batch,
+                      void *workspace, int B, int O, int I, int H, int W, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * K17: key / value reduction of the pooled attention branch, pooled (B, (H/r)(W/r), d) = r x r window mean of GELU(s), s (B, H W, d)
  * token-major at row stride s_stride (a column block of the stacked q | v | sr projection).  Replaces nn.GELU + nn.AdaptiveAvgPool2d
  * at nnUNetTrainer_MLAgg_2D_dt_MS.py:722 (modules at :668, :671) for H % r == W % r == 0 (other sizes: MLAGG_E_UNSUPPORTED, the

@@ -31,7 +31,8 @@ const char *const kNames[K_COUNT] = {
     "sel1_fwd_kernel<R != 2, false>", "sel1_fwd_kernel<R != 2, true>", "sel1_bwd_local_kernel<R != 2>", "sel1_bwd_kernel<R != 2>",
     "sel1_prefix_kernel", "sel1 reductions (step partials + per-chunk rows)",
     "volume_pad_kernel (+ guard fill)", "conv_wgrad_taps_kernel", "conv_wgrad_reduce_kernel", "conv_taps_kernel (forward / data gradient)",
-    "gelu_pool (forward + backward)", "conv1x1 (forward / data gradient / weight gradient)"};
+    "gelu_pool (forward + backward)", "conv1x1 (forward / data gradient / weight gradient)",
+    "conv3x3 (forward / data gradient, incl. weight image)"};
 }  // namespace
 
 // begin/end pairs of one kernel are issued back to back from one host thread (the launcher), so the

@@ -1,0 +1,232 @@
+// K19 -- dense 3 x 3 convolutions (stride 1, zero padding 1) on channel-major (NCHW) maps as nine shifted GEMMs on the 16-bit
+// matrix instructions with fp32 accuracy (bf16x3.h):
+//   y[b][o][p] = sum_t sum_i w[o][i][t] x[b][i][p + off_t],   off_t = (ty - 1) W + (tx - 1),  zero outside the image
+// -- the forward of the convolutional stem / decoder blocks (nnUNetTrainer_MLAgg_2D_dt_MS.py:1340-1368 UnetrBasicBlock / UnetrUpBlock
+// -> UnetResBlock conv1 / conv2, :972-1001 Project, MambaSkip.py:706-712 conv branches) and, on the transposed weight with the taps
+// flipped, their data gradient.  MIOpen runs these as fp32 Winograd kernels at 64-104 TFLOP/s (2.8 ms forward + 2.5 ms data
+// gradient per 256 x 256 step); six bf16 MFMAs per 16-deep block cost 0.375 of the eight fp32 ones.
+//
+// No padded copy, no LDS, no layout change (the structure of K18's forward): D rows = output channels, D columns = pixels; per
+// 16-channel block and tap a lane issues eight loads (its T consecutive pixels, shifted by the tap, of eight input channels; all
+// but the first tap of a block hit L1 / L2), zeroes what falls outside the image (2-bit per-pixel source codes made once per lane), splits the
+// values into bf16 pieces and feeds 6 TO TP MFMAs.  The weights are pre-split once per launch by a tiny kernel into three bf16
+// images [tap][o][i] (i contiguous: a lane's A operand is one 16-byte load per image) -- for the data gradient that kernel also
+// transposes (o <-> i) and flips the taps.  One wave per workgroup, every load unconditional (clamped address, masked value).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "mlagg_hip.h"
+#include "prof.h"
+#include "bf16x3.h"
+
+namespace {
+
+using bf16x3::f32x16;
+
+template <int T>
+struct __attribute__((packed, aligned(4))) FVec {
+    float v[T];
+};
+
+struct C3Geom {
+    int B, O, I, H, W, P;
+    long x_batch, y_batch;
+};
+
+// wimg[q][t][o][i] (bf16 piece q of the weight of tap t); flip: the data gradient's weight, w'[i][o][t] = w[o][i][8 - t] with the
+// roles of o and i exchanged (O, I are the OUTPUT / CONTRACTION extents of the product the image serves)
+__global__ void __launch_bounds__(256)
+conv3x3_weight_image_kernel(const float *__restrict__ w, unsigned short *__restrict__ img, int O, int I, int flip)
+{
+    const int n = 9 * O * I;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int i = idx % I, o = (idx / I) % O, t = idx / (I * O);
+    const float v = flip ? w[((size_t)i * O + o) * 9 + (8 - t)] : w[((size_t)o * I + i) * 9 + t];
+    unsigned hi, mid, lo;
+    bf16x3::split3(v, 0.f, hi, mid, lo);
+    img[idx] = (unsigned short)(hi & 0xffff);
+    img[n + idx] = (unsigned short)(mid & 0xffff);
+    img[2 * n + idx] = (unsigned short)(lo & 0xffff);
+}
+
+template <int TO, int TP>
+__global__ void __launch_bounds__(64)
+conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Wimg, const float *__restrict__ bias,
+               float *__restrict__ Y, C3Geom g)
+{
+    const int lane = threadIdx.x, col = lane & 31, kh = lane >> 5;
+    const int p0 = blockIdx.x * (32 * TP), o0 = blockIdx.y * (32 * TO), b = blockIdx.z;
+    f32x16 acc[TO][TP];
+#pragma unroll
+    for (int a = 0; a < TO; ++a)
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][j][r] = 0.f;
+    const int pnat = p0 + TP * col, pc = min(pnat, g.P - TP);
+    // Per tap: the first pixel of the lane's shifted run, clamped into the plane (so that no load leaves the tensor), and per pixel j
+    // of the run a 2-bit source code: the index of the loaded element that holds pixel p + off_t (j itself unless the clamp moved
+    // the run: at the first / last rows of a plane a run can be partly inside the image with its start outside the plane), or 3 =
+    // outside the image (zero padding).  Made once; sel[0] holds taps 0-4, sel[1] taps 5-8.
+    int poff[9];
+    unsigned sel[2] = {0u, 0u};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+        const int want = pc + dy * g.W + dx;
+        poff[t] = min(max(want, 0), g.P - TP);
+        const int delta = want - poff[t];
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int p = pc + j, y = p / g.W, x = p - y * g.W;
+            const bool ok = (unsigned)(y + dy) < (unsigned)g.H && (unsigned)(x + dx) < (unsigned)g.W;
+            const int src = j + delta;                      // inside [0, TP) whenever ok (the source pixel lies in the plane)
+            const unsigned code = (ok && src >= 0 && src < TP) ? (unsigned)src : 3u;
+            sel[t / 5] |= code << (2 * ((t % 5) * TP + j));
+        }
+    }
+    // every access = wave-uniform base (scalar registers) + per-lane 32-bit byte offset: the loads take the
+    // `global_load v, v_off, s[base]` form and the unrolled tap loop holds no per-lane 64-bit addresses
+    const float *xb = X + (size_t)b * g.x_batch;                                     // + (16 blk + r) * P   (uniform)
+    unsigned xoff[9];                                                                // bytes: 8 kh rows + the tap's shifted run
+#pragma unroll
+    for (int t = 0; t < 9; ++t) xoff[t] = 4u * (unsigned)(8 * kh * g.P + poff[t]);
+    const size_t img = (size_t)9 * g.O * g.I;                                         // elements per weight image
+    unsigned woff[TO];                                                               // bytes: the lane's weight row + its k half
+#pragma unroll
+    for (int a = 0; a < TO; ++a) woff[a] = 2u * (unsigned)(min(o0 + 32 * a + col, g.O - 1) * g.I + 8 * kh);
+    const int nblk = g.I / 16;
+    const size_t tstride = (size_t)g.O * g.I;
+    uint4 wa[2][TO][3];
+    FVec<TP> xv[2][8];
+    // iteration it = 9 blk + t runs on buffer it & 1; the fetch of it + 1 is in flight while it is consumed
+    auto fetch = [&](uint4 (&A)[TO][3], FVec<TP> (&Xv)[8], int blk, int t) {
+        const int kb = 16 * min(blk, nblk - 1);             // past the end: the last block again, dropped
+        const char *src = reinterpret_cast<const char *>(xb + (size_t)kb * g.P);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            Xv[r] = *reinterpret_cast<const FVec<TP> *>(src + (size_t)r * 4u * (size_t)g.P + (size_t)xoff[t]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const char *wsrc = reinterpret_cast<const char *>(Wimg + q * img + t * tstride + kb);
+#pragma unroll
+            for (int a = 0; a < TO; ++a) A[a][q] = *reinterpret_cast<const uint4 *>(wsrc + (size_t)woff[a]);
+        }
+    };
+    auto consume = [&](const uint4 (&A)[TO][3], const FVec<TP> (&Xv)[8], int t) {
+        uint4 bq[TP][3];
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const unsigned code = (sel[t / 5] >> (2 * ((t % 5) * TP + j))) & 3u;
+            float f[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float v = 0.f;
+#pragma unroll
+                for (int e = 0; e < TP; ++e) v = code == (unsigned)e ? Xv[r].v[e] : v;
+                f[r] = v;
+            }
+            bf16x3::split3(f[0], f[1], bq[j][0].x, bq[j][1].x, bq[j][2].x);
+            bf16x3::split3(f[2], f[3], bq[j][0].y, bq[j][1].y, bq[j][2].y);
+            bf16x3::split3(f[4], f[5], bq[j][0].z, bq[j][1].z, bq[j][2].z);
+            bf16x3::split3(f[6], f[7], bq[j][0].w, bq[j][1].w, bq[j][2].w);
+        }
+#pragma unroll
+        for (int a = 0; a < TO; ++a)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) acc[a][j] = bf16x3::mfma6(A[a], bq[j], acc[a][j]);
+    };
+    auto block = [&](int blk, int par) {                    // par = (9 blk) & 1: the buffer of the block's first tap
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int cur = (t + par) & 1;
+            if (t < 8) fetch(wa[cur ^ 1], xv[cur ^ 1], blk, t + 1);
+            else fetch(wa[cur ^ 1], xv[cur ^ 1], blk + 1, 0);
+            consume(wa[cur], xv[cur], t);
+        }
+    };
+    fetch(wa[0], xv[0], 0, 0);
+    int blk = 0;
+#pragma unroll 1
+    for (; blk + 2 <= nblk; blk += 2) {
+        block(blk, 0);
+        block(blk + 1, 1);
+    }
+    if (blk < nblk) block(blk, 0);
+    float *yb = Y + (size_t)b * g.y_batch + pc;
+#pragma unroll
+    for (int a = 0; a < TO; ++a) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (o >= g.O) continue;
+            const float bv = bias ? bias[o] : 0.f;
+            float *dst = yb + (size_t)o * g.P;
+            if (pc == pnat) {
+                FVec<TP> v;
+#pragma unroll
+                for (int j = 0; j < TP; ++j) v.v[j] = acc[a][j][r] + bv;
+                *reinterpret_cast<FVec<TP> *>(dst) = v;
+            } else {
+#pragma unroll
+                for (int j = 0; j < TP; ++j)
+                    if (pc + j >= pnat) dst[j] = acc[a][j][r] + bv;
+            }
+        }
+    }
+}
+
+template <int TO, int TP>
+void launch(const float *x, const unsigned short *wimg, const float *bias, float *y, const C3Geom &g, hipStream_t st)
+{
+    const dim3 grid((g.P + 32 * TP - 1) / (32 * TP), (g.O + 32 * TO - 1) / (32 * TO), g.B);
+    hipLaunchKernelGGL((conv3x3_kernel<TO, TP>), grid, dim3(64), 0, st, x, wimg, bias, y, g);
+}
+
+}  // namespace
+
+extern "C" int mlagg_conv3x3_supported(int O, int I, int H, int W)
+{
+    return O > 0 && I > 0 && (I % 16) == 0 && H > 0 && W > 0 && (long)H * W >= 96 && (long)H * W < (1L << 30);
+}
+
+// bytes of the weight image: 3 pieces x 9 taps x O x I bf16
+extern "C" size_t mlagg_conv3x3_workspace_bytes(int O, int I) { return O > 0 && I > 0 ? (size_t)3 * 9 * O * I * 2 : 0; }
+
+// y (B, O, H, W) = conv3x3(x (B, I, H, W), w) (+ bias).  transposed == 0: w is (O, I, 3, 3), the forward.  transposed != 0: w is the
+// forward weight (I, O, 3, 3) of the layer whose DATA GRADIENT this is (x = dy of that layer, O = its input channels).
+extern "C" int mlagg_conv3x3_fwd(const float *x, long x_batch, const float *w, int transposed, const float *bias, float *y,
+                                 long y_batch, void *workspace, int B, int O, int I, int H, int W, void *stream)
+{
+    if (!x || !w || !y || !workspace) return MLAGG_E_NULLPTR;
+    if (B <= 0 || B > 65535 || !mlagg_conv3x3_supported(O, I, H, W)) return MLAGG_E_UNSUPPORTED;
+    const long P = (long)H * W;
+    if (x_batch < (long)I * P || y_batch < (long)O * P || (reinterpret_cast<uintptr_t>(workspace) & 15)) return MLAGG_E_UNSUPPORTED;
+    C3Geom g{B, O, I, H, W, (int)P, x_batch, y_batch};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MLAGG_TIMED(K_CONV3X3, st);
+    unsigned short *img = static_cast<unsigned short *>(workspace);
+    const int n = 9 * O * I;
+    hipLaunchKernelGGL(conv3x3_weight_image_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, img, O, I, transposed ? 1 : 0);
+    int to = O <= 32 ? 1 : (O <= 64 ? 2 : 3), tp = O <= 64 ? 3 : 2;
+    static const char *env = getenv("MLAGG_K19_TILE");
+    if (env && env[0] >= '1' && env[0] <= '3' && env[1] == ',' && env[2] >= '1' && env[2] <= '3') {
+        to = env[0] - '0';
+        tp = env[2] - '0';
+        if (32 * (to - 1) >= O) to = (O + 31) / 32;
+    }
+    switch (to * 4 + tp) {
+    case 1 * 4 + 1: launch<1, 1>(x, img, bias, y, g, st); break;
+    case 1 * 4 + 2: launch<1, 2>(x, img, bias, y, g, st); break;
+    case 1 * 4 + 3: launch<1, 3>(x, img, bias, y, g, st); break;
+    case 2 * 4 + 1: launch<2, 1>(x, img, bias, y, g, st); break;
+    case 2 * 4 + 2: launch<2, 2>(x, img, bias, y, g, st); break;
+    case 2 * 4 + 3: launch<2, 3>(x, img, bias, y, g, st); break;
+    case 3 * 4 + 1: launch<3, 1>(x, img, bias, y, g, st); break;
+    case 3 * 4 + 2: launch<3, 2>(x, img, bias, y, g, st); break;
+    default: launch<3, 3>(x, img, bias, y, g, st); break;
+    }
+    return (int)hipGetLastError();
+}

@@ -158,6 +158,8 @@ class Conv2d(_ConvMixin, nn.Conv2d):
     def _fp32_conv(self, x):
         if ops.conv1x1_supported(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
             return ops.conv1x1(x, self.weight)                       # K18
+        if ops.conv3x3_supported(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
+            return ops.conv3x3(x, self.weight)                       # K19
         if self.groups == 1 and ops.K15_2D and tuple(self.dilation) == (1, 1):
             return ops.conv_nd(x, self.weight, self.stride, self.padding)
         return self._lib_conv(x, self.weight)

@@ -1617,6 +1617,76 @@ def conv1x1(x, weight):
     return Conv1x1Fn.apply(x, weight)
 
 
+K19 = _os.environ.get("MLAGG_K19", "1") == "1"
+K19_MIN_PIXELS = int(_os.environ.get("MLAGG_K19_MIN_PIXELS", "4096"))
+
+
+def _k19_product(O, I, H, W):
+    """forward-form 3 x 3 product (O output channels, contraction I) on K19?  (the data gradient asks with O and I exchanged)"""
+    return K19 and H * W >= K19_MIN_PIXELS and bool(_lib.lib().mlagg_conv3x3_supported(O, I, H, W))
+
+
+def _conv3x3_k19(x, xb, w, transposed, O, I, H, W):
+    lib = _lib.lib()
+    B = x.shape[0]
+    y = torch.empty(B, O, H, W, device=x.device, dtype=torch.float32)
+    ws = torch.empty(lib.mlagg_conv3x3_workspace_bytes(O, I), device=x.device, dtype=torch.uint8)
+    _lib.check(lib.mlagg_conv3x3_fwd(_ptr(x), xb, _ptr(w), int(transposed), None, _ptr(y), O * H * W, _ptr(ws), B, O, I, H, W, _stream()),
+               "mlagg_conv3x3_fwd")
+    return y
+
+
+class Conv3x3Fn(torch.autograd.Function):
+    """y = conv2d(x, W, padding=1) for a dense 3 x 3 kernel (stride 1, no bias): forward and data gradient on K19 (nine shifted
+    split-bf16 GEMMs straight on the NCHW maps) where it beats the library's Winograd kernels, the weight gradient on the library."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x, xb, P = _planes(x, "x")
+        B, I, H, W = x.shape
+        O = weight.shape[0]
+        w = _require(weight.contiguous(), "weight")
+        if _k19_product(O, I, H, W):
+            y = _conv3x3_k19(x, xb, w, False, O, I, H, W)
+        else:
+            y = torch.nn.functional.conv2d(x, w, None, 1, 1)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, I, H, W = x.shape
+        O = w.shape[0]
+        dx = dW = None
+        if ctx.needs_input_grad[0]:
+            if _k19_product(I, O, H, W):
+                dy, dyb, _ = _planes(dy, "dy")
+                dx = _conv3x3_k19(dy, dyb, w, True, I, O, H, W)
+            else:
+                dx = torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (True, False, False))[0]
+        if ctx.needs_input_grad[1]:
+            dW = torch.ops.aten.convolution_backward(dy.contiguous(), x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                     (False, True, False))[1]
+        return dx, dW
+
+
+def conv3x3_supported(x, weight, stride, padding, dilation, groups):
+    """A dense 3 x 3, stride-1, padding-1 fp32 convolution on the device whose forward or data gradient runs on K19."""
+    if not (K19 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and groups == 1):
+        return False
+    if tuple(weight.shape[2:]) != (3, 3) or any(int(v) != 1 for v in stride) or any(int(v) != 1 for v in padding) or \
+            any(int(v) != 1 for v in dilation):
+        return False
+    O, I = int(weight.shape[0]), int(weight.shape[1])
+    H, W = int(x.shape[2]), int(x.shape[3])
+    return _k19_product(O, I, H, W) or _k19_product(I, O, H, W)
+
+
+def conv3x3(x, weight):
+    return Conv3x3Fn.apply(x, weight)
+
+
 def _pad_geometry(D, H, W, stride, wide=False):
     import ctypes
     Dq, Hq, Wq, guard = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_long()
