@@ -85,14 +85,13 @@ conv1x1_fwd_kernel(const float *__restrict__ X, const float *__restrict__ W, con
             const float f[8] = {Xv[0].v[j], Xv[1].v[j], Xv[2].v[j], Xv[3].v[j], Xv[4].v[j], Xv[5].v[j], Xv[6].v[j], Xv[7].v[j]};
             split8(f, bq[j]);
         }
+        uint4 aq[TO][3];
 #pragma unroll
         for (int a = 0; a < TO; ++a) {
-            uint4 aq[3];
             const float f[8] = {A[a][0].x, A[a][0].y, A[a][0].z, A[a][0].w, A[a][1].x, A[a][1].y, A[a][1].z, A[a][1].w};
-            split8(f, aq);
-#pragma unroll
-            for (int j = 0; j < TP; ++j) acc[a][j] = bf16x3::mfma6(aq, bq[j], acc[a][j]);
+            split8(f, aq[a]);
         }
+        bf16x3::mfma_tiles<TO, TP>(aq, bq, acc);
     };
     fetch(wa[0], xv[0], 0);
     int blk = 0;
@@ -176,14 +175,13 @@ conv1x1_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ X, 
             const float f[8] = {Bv[j][0].x, Bv[j][0].y, Bv[j][0].z, Bv[j][0].w, Bv[j][1].x, Bv[j][1].y, Bv[j][1].z, Bv[j][1].w};
             split8(f, bq[j]);
         }
+        uint4 aq[TO][3];
 #pragma unroll
         for (int a = 0; a < TO; ++a) {
-            uint4 aq[3];
             const float f[8] = {A[a][0].x, A[a][0].y, A[a][0].z, A[a][0].w, A[a][1].x, A[a][1].y, A[a][1].z, A[a][1].w};
-            split8(f, aq);
-#pragma unroll
-            for (int j = 0; j < TI; ++j) acc[a][j] = bf16x3::mfma6(aq, bq[j], acc[a][j]);
+            split8(f, aq[a]);
         }
+        bf16x3::mfma_tiles<TO, TI>(aq, bq, acc);
     };
     if (nblk > 0) {
         fetch(av[0], bv[0], 0);

@@ -23,6 +23,7 @@
 namespace {
 
 using bf16x3::f32x16;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // native vector: HIP's uint4 (a struct) kept register arrays on the stack
 
 template <int T>
 struct __attribute__((packed, aligned(4))) FVec {
@@ -51,13 +52,24 @@ conv3x3_weight_image_kernel(const float *__restrict__ w, unsigned short *__restr
     img[2 * n + idx] = (unsigned short)(lo & 0xffff);
 }
 
+constexpr int WAVES = 4;            // pixel groups per workgroup: they share the weight stage in LDS
+
 template <int TO, int TP>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64 * WAVES, 2)
 conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Wimg, const float *__restrict__ bias,
                float *__restrict__ Y, C3Geom g)
 {
-    const int lane = threadIdx.x, col = lane & 31, kh = lane >> 5;
-    const int p0 = blockIdx.x * (32 * TP), o0 = blockIdx.y * (32 * TO), b = blockIdx.z;
+    // Weight stage: the three taps of one kernel row for one 16-channel block, all three bf16 pieces, the workgroup's 32 TO output
+    // channels: [tap][piece][row][k half] x 16 bytes, double-buffered (2 x 9 x 32 TO x 32 B = 54 KB at TO = 3).  The four waves read
+    // their A operands from it (one conflict-free ds_read_b128 per tile and piece) -- from global memory every wave fetched the same
+    // 9 KB per tap, more than the x rows, and the first form of this kernel was bound by L1 bandwidth (its rate followed bytes per
+    // MFMA across tile shapes: tools/bench_conv3x3.py with MLAGG_K19_TILE).
+    constexpr int ROWS = 32 * TO;
+    constexpr int STAGE = 3 * 3 * ROWS * 2;                 // uint4 per stage
+    constexpr int WL = (STAGE + 64 * WAVES - 1) / (64 * WAVES);
+    __shared__ u32x4 sW[2][STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, kh = lane >> 5;
+    const int p0 = (blockIdx.x * WAVES + wave) * (32 * TP), o0 = blockIdx.y * ROWS, b = blockIdx.z;
     f32x16 acc[TO][TP];
 #pragma unroll
     for (int a = 0; a < TO; ++a)
@@ -65,7 +77,8 @@ conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ W
         for (int j = 0; j < TP; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][j][r] = 0.f;
-    const int pnat = p0 + TP * col, pc = min(pnat, g.P - TP);
+    // a pixel group past the end of the plane (grid rounding) works on the last run again and stores nothing
+    const int pnat = p0 + TP * col, pc = max(min(pnat, g.P - TP), 0);
     // Per tap: the first pixel of the lane's shifted run, clamped into the plane (so that no load leaves the tensor), and per pixel j
     // of the run a 2-bit source code: the index of the loaded element that holds pixel p + off_t (j itself unless the clamp moved
     // the run: at the first / last rows of a plane a run can be partly inside the image with its start outside the plane), or 3 =
@@ -87,35 +100,46 @@ conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ W
             sel[t / 5] |= code << (2 * ((t % 5) * TP + j));
         }
     }
-    // every access = wave-uniform base (scalar registers) + per-lane 32-bit byte offset: the loads take the
-    // `global_load v, v_off, s[base]` form and the unrolled tap loop holds no per-lane 64-bit addresses
+    // every global access = wave-uniform base (scalar registers) + per-lane 32-bit byte offset
     const float *xb = X + (size_t)b * g.x_batch;                                     // + (16 blk + r) * P   (uniform)
     unsigned xoff[9];                                                                // bytes: 8 kh rows + the tap's shifted run
 #pragma unroll
     for (int t = 0; t < 9; ++t) xoff[t] = 4u * (unsigned)(8 * kh * g.P + poff[t]);
     const size_t img = (size_t)9 * g.O * g.I;                                         // elements per weight image
-    unsigned woff[TO];                                                               // bytes: the lane's weight row + its k half
-#pragma unroll
-    for (int a = 0; a < TO; ++a) woff[a] = 2u * (unsigned)(min(o0 + 32 * a + col, g.O - 1) * g.I + 8 * kh);
-    const int nblk = g.I / 16;
     const size_t tstride = (size_t)g.O * g.I;
-    uint4 wa[2][TO][3];
+    const int nblk = g.I / 16, nstage = 3 * nblk;
+    // weight stage loader: element e = ((tt * 3 + q) * ROWS + row) * 2 + h  <-  Wimg[q][3 srow + tt][o0 + row][16 blk + 8 h ..]
+    unsigned wsrc[WL];                                                               // bytes within a (blk, kernel row) slice
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+        const int e = min(tid + 64 * WAVES * i, STAGE - 1);
+        const int h = e & 1, row = (e >> 1) % ROWS, q = ((e >> 1) / ROWS) % 3, tt = (e >> 1) / (3 * ROWS);
+        wsrc[i] = 2u * (unsigned)(q * img + tt * tstride + (size_t)min(o0 + row, g.O - 1) * g.I + 8 * h);
+    }
+    u32x4 wreg[WL];
+    // stage s = 3 blk + kernel row (clamped: past the end the last stage again); macros, not lambdas: captured by reference the
+    // register array stayed on the stack (scratch loads / stores around every stage)
+#define K19_WFETCH(S)                                                                                                         \
+    {                                                                                                                         \
+        const int sc_ = min((S), nstage - 1), blk_ = sc_ / 3, srow_ = sc_ - 3 * blk_;                                         \
+        const char *base_ = reinterpret_cast<const char *>(Wimg + (size_t)(3 * srow_) * tstride + 16 * blk_);                \
+        _Pragma("unroll") for (int i_ = 0; i_ < WL; ++i_) wreg[i_] = *reinterpret_cast<const u32x4 *>(base_ + (size_t)wsrc[i_]); \
+    }
+    // unconditional: the tail threads rewrite the last element with the same value (their load was clamped alike)
+#define K19_WSTORE(BUF)                                                                                                       \
+    {                                                                                                                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < WL; ++i_) sW[(BUF)][min(tid + 64 * WAVES * i_, STAGE - 1)] = wreg[i_];        \
+    }
     FVec<TP> xv[2][8];
-    // iteration it = 9 blk + t runs on buffer it & 1; the fetch of it + 1 is in flight while it is consumed
-    auto fetch = [&](uint4 (&A)[TO][3], FVec<TP> (&Xv)[8], int blk, int t) {
+    // x rows: iteration it = 9 blk + t runs on buffer it & 1; the fetch of it + 1 is in flight while it is consumed
+    auto xfetch = [&](FVec<TP> (&Xv)[8], int blk, int t) __attribute__((always_inline)) {
         const int kb = 16 * min(blk, nblk - 1);             // past the end: the last block again, dropped
         const char *src = reinterpret_cast<const char *>(xb + (size_t)kb * g.P);
 #pragma unroll
         for (int r = 0; r < 8; ++r)
             Xv[r] = *reinterpret_cast<const FVec<TP> *>(src + (size_t)r * 4u * (size_t)g.P + (size_t)xoff[t]);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const char *wsrc = reinterpret_cast<const char *>(Wimg + q * img + t * tstride + kb);
-#pragma unroll
-            for (int a = 0; a < TO; ++a) A[a][q] = *reinterpret_cast<const uint4 *>(wsrc + (size_t)woff[a]);
-        }
     };
-    auto consume = [&](const uint4 (&A)[TO][3], const FVec<TP> (&Xv)[8], int t) {
+    auto consume = [&](const u32x4 *wst, const FVec<TP> (&Xv)[8], int t) __attribute__((always_inline)) {
         uint4 bq[TP][3];
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
@@ -133,28 +157,49 @@ conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ W
             bf16x3::split3(f[4], f[5], bq[j][0].z, bq[j][1].z, bq[j][2].z);
             bf16x3::split3(f[6], f[7], bq[j][0].w, bq[j][1].w, bq[j][2].w);
         }
+        uint4 aq[TO][3];
 #pragma unroll
         for (int a = 0; a < TO; ++a)
 #pragma unroll
-            for (int j = 0; j < TP; ++j) acc[a][j] = bf16x3::mfma6(A[a], bq[j], acc[a][j]);
+            for (int q = 0; q < 3; ++q) {
+                const u32x4 v = wst[((t % 3) * 3 + q) * ROWS * 2 + (32 * a + col) * 2 + kh];
+                aq[a][q] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+        bf16x3::mfma_tiles<TO, TP>(aq, bq, acc);
     };
-    auto block = [&](int blk, int par) {                    // par = (9 blk) & 1: the buffer of the block's first tap
+    // one stage: three taps on weight buffer s & 1 while the next stage's weights travel global -> registers, then -> LDS
+    auto stage = [&](int blk, int srow, int par) __attribute__((always_inline)) {          // par = (9 blk + 3 srow) & 1 = x buffer of the stage's first tap
+        const int s = 3 * blk + srow;
+        K19_WFETCH(s + 1)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int cur = (t + par) & 1;
-            if (t < 8) fetch(wa[cur ^ 1], xv[cur ^ 1], blk, t + 1);
-            else fetch(wa[cur ^ 1], xv[cur ^ 1], blk + 1, 0);
-            consume(wa[cur], xv[cur], t);
+        for (int tt = 0; tt < 3; ++tt) {
+            const int t = 3 * srow + tt, cur = (tt + par) & 1;
+            if (t < 8) xfetch(xv[cur ^ 1], blk, t + 1);
+            else xfetch(xv[cur ^ 1], blk + 1, 0);
+            consume(sW[s & 1], xv[cur], t);
         }
+        K19_WSTORE((s + 1) & 1)
+        __syncthreads();                                      // next stage's weights visible; this stage's buffer free for s + 2
     };
-    fetch(wa[0], xv[0], 0, 0);
+    K19_WFETCH(0)
+    K19_WSTORE(0)
+    xfetch(xv[0], 0, 0);
+    __syncthreads();
     int blk = 0;
 #pragma unroll 1
-    for (; blk + 2 <= nblk; blk += 2) {
-        block(blk, 0);
-        block(blk + 1, 1);
+    for (; blk + 2 <= nblk; blk += 2) {                    // 18 taps: x-buffer parity and weight-buffer parity both repeat
+        stage(blk, 0, 0);
+        stage(blk, 1, 1);
+        stage(blk, 2, 0);
+        stage(blk + 1, 0, 1);
+        stage(blk + 1, 1, 0);
+        stage(blk + 1, 2, 1);
     }
-    if (blk < nblk) block(blk, 0);
+    if (blk < nblk) {
+        stage(blk, 0, 0);
+        stage(blk, 1, 1);
+        stage(blk, 2, 0);
+    }
     float *yb = Y + (size_t)b * g.y_batch + pc;
 #pragma unroll
     for (int a = 0; a < TO; ++a) {
@@ -172,17 +217,21 @@ conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ W
             } else {
 #pragma unroll
                 for (int j = 0; j < TP; ++j)
-                    if (pc + j >= pnat) dst[j] = acc[a][j][r] + bv;
+                    if (pc + j >= pnat && pnat < g.P) dst[j] = acc[a][j][r] + bv;
             }
         }
     }
 }
 
+#undef K19_WFETCH
+#undef K19_WSTORE
+
 template <int TO, int TP>
 void launch(const float *x, const unsigned short *wimg, const float *bias, float *y, const C3Geom &g, hipStream_t st)
 {
-    const dim3 grid((g.P + 32 * TP - 1) / (32 * TP), (g.O + 32 * TO - 1) / (32 * TO), g.B);
-    hipLaunchKernelGGL((conv3x3_kernel<TO, TP>), grid, dim3(64), 0, st, x, wimg, bias, y, g);
+    const int groups = (g.P + 32 * TP - 1) / (32 * TP);
+    const dim3 grid((groups + WAVES - 1) / WAVES, (g.O + 32 * TO - 1) / (32 * TO), g.B);
+    hipLaunchKernelGGL((conv3x3_kernel<TO, TP>), grid, dim3(64 * WAVES), 0, st, x, wimg, bias, y, g);
 }
 
 }  // namespace
@@ -210,7 +259,14 @@ extern "C" int mlagg_conv3x3_fwd(const float *x, long x_batch, const float *w, i
     unsigned short *img = static_cast<unsigned short *>(workspace);
     const int n = 9 * O * I;
     hipLaunchKernelGGL(conv3x3_weight_image_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, img, O, I, transposed ? 1 : 0);
-    int to = O <= 32 ? 1 : (O <= 64 ? 2 : 3), tp = O <= 64 ? 3 : 2;
+    // tile per wave = (32 TO output channels) x (32 TP pixels); measured on the step's shapes (tools/bench_conv3x3.py with
+    // MLAGG_K19_TILE, profiles/round3_g_conv3x3_tiles.log): 2 x 2 (two workgroups per CU, most waves) everywhere except outputs
+    // that fill 96-channel groups exactly on large maps
+    int to = O <= 32 ? 1 : 2, tp = 2;
+    if (O % 96 == 0 && P >= 16384) {
+        to = 3;
+        tp = P >= 65536 ? 2 : 1;
+    }
     static const char *env = getenv("MLAGG_K19_TILE");
     if (env && env[0] >= '1' && env[0] <= '3' && env[1] == ',' && env[2] >= '1' && env[2] <= '3') {
         to = env[0] - '0';

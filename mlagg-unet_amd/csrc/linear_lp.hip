@@ -160,26 +160,25 @@ linear_lp_kernel(const float *__restrict__ X, const float *__restrict__ W, const
 #pragma unroll
         for (int p = 0; p < KC / 16; ++p) {
             // lane (col, kh): row 32 wave + col of A / column 32 t + col of B, k = 16 p + 8 kh .. + 8
-            uint4 a[NP];
+            uint4 a[NP], b[3][NP];
 #pragma unroll
             for (int q = 0; q < NP; ++q)
                 a[q] = *reinterpret_cast<const uint4 *>(sA + q * BM * PITCH + (32 * wave + col) * PITCH + 16 * p + 8 * kh);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                uint4 b[NP];
+            for (int t = 0; t < 3; ++t)
 #pragma unroll
                 for (int q = 0; q < NP; ++q)
-                    b[q] = *reinterpret_cast<const uint4 *>(sB + q * BN * PITCH + (32 * t + col) * PITCH + 16 * p + 8 * kh);
-                if (MODE == 2) {                             // smallest terms first
-                    acc[t] = mfma16<true>(a[NP - 1], b[0], acc[t]);          // lo . hi
-                    acc[t] = mfma16<true>(a[0], b[NP - 1], acc[t]);          // hi . lo
-                    acc[t] = mfma16<true>(a[NP > 1 ? 1 : 0], b[NP > 1 ? 1 : 0], acc[t]);      // mid . mid
-                    acc[t] = mfma16<true>(a[NP > 1 ? 1 : 0], b[0], acc[t]);  // mid . hi
-                    acc[t] = mfma16<true>(a[0], b[NP > 1 ? 1 : 0], acc[t]);  // hi . mid
-                    acc[t] = mfma16<true>(a[0], b[0], acc[t]);               // hi . hi
-                } else {
-                    acc[t] = mfma16<BF16>(a[0], b[0], acc[t]);
-                }
+                    b[t][q] = *reinterpret_cast<const uint4 *>(sB + q * BN * PITCH + (32 * t + col) * PITCH + 16 * p + 8 * kh);
+            if (MODE == 2) {
+                // the six partial products, smallest first, term-major over the three column tiles: consecutive MFMAs are independent
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        acc[t] = mfma16<true>(a[bf16x3::kTermA[term] % NP], b[t][bf16x3::kTermB[term] % NP], acc[t]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[t] = mfma16<BF16>(a[0], b[t][0], acc[t]);
             }
         }
     }

@@ -219,17 +219,16 @@ linear_wgrad_x3_kernel(const float *__restrict__ dy, const float *__restrict__ x
             bf16x3::split3(Bv[4].v[b], Bv[5].v[b], bq[b][0].z, bq[b][1].z, bq[b][2].z);
             bf16x3::split3(Bv[6].v[b], Bv[7].v[b], bq[b][0].w, bq[b][1].w, bq[b][2].w);
         }
+        uint4 aq[TO][3];
 #pragma unroll
         for (int a = 0; a < TO; ++a) {
-            uint4 aq[3];
-            bf16x3::split3(A[0].v[a], A[1].v[a], aq[0].x, aq[1].x, aq[2].x);
-            bf16x3::split3(A[2].v[a], A[3].v[a], aq[0].y, aq[1].y, aq[2].y);
-            bf16x3::split3(A[4].v[a], A[5].v[a], aq[0].z, aq[1].z, aq[2].z);
-            bf16x3::split3(A[6].v[a], A[7].v[a], aq[0].w, aq[1].w, aq[2].w);
+            bf16x3::split3(A[0].v[a], A[1].v[a], aq[a][0].x, aq[a][1].x, aq[a][2].x);
+            bf16x3::split3(A[2].v[a], A[3].v[a], aq[a][0].y, aq[a][1].y, aq[a][2].y);
+            bf16x3::split3(A[4].v[a], A[5].v[a], aq[a][0].z, aq[a][1].z, aq[a][2].z);
+            bf16x3::split3(A[6].v[a], A[7].v[a], aq[a][0].w, aq[a][1].w, aq[a][2].w);
             bsum[a] += ((A[0].v[a] + A[1].v[a]) + (A[2].v[a] + A[3].v[a])) + ((A[4].v[a] + A[5].v[a]) + (A[6].v[a] + A[7].v[a]));
-#pragma unroll
-            for (int b = 0; b < TI; ++b) acc[a][b] = bf16x3::mfma6(aq, bq[b], acc[a][b]);
         }
+        bf16x3::mfma_tiles<TO, TI>(aq, bq, acc);
     };
     if (nfull > 0) {
         fetch(av[0], bv[0], 0);

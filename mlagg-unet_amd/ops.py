@@ -1618,7 +1618,10 @@ def conv1x1(x, weight):
 
 
 K19 = _os.environ.get("MLAGG_K19", "1") == "1"
-K19_MIN_PIXELS = int(_os.environ.get("MLAGG_K19_MIN_PIXELS", "4096"))
+# K19 against MIOpen's tuned Winograd kernels (tools/bench_conv3x3.py, batch 10): 17-30 % faster from 32 x 32 maps up (48 -> 48 at
+# 256 x 256: 302 vs 416 us forward, 272 vs 356 us data gradient; 96 -> 96 at 128 x 128: 202 vs 262), slower on the 16 x 16 maps
+# (720 channels: few pixel tiles, long contractions: 315 vs 262 us)
+K19_MIN_PIXELS = int(_os.environ.get("MLAGG_K19_MIN_PIXELS", "1024"))
 
 
 def _k19_product(O, I, H, W):
