@@ -226,6 +226,164 @@ conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ W
 #undef K19_WFETCH
 #undef K19_WSTORE
 
+// ---- weight gradient: dW[o][i][t] = sum_b sum_p dy[b][o][p] x[b][i][p + off_t]  (x = 0 outside the image) ----------------------
+// The pixel is the contraction and it is contiguous in both operands (K18's weight gradient with nine shifted B operands): a wave
+// owns 32 output x 32 input channels x 9 taps (144 accumulators) and a slab of pixels of one sample; per 16-pixel block a lane reads
+// 8 consecutive pixels of its dy row once (A) and, per tap, 8 consecutive pixels of its x row shifted by the tap (B: two 16-byte
+// loads at a 4-byte-aligned address; the nine taps of a block overlap in L1).  W % 16 == 0, so a 16-pixel block lies in ONE image
+// row: the row test of a tap is wave-uniform (a kernel row whose source row is outside the image is skipped: no loads sit under
+// that branch, they were issued unconditionally with a clamped address), and the only per-element cases are the first pixel of a
+// row for dx = -1 and the last one for dx = +1.  Partials [slab][tap][o][i] (coalesced stores), summed in a fixed order into the
+// (O, I, 3, 3) layout by a second launch.
+struct W3Geom {
+    int B, O, I, H, W, P;
+    long dy_batch, x_batch;
+    int slab, nslabs;
+    long x_last;                    // last float offset from x at which an 8-float load stays inside the operand
+};
+
+__global__ void __launch_bounds__(64)
+conv3x3_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ part, W3Geom g)
+{
+    const int lane = threadIdx.x, col = lane & 31, kh = lane >> 5;
+    const int b = blockIdx.x / g.nslabs, s = blockIdx.x % g.nslabs;
+    const int o0 = blockIdx.y * 32, i0 = blockIdx.z * 32;
+    f32x16 acc[1][9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][t][r] = 0.f;
+    const int pb = s * g.slab, pe = min(pb + g.slab, g.P);
+    const int nblk = (pe - pb) / 16;
+    const int oc = min(o0 + col, g.O - 1), ic = min(i0 + col, g.I - 1);
+    const float *ap = dY + (size_t)b * g.dy_batch + (size_t)oc * g.P + pb + 8 * kh;          // + 16 blk
+    const long xrow = (long)b * g.x_batch + (long)ic * g.P + pb + 8 * kh;                      // float offset of the lane's run, + 16 blk
+    // iteration = (blk, kernel row): A (row 0 only) + the ten pixels p - 1 .. p + 8 of the source row (the aligned run as two
+    // 16-byte loads + its two neighbours); double-buffered.  The ten values are split ONCE into five dwords per bf16 piece --
+    // pairs (p-1, p), (p+1, p+2) .. (p+7, p+8) -- which ARE the operands of the taps dx = -1 (dwords 0-3) and dx = +1 (dwords 1-4);
+    // the centre tap's pairs (p, p+1) .. are one v_alignbit_b32 each.  (Splitting every tap's run separately made the kernel
+    // VALU-bound: 680 instead of 250 vector instructions per block, 45-85 TFLOP/s.)
+    float4 av[2][2], bv[2][2];
+    float be[2][2];                                             // x[p - 1], x[p + 8]
+    auto fetch = [&](float4 (&A)[2], float4 (&Bv)[2], float (&E)[2], int blk, int ky) __attribute__((always_inline)) {
+        const int bc = min(blk, nblk - 1);
+        if (ky == 0) {
+            A[0] = *reinterpret_cast<const float4 *>(ap + 16 * bc);
+            A[1] = *reinterpret_cast<const float4 *>(ap + 16 * bc + 4);
+        }
+        // clamped into the operand: a displaced address only occurs for a source row outside the image (skipped) or for the two
+        // neighbours at the operand's very first / last float, which are the zero-padded ones
+        const long want = xrow + 16 * bc + (long)(ky - 1) * g.W;
+        const long at = min(max(want, 0L), g.x_last);
+        Bv[0] = *reinterpret_cast<const float4 *>(X + at);
+        Bv[1] = *reinterpret_cast<const float4 *>(X + at + 4);
+        E[0] = X[min(max(want - 1, 0L), g.x_last + 7)];
+        E[1] = X[min(max(want + 8, 0L), g.x_last + 7)];
+    };
+    uint4 aq[1][3];
+    auto consume = [&](const float4 (&A)[2], const float4 (&Bv)[2], const float (&E)[2], int blk, int ky) __attribute__((always_inline)) {
+        if (ky == 0) {
+            const float f[8] = {A[0].x, A[0].y, A[0].z, A[0].w, A[1].x, A[1].y, A[1].z, A[1].w};
+            bf16x3::split3(f[0], f[1], aq[0][0].x, aq[0][1].x, aq[0][2].x);
+            bf16x3::split3(f[2], f[3], aq[0][0].y, aq[0][1].y, aq[0][2].y);
+            bf16x3::split3(f[4], f[5], aq[0][0].z, aq[0][1].z, aq[0][2].z);
+            bf16x3::split3(f[6], f[7], aq[0][0].w, aq[0][1].w, aq[0][2].w);
+        }
+        const int p = pb + 16 * blk;                            // wave-uniform: the block lies in one image row
+        const int y = p / g.W, xb = p - y * g.W;
+        if ((unsigned)(y + ky - 1) >= (unsigned)g.H) return;     // source row outside the image: the three taps add nothing
+        const float left = (kh == 0 && xb == 0) ? 0.f : E[0];                               // left neighbour of the row's first pixel
+        const float right = (kh == 1 && xb + 16 == g.W) ? 0.f : E[1];                       // right neighbour of its last pixel
+        unsigned d[3][5];                                        // [piece][pair]: (p-1, p), (p+1, p+2), (p+3, p+4), (p+5, p+6), (p+7, p+8)
+        bf16x3::split3(left, Bv[0].x, d[0][0], d[1][0], d[2][0]);
+        bf16x3::split3(Bv[0].y, Bv[0].z, d[0][1], d[1][1], d[2][1]);
+        bf16x3::split3(Bv[0].w, Bv[1].x, d[0][2], d[1][2], d[2][2]);
+        bf16x3::split3(Bv[1].y, Bv[1].z, d[0][3], d[1][3], d[2][3]);
+        bf16x3::split3(Bv[1].w, right, d[0][4], d[1][4], d[2][4]);
+        uint4 bq[3][3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            bq[0][q] = make_uint4(d[q][0], d[q][1], d[q][2], d[q][3]);                                          // dx = -1
+            bq[2][q] = make_uint4(d[q][1], d[q][2], d[q][3], d[q][4]);                                          // dx = +1
+            bq[1][q] = make_uint4(__builtin_amdgcn_alignbit(d[q][1], d[q][0], 16), __builtin_amdgcn_alignbit(d[q][2], d[q][1], 16),
+                                  __builtin_amdgcn_alignbit(d[q][3], d[q][2], 16), __builtin_amdgcn_alignbit(d[q][4], d[q][3], 16));
+        }
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+                acc[0][3 * ky + kx] = bf16x3::mfma(aq[0][bf16x3::kTermA[term]], bq[kx][bf16x3::kTermB[term]], acc[0][3 * ky + kx]);
+    };
+    if (nblk > 0) {
+        fetch(av[0], bv[0], be[0], 0, 0);
+#pragma unroll 1
+        for (int blk = 0; blk < nblk; blk += 2) {              // six iterations: buffer parity repeats every two blocks
+            fetch(av[1], bv[1], be[1], blk, 1);
+            consume(av[0], bv[0], be[0], blk, 0);
+            fetch(av[0], bv[0], be[0], blk, 2);
+            consume(av[0], bv[1], be[1], blk, 1);
+            fetch(av[1], bv[1], be[1], blk + 1, 0);
+            consume(av[0], bv[0], be[0], blk, 2);
+            if (blk + 1 < nblk) {
+                fetch(av[0], bv[0], be[0], blk + 1, 1);
+                consume(av[1], bv[1], be[1], blk + 1, 0);
+                fetch(av[1], bv[1], be[1], blk + 1, 2);
+                consume(av[1], bv[0], be[0], blk + 1, 1);
+                fetch(av[0], bv[0], be[0], blk + 2, 0);
+                consume(av[1], bv[1], be[1], blk + 1, 2);
+            }
+        }
+    }
+    // partial [slab][tap][O][I]: D row R -> output channel o0 + R, column = lane -> input channel i0 + col
+    float *prow = part + (size_t)blockIdx.x * ((size_t)9 * g.O * g.I);
+    const int i = i0 + col;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (o < g.O && i < g.I) prow[((size_t)t * g.O + o) * g.I + i] = acc[0][t][r];
+        }
+}
+
+// dW[(o, i, t)] = sum over partial blocks of part[s][t][o][i], fixed order
+__global__ void __launch_bounds__(256)
+conv3x3_wgrad_reduce_kernel(const float *__restrict__ part, int nparts, int O, int I, float *__restrict__ dW)
+{
+    const int n = 9 * O * I;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;        // (t, o, i): the partial layout, coalesced reads
+    if (idx >= n) return;
+    float s0 = 0.f, s1 = 0.f;
+    int sidx = 0;
+    for (; sidx + 1 < nparts; sidx += 2) {
+        s0 += part[(size_t)sidx * n + idx];
+        s1 += part[(size_t)(sidx + 1) * n + idx];
+    }
+    if (sidx < nparts) s0 += part[(size_t)sidx * n + idx];
+    const int i = idx % I, o = (idx / I) % O, t = idx / (I * O);
+    dW[((size_t)o * I + i) * 9 + t] = s0 + s1;
+}
+
+int make_w3geom(W3Geom &g, int B, int O, int I, int H, int W, long dy_batch, long x_batch)
+{
+    if (B <= 0 || O <= 0 || I <= 0 || H <= 0 || W <= 0 || (W & 15)) return MLAGG_E_UNSUPPORTED;
+    const long P = (long)H * W;
+    if (P >= (1L << 30) || dy_batch < (long)O * P || x_batch < (long)I * P || ((dy_batch | x_batch) & 3)) return MLAGG_E_UNSUPPORTED;
+    g = W3Geom{B, O, I, H, W, (int)P, dy_batch, x_batch, 0, 0, (long)(B - 1) * x_batch + (long)I * P - 8};
+    const int og = (O + 31) / 32, ig = (I + 31) / 32;
+    static const int target = [] { const char *e = getenv("MLAGG_K19W_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2048; }();
+    int per_sample = (target + B * og * ig - 1) / (B * og * ig);
+    if (per_sample < 1) per_sample = 1;
+    int slab = (int)((P + per_sample - 1) / per_sample);
+    slab = ((slab + 15) / 16) * 16;
+    if (slab < 64) slab = 64;
+    g.slab = slab;
+    g.nslabs = (int)((P + slab - 1) / slab);
+    if ((long)B * g.nslabs > 2147483647L || og > 65535 || ig > 65535) return MLAGG_E_UNSUPPORTED;
+    return 0;
+}
+
+
 template <int TO, int TP>
 void launch(const float *x, const unsigned short *wimg, const float *bias, float *y, const C3Geom &g, hipStream_t st)
 {
@@ -284,5 +442,31 @@ extern "C" int mlagg_conv3x3_fwd(const float *x, long x_batch, const float *w, i
     case 3 * 4 + 2: launch<3, 2>(x, img, bias, y, g, st); break;
     default: launch<3, 3>(x, img, bias, y, g, st); break;
     }
+    return (int)hipGetLastError();
+}
+
+extern "C" int mlagg_conv3x3_wgrad_supported(int O, int I, int H, int W) { return O > 0 && I > 0 && H > 0 && W >= 16 && (W % 16) == 0; }
+
+extern "C" size_t mlagg_conv3x3_wgrad_workspace_floats(int B, int O, int I, int H, int W)
+{
+    W3Geom g;
+    if (make_w3geom(g, B, O, I, H, W, (long)O * H * W, (long)I * H * W)) return 0;
+    return (size_t)B * g.nslabs * 9 * O * I;
+}
+
+// dW (O, I, 3, 3) = weight gradient of y = conv3x3(x, w, padding 1) from dy (B, O, H, W) and x (B, I, H, W); overwritten
+extern "C" int mlagg_conv3x3_wgrad(const float *dy, long dy_batch, const float *x, long x_batch, float *dW, float *workspace, int B,
+                                   int O, int I, int H, int W, void *stream)
+{
+    if (!dy || !x || !dW || !workspace) return MLAGG_E_NULLPTR;
+    W3Geom g;
+    if (int rc = make_w3geom(g, B, O, I, H, W, dy_batch, x_batch)) return rc;
+    if ((reinterpret_cast<uintptr_t>(dy) & 15) || (reinterpret_cast<uintptr_t>(x) & 3)) return MLAGG_E_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MLAGG_TIMED(K_CONV3X3, st);
+    const dim3 grid(B * g.nslabs, (O + 31) / 32, (I + 31) / 32);
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(64), 0, st, dy, x, workspace, g);
+    const int n = 9 * O * I;
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, workspace, B * g.nslabs, O, I, dW);
     return (int)hipGetLastError();
 }

@@ -1624,6 +1624,18 @@ K19 = _os.environ.get("MLAGG_K19", "1") == "1"
 K19_MIN_PIXELS = int(_os.environ.get("MLAGG_K19_MIN_PIXELS", "1024"))
 
 
+K19_WGRAD = _os.environ.get("MLAGG_K19_WGRAD", "1") == "1"
+K19_WGRAD_MIN_PIXELS = int(_os.environ.get("MLAGG_K19_WGRAD_MIN_PIXELS", "1024"))
+
+
+def _k19_wgrad(O, I, H, W):
+    """3 x 3 weight gradient on K19?  Measured against MIOpen's implicit-GEMM kernels + their NHWC transposes (tools/bench_conv3x3.py):
+    706 vs 816, 280 vs 323, 175 vs 205, 190 vs 212 us where a channel extent reaches 96 (32-channel tiles are then well filled);
+    48 x 48 channels fill 56 % of a tile pair and lose or tie (492 vs 493, 179 vs 119 us), 16 x 16 maps tie."""
+    return (K19_WGRAD and H * W >= K19_WGRAD_MIN_PIXELS and max(O, I) >= 96 and
+            bool(_lib.lib().mlagg_conv3x3_wgrad_supported(O, I, H, W)))
+
+
 def _k19_product(O, I, H, W):
     """forward-form 3 x 3 product (O output channels, contraction I) on K19?  (the data gradient asks with O and I exchanged)"""
     return K19 and H * W >= K19_MIN_PIXELS and bool(_lib.lib().mlagg_conv3x3_supported(O, I, H, W))
@@ -1669,8 +1681,16 @@ class Conv3x3Fn(torch.autograd.Function):
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (True, False, False))[0]
         if ctx.needs_input_grad[1]:
-            dW = torch.ops.aten.convolution_backward(dy.contiguous(), x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
-                                                     (False, True, False))[1]
+            lib = _lib.lib()
+            if _k19_wgrad(O, I, H, W):
+                dy, dyb, _ = _planes(dy, "dy")
+                dW = torch.empty(O, I, 3, 3, device=x.device, dtype=torch.float32)
+                ws = torch.empty(lib.mlagg_conv3x3_wgrad_workspace_floats(B, O, I, H, W), device=x.device, dtype=torch.float32)
+                _lib.check(lib.mlagg_conv3x3_wgrad(_ptr(dy), dyb, _ptr(x), x.stride(0), _ptr(dW), _ptr(ws), B, O, I, H, W, _stream()),
+                           "mlagg_conv3x3_wgrad")
+            else:
+                dW = torch.ops.aten.convolution_backward(dy.contiguous(), x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                         (False, True, False))[1]
         return dx, dW
 
 

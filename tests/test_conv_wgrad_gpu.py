@@ -148,7 +148,8 @@ def test_conv1x1_dispatch_rules_and_large_map():
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,I,O,H,W,sliced", [(2, 48, 48, 16, 16, False), (2, 96, 48, 12, 20, True), (1, 144, 144, 10, 10, False),
                                               (2, 16, 40, 9, 13, False), (1, 48, 96, 3, 32, False), (2, 32, 14, 24, 5, False),
-                                              (1, 48, 48, 128, 128, False)])
+                                              (1, 48, 48, 128, 128, False), (3, 48, 33, 6, 16, True), (2, 16, 16, 2, 48, False),
+                                              (2, 80, 48, 7, 64, False)])
 def test_conv3x3_matches_float64(monkeypatch, B, I, O, H, W, sliced):
     """K19 (3 x 3 convolution as nine shifted split-bf16 GEMMs): output and data gradient against float64 conv2d at the error of an
     fp32 convolution.  Cases: widths that are not multiples of the lanes' pixel runs (runs straddle image rows), three-row images,
@@ -156,6 +157,7 @@ def test_conv3x3_matches_float64(monkeypatch, B, I, O, H, W, sliced):
     output widths off the 32-channel tiles, and one full-size map."""
     from mlagg_unet_amd import ops
     monkeypatch.setattr(ops, "K19_MIN_PIXELS", 0)
+    monkeypatch.setattr(ops, "_k19_wgrad", lambda O, I, H, W: W % 16 == 0)      # the weight gradient too where the kernel supports it
     g = torch.Generator().manual_seed(B * I + O + H)
     wide = torch.randn(B, I + 16, H, W, generator=g).to(DEV)
     x = (wide[:, 8:8 + I] if sliced else wide[:, :I].contiguous()).detach()
@@ -168,6 +170,6 @@ def test_conv3x3_matches_float64(monkeypatch, B, I, O, H, W, sliced):
     xp, wp = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     yp = ops.conv3x3(xp, wp)
     yp.backward(gy)
-    for name, got, want, tol in (("y", yp, yr, 2e-6), ("dx", xp.grad, xr.grad, 2e-6), ("dW", wp.grad, wr.grad, 2e-5)):
+    for name, got, want, tol in (("y", yp, yr, 2e-6), ("dx", xp.grad, xr.grad, 2e-6), ("dW", wp.grad, wr.grad, 4e-6)):
         err = float((got.detach().double() - want.detach()).abs().max() / want.detach().abs().max())
         assert err < tol, (name, err)

@@ -32,7 +32,7 @@ def main():
     lib = _lib.lib()
     st = torch.cuda.current_stream().cuda_stream
     B = 10
-    print(f"{'(I, O, H)':20s} {'fwd K19':>8s} {'TF/s':>6s} {'MIOpen':>8s} | {'dgrad':>8s} {'TF/s':>6s} {'MIOpen':>8s} | {'wgrad MIOpen':>12s}")
+    print(f"{'(I, O, H)':20s} {'fwd K19':>8s} {'TF/s':>6s} {'MIOpen':>8s} | {'dgrad':>8s} {'TF/s':>6s} {'MIOpen':>8s} | {'wgrad':>8s} {'TF/s':>6s} {'MIOpen':>8s}")
     tot = [0.0] * 4
     for I, O, H in SHAPES:
         P = H * H
@@ -51,9 +51,14 @@ def main():
         assert float((dx - dref).abs().max()) < 1e-3
         dm = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (True, False, False)))
         gm = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False)))
+        dW = torch.empty(O, I, 3, 3, device=DEV)
+        wws = torch.empty(lib.mlagg_conv3x3_wgrad_workspace_floats(B, O, I, H, H), device=DEV)
+        gk = timeit(lambda: _lib.check(lib.mlagg_conv3x3_wgrad(gy.data_ptr(), O * P, x.data_ptr(), I * P, dW.data_ptr(), wws.data_ptr(), B, O, I, H, H, st), "g"))
+        wref = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False))[1]
+        assert float((dW - wref).abs().max()) < 2e-3 * float(wref.abs().max()), float((dW - wref).abs().max())
         for i, v in enumerate((f, fm, d, dm)):
             tot[i] += v
-        print(f"{str((I, O, H)):20s} {f:8.1f} {fl / f / 1e6:6.1f} {fm:8.1f} | {d:8.1f} {fl / d / 1e6:6.1f} {dm:8.1f} | {gm:12.1f}", flush=True)
+        print(f"{str((I, O, H)):20s} {f:8.1f} {fl / f / 1e6:6.1f} {fm:8.1f} | {d:8.1f} {fl / d / 1e6:6.1f} {dm:8.1f} | {gk:8.1f} {fl / gk / 1e6:6.1f} {gm:8.1f}", flush=True)
     print("totals us: fwd %.0f (MIOpen %.0f)  dgrad %.0f (MIOpen %.0f)" % tuple(tot))
 
 
