@@ -79,32 +79,25 @@ conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ W
             for (int r = 0; r < 16; ++r) acc[a][j][r] = 0.f;
     // a pixel group past the end of the plane (grid rounding) works on the last run again and stores nothing
     const int pnat = p0 + TP * col, pc = max(min(pnat, g.P - TP), 0);
-    // Per tap: the first pixel of the lane's shifted run, clamped into the plane (so that no load leaves the tensor), and per pixel j
-    // of the run a 2-bit source code: the index of the loaded element that holds pixel p + off_t (j itself unless the clamp moved
-    // the run: at the first / last rows of a plane a run can be partly inside the image with its start outside the plane), or 3 =
-    // outside the image (zero padding).  Made once; sel[0] holds taps 0-4, sel[1] taps 5-8.
-    int poff[9];
-    unsigned sel[2] = {0u, 0u};
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int dy = t / 3 - 1, dx = t % 3 - 1;
-        const int want = pc + dy * g.W + dx;
-        poff[t] = min(max(want, 0), g.P - TP);
-        const int delta = want - poff[t];
-#pragma unroll
-        for (int j = 0; j < TP; ++j) {
-            const int p = pc + j, y = p / g.W, x = p - y * g.W;
-            const bool ok = (unsigned)(y + dy) < (unsigned)g.H && (unsigned)(x + dx) < (unsigned)g.W;
-            const int src = j + delta;                      // inside [0, TP) whenever ok (the source pixel lies in the plane)
-            const unsigned code = (ok && src >= 0 && src < TP) ? (unsigned)src : 3u;
-            sel[t / 5] |= code << (2 * ((t % 5) * TP + j));
-        }
-    }
-    // every global access = wave-uniform base (scalar registers) + per-lane 32-bit byte offset
+    // The lane's TP pixels lie in one image row (W % TP == 0, checked by the launcher).  Per kernel row ky the lane needs the source
+    // pixels pc + (ky - 1) W - 1 .. + TP: its own run (one TP-float load per channel row, inside the plane whenever the source row
+    // is) and the two neighbours (scalar loads).  They are split ONCE and serve the three taps of the row: tap kx, pixel j reads
+    // source element j + kx.  Zero padding: a source row outside the image zeroes everything; the left neighbour is padding iff the
+    // run starts the row, the right one iff it ends it -- and only then can their clamped addresses be displaced.
+    const int y0 = pc / g.W, x0 = pc - y0 * g.W;
+    const bool row_ok[3] = {y0 >= 1, true, y0 + 1 < g.H};
+    const bool left_ok = x0 > 0, right_ok = x0 + TP < g.W;
+    // addresses: wave-uniform base (sample, channel row) + per-lane 32-bit byte offset.  The pixel part is clamped into the plane:
+    // whenever a clamp is active the value is padding (source row outside the image, or the neighbour beyond the row's end)
     const float *xb = X + (size_t)b * g.x_batch;                                     // + (16 blk + r) * P   (uniform)
-    unsigned xoff[9];                                                                // bytes: 8 kh rows + the tap's shifted run
+    unsigned offc[3], offl[3], offr[3];                                               // run / left / right neighbour per kernel row
 #pragma unroll
-    for (int t = 0; t < 9; ++t) xoff[t] = 4u * (unsigned)(8 * kh * g.P + poff[t]);
+    for (int ky = 0; ky < 3; ++ky) {
+        const int q = pc + (ky - 1) * g.W;
+        offc[ky] = 4u * (unsigned)(8 * kh * g.P + min(max(q, 0), g.P - TP));
+        offl[ky] = 4u * (unsigned)(8 * kh * g.P + min(max(q - 1, 0), g.P - 1));
+        offr[ky] = 4u * (unsigned)(8 * kh * g.P + min(max(q + TP, 0), g.P - 1));
+    }
     const size_t img = (size_t)9 * g.O * g.I;                                         // elements per weight image
     const size_t tstride = (size_t)g.O * g.I;
     const int nblk = g.I / 16, nstage = 3 * nblk;
@@ -117,8 +110,7 @@ conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ W
         wsrc[i] = 2u * (unsigned)(q * img + tt * tstride + (size_t)min(o0 + row, g.O - 1) * g.I + 8 * h);
     }
     u32x4 wreg[WL];
-    // stage s = 3 blk + kernel row (clamped: past the end the last stage again); macros, not lambdas: captured by reference the
-    // register array stayed on the stack (scratch loads / stores around every stage)
+    // stage s = 3 blk + kernel row (clamped: past the end the last stage again); macros, not lambdas (see u32x4)
 #define K19_WFETCH(S)                                                                                                         \
     {                                                                                                                         \
         const int sc_ = min((S), nstage - 1), blk_ = sc_ / 3, srow_ = sc_ - 3 * blk_;                                         \
@@ -130,64 +122,74 @@ conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ W
     {                                                                                                                         \
         _Pragma("unroll") for (int i_ = 0; i_ < WL; ++i_) sW[(BUF)][min(tid + 64 * WAVES * i_, STAGE - 1)] = wreg[i_];        \
     }
-    FVec<TP> xv[2][8];
-    // x rows: iteration it = 9 blk + t runs on buffer it & 1; the fetch of it + 1 is in flight while it is consumed
-    auto xfetch = [&](FVec<TP> (&Xv)[8], int blk, int t) __attribute__((always_inline)) {
-        const int kb = 16 * min(blk, nblk - 1);             // past the end: the last block again, dropped
-        const char *src = reinterpret_cast<const char *>(xb + (size_t)kb * g.P);
+    FVec<TP> xc[2][8];
+    float xl[2][8], xr[2][8];
+    // x rows of stage s (= iteration s): buffer s & 1; the fetch of s + 1 is in flight while s is consumed
+    auto xfetch = [&](FVec<TP> (&C)[8], float (&L)[8], float (&R)[8], int blk_, int ky) __attribute__((always_inline)) {
+        const int blk = min(blk_, nblk - 1);                    // past the end: the last block again, dropped
+        const char *src = reinterpret_cast<const char *>(xb + (size_t)(16 * blk) * g.P);
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-            Xv[r] = *reinterpret_cast<const FVec<TP> *>(src + (size_t)r * 4u * (size_t)g.P + (size_t)xoff[t]);
+        for (int r = 0; r < 8; ++r) {
+            const char *rowp = src + (size_t)r * 4u * (size_t)g.P;
+            C[r] = *reinterpret_cast<const FVec<TP> *>(rowp + (size_t)(ky == 0 ? offc[0] : ky == 1 ? offc[1] : offc[2]));
+            L[r] = *reinterpret_cast<const float *>(rowp + (size_t)(ky == 0 ? offl[0] : ky == 1 ? offl[1] : offl[2]));
+            R[r] = *reinterpret_cast<const float *>(rowp + (size_t)(ky == 0 ? offr[0] : ky == 1 ? offr[1] : offr[2]));
+        }
     };
-    auto consume = [&](const u32x4 *wst, const FVec<TP> (&Xv)[8], int t) __attribute__((always_inline)) {
-        uint4 bq[TP][3];
+    auto consume = [&](const u32x4 *wst, const FVec<TP> (&C)[8], const float (&L)[8], const float (&R)[8], int ky)
+                       __attribute__((always_inline)) {
+        // source elements m = 0 .. TP + 1 (left neighbour, the run, right neighbour), three bf16 pieces each
+        uint4 src[TP + 2][3];
+        const bool rok = row_ok[ky];
 #pragma unroll
-        for (int j = 0; j < TP; ++j) {
-            const unsigned code = (sel[t / 5] >> (2 * ((t % 5) * TP + j))) & 3u;
+        for (int m = 0; m < TP + 2; ++m) {
+            const bool ok = rok && (m == 0 ? left_ok : (m == TP + 1 ? right_ok : true));
             float f[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                float v = 0.f;
-#pragma unroll
-                for (int e = 0; e < TP; ++e) v = code == (unsigned)e ? Xv[r].v[e] : v;
-                f[r] = v;
+                const float v = m == 0 ? L[r] : (m == TP + 1 ? R[r] : C[r].v[(m >= 1 && m <= TP) ? m - 1 : 0]);
+                f[r] = ok ? v : 0.f;
             }
-            bf16x3::split3(f[0], f[1], bq[j][0].x, bq[j][1].x, bq[j][2].x);
-            bf16x3::split3(f[2], f[3], bq[j][0].y, bq[j][1].y, bq[j][2].y);
-            bf16x3::split3(f[4], f[5], bq[j][0].z, bq[j][1].z, bq[j][2].z);
-            bf16x3::split3(f[6], f[7], bq[j][0].w, bq[j][1].w, bq[j][2].w);
+            bf16x3::split3(f[0], f[1], src[m][0].x, src[m][1].x, src[m][2].x);
+            bf16x3::split3(f[2], f[3], src[m][0].y, src[m][1].y, src[m][2].y);
+            bf16x3::split3(f[4], f[5], src[m][0].z, src[m][1].z, src[m][2].z);
+            bf16x3::split3(f[6], f[7], src[m][0].w, src[m][1].w, src[m][2].w);
         }
-        uint4 aq[TO][3];
 #pragma unroll
-        for (int a = 0; a < TO; ++a)
+        for (int tt = 0; tt < 3; ++tt) {                         // tap (ky, tt): pixel j reads source element j + tt
+            uint4 aq[TO][3];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const u32x4 v = wst[((t % 3) * 3 + q) * ROWS * 2 + (32 * a + col) * 2 + kh];
-                aq[a][q] = make_uint4(v.x, v.y, v.z, v.w);
-            }
-        bf16x3::mfma_tiles<TO, TP>(aq, bq, acc);
+            for (int a = 0; a < TO; ++a)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const u32x4 v = wst[(tt * 3 + q) * ROWS * 2 + (32 * a + col) * 2 + kh];
+                    aq[a][q] = make_uint4(v.x, v.y, v.z, v.w);
+                }
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int a = 0; a < TO; ++a)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j)
+                        acc[a][j] = bf16x3::mfma(aq[a][bf16x3::kTermA[term]], src[j + tt][bf16x3::kTermB[term]], acc[a][j]);
+        }
     };
-    // one stage: three taps on weight buffer s & 1 while the next stage's weights travel global -> registers, then -> LDS
-    auto stage = [&](int blk, int srow, int par) __attribute__((always_inline)) {          // par = (9 blk + 3 srow) & 1 = x buffer of the stage's first tap
-        const int s = 3 * blk + srow;
-        K19_WFETCH(s + 1)
-#pragma unroll
-        for (int tt = 0; tt < 3; ++tt) {
-            const int t = 3 * srow + tt, cur = (tt + par) & 1;
-            if (t < 8) xfetch(xv[cur ^ 1], blk, t + 1);
-            else xfetch(xv[cur ^ 1], blk + 1, 0);
-            consume(sW[s & 1], xv[cur], t);
-        }
-        K19_WSTORE((s + 1) & 1)
-        __syncthreads();                                      // next stage's weights visible; this stage's buffer free for s + 2
+    // one stage: the three taps of a kernel row on weight buffer s & 1 while the next stage's weights travel global -> registers
+    // -> LDS and the next stage's x rows are in flight
+    auto stage = [&](int blk_, int ky, int par) __attribute__((always_inline)) {          // stage s = 3 blk + ky, par = s & 1
+        K19_WFETCH(3 * blk_ + ky + 1)
+        xfetch(xc[par ^ 1], xl[par ^ 1], xr[par ^ 1], ky == 2 ? blk_ + 1 : blk_, ky == 2 ? 0 : ky + 1);
+        consume(sW[par], xc[par], xl[par], xr[par], ky);
+        K19_WSTORE(par ^ 1)
+        __syncthreads();                                          // next stage's weights visible; this stage's buffer free for s + 2
     };
     K19_WFETCH(0)
     K19_WSTORE(0)
-    xfetch(xv[0], 0, 0);
+    xfetch(xc[0], xl[0], xr[0], 0, 0);
     __syncthreads();
     int blk = 0;
 #pragma unroll 1
-    for (; blk + 2 <= nblk; blk += 2) {                    // 18 taps: x-buffer parity and weight-buffer parity both repeat
+    for (; blk + 2 <= nblk; blk += 2) {                    // six stages: kernel row and buffer parity both repeat
         stage(blk, 0, 0);
         stage(blk, 1, 1);
         stage(blk, 2, 0);
@@ -425,11 +427,13 @@ extern "C" int mlagg_conv3x3_fwd(const float *x, long x_batch, const float *w, i
         to = 3;
         tp = P >= 65536 ? 2 : 1;
     }
+    if (W % tp) tp = 1;                                     // the kernel wants a lane's pixel run inside one image row
     static const char *env = getenv("MLAGG_K19_TILE");
     if (env && env[0] >= '1' && env[0] <= '3' && env[1] == ',' && env[2] >= '1' && env[2] <= '3') {
         to = env[0] - '0';
         tp = env[2] - '0';
         if (32 * (to - 1) >= O) to = (O + 31) / 32;
+        if (W % tp) tp = 1;
     }
     switch (to * 4 + tp) {
     case 1 * 4 + 1: launch<1, 1>(x, img, bias, y, g, st); break;

@@ -20,6 +20,9 @@ def family(n):
     for key, lab in (("linear_lp", "HIP K5 projections (fwd, dx), 16-bit operands"), ("selscan", "HIP K1 selective scan"), ("sel1_", "HIP K1s one-state selective scan (3-D)"),
                      ("conv_taps_kernel", "HIP K16 convolution forward / data gradient (tap GEMM)"),
                      ("dwconv", "HIP K2 depthwise conv"), ("gelu_pool", "HIP K17 GELU + window mean"),
+                     ("conv1x1_", "HIP K18 1x1 convolution (split bf16)"), ("conv3x3_", "HIP K19 3x3 convolution (split bf16)"),
+                     ("linear_wgrad_x3", "HIP K5w linear weight-grad"), ("linear_lp_kernel<true, 2>", "HIP K5 projections (fwd, dx)"),
+                     ("linear_lp_kernel<false, 2>", "HIP K5 projections (fwd, dx)"),
                      ("conv_wgrad_", "HIP K15 convolution weight gradient (tap GEMM)"), ("volume_pad_kernel", "HIP K15/K16 padded copies"),
                      ("guard_zero_kernel", "HIP K15/K16 padded copies"), ("pooled_lp_", "HIP K4lp pooled diff-attention (16-bit MFMA)"),
                      ("plane_split_", "HIP K10 plane norm + activation"), ("channel_epilogue", "HIP K13 convolution epilogue"),
