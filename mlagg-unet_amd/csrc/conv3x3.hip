@@ -52,6 +52,9 @@ conv3x3_weight_image_kernel(const float *__restrict__ w, unsigned short *__restr
     img[2 * n + idx] = (unsigned short)(lo & 0xffff);
 }
 
+#ifndef K19_INTERLEAVE
+#define K19_INTERLEAVE 0
+#endif
 constexpr int WAVES = 4;            // pixel groups per workgroup: they share the weight stage in LDS
 
 template <int TO, int TP>
@@ -155,6 +158,15 @@ conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ W
             bf16x3::split3(f[4], f[5], src[m][0].z, src[m][1].z, src[m][2].z);
             bf16x3::split3(f[6], f[7], src[m][0].w, src[m][1].w, src[m][2].w);
         }
+#if K19_INTERLEAVE
+        // ask the scheduler for MFMA / VALU alternation over the stage: the split of the later source elements and the LDS reads of
+        // the next tap's weights then issue in the matrix instructions' shadows instead of in a phase of their own
+#pragma unroll
+        for (int i = 0; i < 18 * TO * TP; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, K19_INTERLEAVE, 0);   // VALU
+        }
+#endif
 #pragma unroll
         for (int tt = 0; tt < 3; ++tt) {                         // tap (ky, tt): pixel j reads source element j + tt
             uint4 aq[TO][3];
