@@ -218,6 +218,19 @@ def main_3d(args, cfg, world, rank, dev, dev_index, ddp):
         dist.destroy_process_group()
 
 
+def matrix_arithmetic(precision):
+    """How the dense products of this package's own GEMM / convolution kernels are formed (operands, accumulation and results are
+    fp32 in the fp32 mode whichever way the products are issued)."""
+    from mlagg_unet_amd import ops
+    if precision != "fp32":
+        return f"{precision} operands (rounded once), fp32 accumulation"
+    on = [n for n, f in (("K5/K5w", ops.K5_X3), ("K18", ops.K18), ("K19", ops.K19)) if f]
+    if not on:
+        return "fp32 MFMA (v_mfma_f32_32x32x2_f32)"
+    return ("fp32 operands as 3 exact bf16 pieces, 6 partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulation (DESIGN 4i; error of an "
+            "fp32 GEMM against float64) in " + ", ".join(on) + "; fp32 MFMA / libraries elsewhere")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -382,7 +395,8 @@ def main():
                        "final_loss": round(float(loss), 5),
                        "launch": "hipGraph replay of the whole step" if use_graph else "eager",
                        "miopen": "tuned find-db (mlagg-unet_amd/miopen_db)" if miopen_db else "immediate mode",
-                       "library_gemm": "TunableOp table (mlagg-unet_amd/gemm_db), tuning off" if gemm_db else "library default"},
+                       "library_gemm": "TunableOp table (mlagg-unet_amd/gemm_db), tuning off" if gemm_db else "library default",
+                       "matrix_arithmetic": matrix_arithmetic(cfg["precision"])},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline and args.config == 2:
