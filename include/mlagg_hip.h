@@ -297,6 +297,14 @@ int mlagg_conv3x3_supported(int O, int I, int H, int W);
 size_t mlagg_conv3x3_workspace_bytes(int O, int I);
 int mlagg_conv3x3_fwd(const float *x, long x_batch, const float *w, int transposed, const float *bias, float *y, long y_batch,
                       void *workspace, int B, int O, int I, int H, int W, void *stream);
+/* The same kernel for 3 x 3 x 3 convolutions (stride 1, padding 1) on (B, C, D, H, W) volumes -- nine kernel rows (kz, ky) of three
+ * taps: the forward / data gradient of `nn.Conv3d(kernel_size=3, padding=1)` in the 3-D network (variants/mamba/UMambaEnc_SS3D.py:49-66
+ * BasicResBlock / BasicBlockD convolutions, :477-513, 589-637, 744-779), straight on the unpadded volumes; w (O, I, 3, 3, 3).
+ * workspace: mlagg_conv3x3x3_workspace_bytes(O, I). */
+int mlagg_conv3x3x3_supported(int O, int I, int D, int H, int W);
+size_t mlagg_conv3x3x3_workspace_bytes(int O, int I);
+int mlagg_conv3x3x3_fwd(const float *x, long x_batch, const float *w, int transposed, const float *bias, float *y, long y_batch,
+                        void *workspace, int B, int O, int I, int D, int H, int W, void *stream);
 /* Weight gradient of the same convolution: dW (O, I, 3, 3) = sum_b sum_p dy (B, O, H, W) [.] x (B, I, H, W) shifted by the tap,
  * overwritten (inside `convolution_backward` of the layers above); W % 16 == 0 (mlagg_conv3x3_wgrad_supported); workspace:
  * mlagg_conv3x3_wgrad_workspace_floats floats.  dy 16-byte aligned. */

@@ -31,20 +31,20 @@ struct __attribute__((packed, aligned(4))) FVec {
 };
 
 struct C3Geom {
-    int B, O, I, H, W, P;
+    int B, O, I, D, H, W, P;        // D = 1: 2-D (three kernel rows); D > 1: 3 x 3 x 3 (nine kernel rows (kz, ky))
     long x_batch, y_batch;
 };
 
 // wimg[q][t][o][i] (bf16 piece q of the weight of tap t); flip: the data gradient's weight, w'[i][o][t] = w[o][i][8 - t] with the
 // roles of o and i exchanged (O, I are the OUTPUT / CONTRACTION extents of the product the image serves)
 __global__ void __launch_bounds__(256)
-conv3x3_weight_image_kernel(const float *__restrict__ w, unsigned short *__restrict__ img, int O, int I, int flip)
+conv3x3_weight_image_kernel(const float *__restrict__ w, unsigned short *__restrict__ img, int O, int I, int ntaps, int flip)
 {
-    const int n = 9 * O * I;
+    const int n = ntaps * O * I;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const int i = idx % I, o = (idx / I) % O, t = idx / (I * O);
-    const float v = flip ? w[((size_t)i * O + o) * 9 + (8 - t)] : w[((size_t)o * I + i) * 9 + t];
+    const float v = flip ? w[((size_t)i * O + o) * ntaps + (ntaps - 1 - t)] : w[((size_t)o * I + i) * ntaps + t];
     unsigned hi, mid, lo;
     bf16x3::split3(v, 0.f, hi, mid, lo);
     img[idx] = (unsigned short)(hi & 0xffff);
@@ -57,7 +57,7 @@ conv3x3_weight_image_kernel(const float *__restrict__ w, unsigned short *__restr
 #endif
 constexpr int WAVES = 4;            // pixel groups per workgroup: they share the weight stage in LDS
 
-template <int TO, int TP>
+template <int TO, int TP, int NR>
 __global__ void __launch_bounds__(64 * WAVES, 2)
 conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Wimg, const float *__restrict__ bias,
                float *__restrict__ Y, C3Geom g)
@@ -87,23 +87,29 @@ conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ W
     // is) and the two neighbours (scalar loads).  They are split ONCE and serve the three taps of the row: tap kx, pixel j reads
     // source element j + kx.  Zero padding: a source row outside the image zeroes everything; the left neighbour is padding iff the
     // run starts the row, the right one iff it ends it -- and only then can their clamped addresses be displaced.
-    const int y0 = pc / g.W, x0 = pc - y0 * g.W;
-    const bool row_ok[3] = {y0 >= 1, true, y0 + 1 < g.H};
+    const int x0 = pc % g.W, yz = pc / g.W, y0 = yz % g.H, z0 = yz / g.H;
+    bool row_ok[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int kz = NR == 9 ? r / 3 : 1, ky = NR == 9 ? r % 3 : r;
+        row_ok[r] = (unsigned)(z0 + kz - 1) < (unsigned)g.D && (unsigned)(y0 + ky - 1) < (unsigned)g.H;
+    }
     const bool left_ok = x0 > 0, right_ok = x0 + TP < g.W;
     // addresses: wave-uniform base (sample, channel row) + per-lane 32-bit byte offset.  The pixel part is clamped into the plane:
     // whenever a clamp is active the value is padding (source row outside the image, or the neighbour beyond the row's end)
     const float *xb = X + (size_t)b * g.x_batch;                                     // + (16 blk + r) * P   (uniform)
-    unsigned offc[3], offl[3], offr[3];                                               // run / left / right neighbour per kernel row
+    unsigned offc[NR], offl[NR], offr[NR];                                            // run / left / right neighbour per kernel row
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int q = pc + (ky - 1) * g.W;
-        offc[ky] = 4u * (unsigned)(8 * kh * g.P + min(max(q, 0), g.P - TP));
-        offl[ky] = 4u * (unsigned)(8 * kh * g.P + min(max(q - 1, 0), g.P - 1));
-        offr[ky] = 4u * (unsigned)(8 * kh * g.P + min(max(q + TP, 0), g.P - 1));
+    for (int r = 0; r < NR; ++r) {
+        const int kz = NR == 9 ? r / 3 : 1, ky = NR == 9 ? r % 3 : r;
+        const int q = pc + (kz - 1) * g.H * g.W + (ky - 1) * g.W;
+        offc[r] = 4u * (unsigned)(8 * kh * g.P + min(max(q, 0), g.P - TP));
+        offl[r] = 4u * (unsigned)(8 * kh * g.P + min(max(q - 1, 0), g.P - 1));
+        offr[r] = 4u * (unsigned)(8 * kh * g.P + min(max(q + TP, 0), g.P - 1));
     }
-    const size_t img = (size_t)9 * g.O * g.I;                                         // elements per weight image
+    const size_t img = (size_t)(3 * NR) * g.O * g.I;                                  // elements per weight image
     const size_t tstride = (size_t)g.O * g.I;
-    const int nblk = g.I / 16, nstage = 3 * nblk;
+    const int nblk = g.I / 16, nstage = NR * nblk;
     // weight stage loader: element e = ((tt * 3 + q) * ROWS + row) * 2 + h  <-  Wimg[q][3 srow + tt][o0 + row][16 blk + 8 h ..]
     unsigned wsrc[WL];                                                               // bytes within a (blk, kernel row) slice
 #pragma unroll
@@ -116,7 +122,7 @@ conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ W
     // stage s = 3 blk + kernel row (clamped: past the end the last stage again); macros, not lambdas (see u32x4)
 #define K19_WFETCH(S)                                                                                                         \
     {                                                                                                                         \
-        const int sc_ = min((S), nstage - 1), blk_ = sc_ / 3, srow_ = sc_ - 3 * blk_;                                         \
+        const int sc_ = min((S), nstage - 1), blk_ = sc_ / NR, srow_ = sc_ - NR * blk_;                                       \
         const char *base_ = reinterpret_cast<const char *>(Wimg + (size_t)(3 * srow_) * tstride + 16 * blk_);                \
         _Pragma("unroll") for (int i_ = 0; i_ < WL; ++i_) wreg[i_] = *reinterpret_cast<const u32x4 *>(base_ + (size_t)wsrc[i_]); \
     }
@@ -134,9 +140,9 @@ conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ W
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const char *rowp = src + (size_t)r * 4u * (size_t)g.P;
-            C[r] = *reinterpret_cast<const FVec<TP> *>(rowp + (size_t)(ky == 0 ? offc[0] : ky == 1 ? offc[1] : offc[2]));
-            L[r] = *reinterpret_cast<const float *>(rowp + (size_t)(ky == 0 ? offl[0] : ky == 1 ? offl[1] : offl[2]));
-            R[r] = *reinterpret_cast<const float *>(rowp + (size_t)(ky == 0 ? offr[0] : ky == 1 ? offr[1] : offr[2]));
+            C[r] = *reinterpret_cast<const FVec<TP> *>(rowp + (size_t)offc[ky]);
+            L[r] = *reinterpret_cast<const float *>(rowp + (size_t)offl[ky]);
+            R[r] = *reinterpret_cast<const float *>(rowp + (size_t)offr[ky]);
         }
     };
     auto consume = [&](const u32x4 *wst, const FVec<TP> (&C)[8], const float (&L)[8], const float (&R)[8], int ky)
@@ -188,9 +194,9 @@ conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ W
     };
     // one stage: the three taps of a kernel row on weight buffer s & 1 while the next stage's weights travel global -> registers
     // -> LDS and the next stage's x rows are in flight
-    auto stage = [&](int blk_, int ky, int par) __attribute__((always_inline)) {          // stage s = 3 blk + ky, par = s & 1
-        K19_WFETCH(3 * blk_ + ky + 1)
-        xfetch(xc[par ^ 1], xl[par ^ 1], xr[par ^ 1], ky == 2 ? blk_ + 1 : blk_, ky == 2 ? 0 : ky + 1);
+    auto stage = [&](int blk_, int ky, int par) __attribute__((always_inline)) {          // stage s = NR blk + ky, par = s & 1
+        K19_WFETCH(NR * blk_ + ky + 1)
+        xfetch(xc[par ^ 1], xl[par ^ 1], xr[par ^ 1], ky == NR - 1 ? blk_ + 1 : blk_, ky == NR - 1 ? 0 : ky + 1);
         consume(sW[par], xc[par], xl[par], xr[par], ky);
         K19_WSTORE(par ^ 1)
         __syncthreads();                                          // next stage's weights visible; this stage's buffer free for s + 2
@@ -201,18 +207,15 @@ conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ W
     __syncthreads();
     int blk = 0;
 #pragma unroll 1
-    for (; blk + 2 <= nblk; blk += 2) {                    // six stages: kernel row and buffer parity both repeat
-        stage(blk, 0, 0);
-        stage(blk, 1, 1);
-        stage(blk, 2, 0);
-        stage(blk + 1, 0, 1);
-        stage(blk + 1, 1, 0);
-        stage(blk + 1, 2, 1);
+    for (; blk + 2 <= nblk; blk += 2) {                    // 2 NR stages (NR is odd): kernel row and buffer parity both repeat
+#pragma unroll
+        for (int r = 0; r < NR; ++r) stage(blk, r, r & 1);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) stage(blk + 1, r, (r + 1) & 1);
     }
     if (blk < nblk) {
-        stage(blk, 0, 0);
-        stage(blk, 1, 1);
-        stage(blk, 2, 0);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) stage(blk, r, r & 1);
     }
     float *yb = Y + (size_t)b * g.y_batch + pc;
 #pragma unroll
@@ -403,37 +406,34 @@ void launch(const float *x, const unsigned short *wimg, const float *bias, float
 {
     const int groups = (g.P + 32 * TP - 1) / (32 * TP);
     const dim3 grid((groups + WAVES - 1) / WAVES, (g.O + 32 * TO - 1) / (32 * TO), g.B);
-    hipLaunchKernelGGL((conv3x3_kernel<TO, TP>), grid, dim3(64 * WAVES), 0, st, x, wimg, bias, y, g);
+    if (g.D > 1)
+        hipLaunchKernelGGL((conv3x3_kernel<TO, TP, 9>), grid, dim3(64 * WAVES), 0, st, x, wimg, bias, y, g);
+    else
+        hipLaunchKernelGGL((conv3x3_kernel<TO, TP, 3>), grid, dim3(64 * WAVES), 0, st, x, wimg, bias, y, g);
 }
 
 }  // namespace
 
-extern "C" int mlagg_conv3x3_supported(int O, int I, int H, int W)
-{
-    return O > 0 && I > 0 && (I % 16) == 0 && H > 0 && W > 0 && (long)H * W >= 96 && (long)H * W < (1L << 30);
-}
-
-// bytes of the weight image: 3 pieces x 9 taps x O x I bf16
-extern "C" size_t mlagg_conv3x3_workspace_bytes(int O, int I) { return O > 0 && I > 0 ? (size_t)3 * 9 * O * I * 2 : 0; }
-
-// y (B, O, H, W) = conv3x3(x (B, I, H, W), w) (+ bias).  transposed == 0: w is (O, I, 3, 3), the forward.  transposed != 0: w is the
-// forward weight (I, O, 3, 3) of the layer whose DATA GRADIENT this is (x = dy of that layer, O = its input channels).
-extern "C" int mlagg_conv3x3_fwd(const float *x, long x_batch, const float *w, int transposed, const float *bias, float *y,
-                                 long y_batch, void *workspace, int B, int O, int I, int H, int W, void *stream)
+namespace {
+// y = conv(x, w) for a 3 x 3 (D == 1) or 3 x 3 x 3 kernel, stride 1, zero padding 1
+int conv_fwd(const float *x, long x_batch, const float *w, int transposed, const float *bias, float *y, long y_batch, void *workspace,
+             int B, int O, int I, int D, int H, int W, void *stream)
 {
     if (!x || !w || !y || !workspace) return MLAGG_E_NULLPTR;
-    if (B <= 0 || B > 65535 || !mlagg_conv3x3_supported(O, I, H, W)) return MLAGG_E_UNSUPPORTED;
-    const long P = (long)H * W;
+    const long P = (long)D * H * W;
+    if (B <= 0 || B > 65535 || O <= 0 || I <= 0 || (I % 16) || D <= 0 || H <= 0 || W <= 0 || P < 96 || P >= (1L << 28))
+        return MLAGG_E_UNSUPPORTED;
     if (x_batch < (long)I * P || y_batch < (long)O * P || (reinterpret_cast<uintptr_t>(workspace) & 15)) return MLAGG_E_UNSUPPORTED;
-    C3Geom g{B, O, I, H, W, (int)P, x_batch, y_batch};
+    C3Geom g{B, O, I, D, H, W, (int)P, x_batch, y_batch};
     hipStream_t st = static_cast<hipStream_t>(stream);
     MLAGG_TIMED(K_CONV3X3, st);
     unsigned short *img = static_cast<unsigned short *>(workspace);
-    const int n = 9 * O * I;
-    hipLaunchKernelGGL(conv3x3_weight_image_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, img, O, I, transposed ? 1 : 0);
+    const int ntaps = D > 1 ? 27 : 9;
+    const int n = ntaps * O * I;
+    hipLaunchKernelGGL(conv3x3_weight_image_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, img, O, I, ntaps, transposed ? 1 : 0);
     // tile per wave = (32 TO output channels) x (32 TP pixels); measured on the step's shapes (tools/bench_conv3x3.py with
-    // MLAGG_K19_TILE, profiles/round3_g_conv3x3_tiles.log): 2 x 2 (two workgroups per CU, most waves) everywhere except outputs
-    // that fill 96-channel groups exactly on large maps
+    // MLAGG_K19_TILE, profiles/round3_h_conv3x3_k19_vs_miopen_tiles.log): 2 x 2 (two workgroups per CU, most waves) everywhere
+    // except outputs that fill 96-channel groups exactly on large maps
     int to = O <= 32 ? 1 : 2, tp = 2;
     if (O % 96 == 0 && P >= 16384) {
         to = 3;
@@ -447,18 +447,48 @@ extern "C" int mlagg_conv3x3_fwd(const float *x, long x_batch, const float *w, i
         if (32 * (to - 1) >= O) to = (O + 31) / 32;
         if (W % tp) tp = 1;
     }
+    if (tp == 3) tp = 2 - (W & 1);                          // three-pixel runs are not instantiated
     switch (to * 4 + tp) {
     case 1 * 4 + 1: launch<1, 1>(x, img, bias, y, g, st); break;
     case 1 * 4 + 2: launch<1, 2>(x, img, bias, y, g, st); break;
-    case 1 * 4 + 3: launch<1, 3>(x, img, bias, y, g, st); break;
     case 2 * 4 + 1: launch<2, 1>(x, img, bias, y, g, st); break;
     case 2 * 4 + 2: launch<2, 2>(x, img, bias, y, g, st); break;
-    case 2 * 4 + 3: launch<2, 3>(x, img, bias, y, g, st); break;
     case 3 * 4 + 1: launch<3, 1>(x, img, bias, y, g, st); break;
-    case 3 * 4 + 2: launch<3, 2>(x, img, bias, y, g, st); break;
-    default: launch<3, 3>(x, img, bias, y, g, st); break;
+    default: launch<3, 2>(x, img, bias, y, g, st); break;
     }
     return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int mlagg_conv3x3_supported(int O, int I, int H, int W)
+{
+    return O > 0 && I > 0 && (I % 16) == 0 && H > 0 && W > 0 && (long)H * W >= 96 && (long)H * W < (1L << 28);
+}
+
+// bytes of the weight image: 3 pieces x 9 taps x O x I bf16
+extern "C" size_t mlagg_conv3x3_workspace_bytes(int O, int I) { return O > 0 && I > 0 ? (size_t)3 * 9 * O * I * 2 : 0; }
+
+// y (B, O, H, W) = conv3x3(x (B, I, H, W), w) (+ bias).  transposed == 0: w is (O, I, 3, 3), the forward.  transposed != 0: w is the
+// forward weight (I, O, 3, 3) of the layer whose DATA GRADIENT this is (x = dy of that layer, O = its input channels).
+extern "C" int mlagg_conv3x3_fwd(const float *x, long x_batch, const float *w, int transposed, const float *bias, float *y,
+                                 long y_batch, void *workspace, int B, int O, int I, int H, int W, void *stream)
+{
+    return conv_fwd(x, x_batch, w, transposed, bias, y, y_batch, workspace, B, O, I, 1, H, W, stream);
+}
+
+// the same for 3 x 3 x 3 kernels on (B, C, D, H, W) volumes (nine kernel rows (kz, ky) of three taps each)
+extern "C" int mlagg_conv3x3x3_supported(int O, int I, int D, int H, int W)
+{
+    return O > 0 && I > 0 && (I % 16) == 0 && D > 0 && H > 0 && W > 0 && (long)D * H * W >= 96 && (long)D * H * W < (1L << 28);
+}
+
+extern "C" size_t mlagg_conv3x3x3_workspace_bytes(int O, int I) { return O > 0 && I > 0 ? (size_t)3 * 27 * O * I * 2 : 0; }
+
+extern "C" int mlagg_conv3x3x3_fwd(const float *x, long x_batch, const float *w, int transposed, const float *bias, float *y,
+                                   long y_batch, void *workspace, int B, int O, int I, int D, int H, int W, void *stream)
+{
+    if (D <= 1) return MLAGG_E_UNSUPPORTED;
+    return conv_fwd(x, x_batch, w, transposed, bias, y, y_batch, workspace, B, O, I, D, H, W, stream);
 }
 
 extern "C" int mlagg_conv3x3_wgrad_supported(int O, int I, int H, int W) { return O > 0 && I > 0 && H > 0 && W >= 16 && (W % 16) == 0; }

@@ -1713,6 +1713,62 @@ def conv3x3(x, weight):
     return Conv3x3Fn.apply(x, weight)
 
 
+K19_3D = _os.environ.get("MLAGG_K19_3D", "1") == "1"
+
+
+def _conv3x3x3_k19(x, xb, w, transposed, O, I, dims):
+    lib = _lib.lib()
+    B = x.shape[0]
+    D, H, W = dims
+    y = torch.empty(B, O, D, H, W, device=x.device, dtype=torch.float32)
+    ws = torch.empty(lib.mlagg_conv3x3x3_workspace_bytes(O, I), device=x.device, dtype=torch.uint8)
+    _lib.check(lib.mlagg_conv3x3x3_fwd(_ptr(x), xb, _ptr(w), int(transposed), None, _ptr(y), O * D * H * W, _ptr(ws), B, O, I, D, H, W,
+                                       _stream()), "mlagg_conv3x3x3_fwd")
+    return y
+
+
+class Conv3x3x3Fn(torch.autograd.Function):
+    """y = conv3d(x, W, padding=1) for a dense 3 x 3 x 3 kernel (stride 1, no bias): forward and data gradient on K19 (27 shifted
+    split-bf16 GEMMs straight on the NCDHW volumes, no padded copy), weight gradient on K15 (its two padded copies are made in
+    backward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x, xb, P = _planes(x, "x")
+        dims = tuple(int(v) for v in x.shape[2:])
+        O, I = int(weight.shape[0]), int(weight.shape[1])
+        w = _require(weight.contiguous(), "weight")
+        y = _conv3x3x3_k19(x, xb, w, False, O, I, dims)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dims = tuple(int(v) for v in x.shape[2:])
+        O, I = int(w.shape[0]), int(w.shape[1])
+        dx = dW = None
+        dy = dy.contiguous()
+        lib = _lib.lib()
+        if ctx.needs_input_grad[0]:
+            if lib.mlagg_conv3x3x3_supported(I, O, *dims):
+                dx = _conv3x3x3_k19(dy, O * dims[0] * dims[1] * dims[2], w, True, I, O, dims)
+            else:                                               # contraction (the layer's output channels) not a multiple of 16
+                dx = torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1, 1), (1, 1, 1), (1, 1, 1), False, (0, 0, 0), 1,
+                                                         (True, False, False))[0]
+        if ctx.needs_input_grad[1]:
+            dW = conv_weight_grad(x if x.is_contiguous() else x.contiguous(), dy, 3, 1).view(w.shape)
+        return dx, dW
+
+
+def conv3x3x3_supported(x, weight, stride, padding):
+    if not (K19_3D and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and tuple(weight.shape[2:]) == (3, 3, 3)):
+        return False
+    if any(int(v) != 1 for v in stride) or any(int(v) != 1 for v in padding):
+        return False
+    return bool(_lib.lib().mlagg_conv3x3x3_supported(int(weight.shape[0]), int(weight.shape[1]), *(int(v) for v in x.shape[2:])))
+
+
 def _pad_geometry(D, H, W, stride, wide=False):
     import ctypes
     Dq, Hq, Wq, guard = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_long()
@@ -1893,6 +1949,8 @@ class ConvNdFn(torch.autograd.Function):
 def conv_nd(x, weight, stride, padding):
     """Bias-free convolution; the tap-GEMM kernels when the shape is one they are built for (K16 + K15: 3-D stride 1; K15 weight
     gradient behind MIOpen's forward / data gradient: 3-D stride 2), plain torch otherwise."""
+    if conv3x3x3_supported(x, weight, stride, padding):
+        return Conv3x3x3Fn.apply(x, weight)
     if conv_taps_supported(x, weight, stride, padding):
         return ConvTapsFn.apply(x, weight)
     if conv_wgrad_supported(x, weight, stride, padding):

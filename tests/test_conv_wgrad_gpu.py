@@ -173,3 +173,27 @@ def test_conv3x3_matches_float64(monkeypatch, B, I, O, H, W, sliced):
     for name, got, want, tol in (("y", yp, yr, 2e-6), ("dx", xp.grad, xr.grad, 2e-6), ("dW", wp.grad, wr.grad, 4e-6)):
         err = float((got.detach().double() - want.detach()).abs().max() / want.detach().abs().max())
         assert err < tol, (name, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,I,O,dims", [(1, 32, 32, (6, 10, 16)), (2, 16, 48, (5, 7, 9)), (1, 64, 32, (3, 8, 12)), (1, 32, 40, (2, 4, 12)),
+                                        (1, 32, 32, (24, 40, 40))])
+def test_conv3x3x3_matches_float64(B, I, O, dims):
+    """K19 with nine kernel rows: 3 x 3 x 3 convolution straight on the unpadded NCDHW volume -- output, data gradient (the same
+    kernel on the transposed, tap-flipped weight) and weight gradient (K15 on padded copies made in backward) against float64 conv3d.
+    Odd widths (one-pixel runs), two-slice volumes, output widths off the 32-channel tiles, a stage of BASELINE configs[3] at 1/64."""
+    from mlagg_unet_amd import ops
+    g = torch.Generator().manual_seed(I + O + dims[0])
+    x = torch.randn(B, I, *dims, generator=g).to(DEV)
+    w = (torch.randn(O, I, 3, 3, 3, generator=g) * (27 * I) ** -0.5).to(DEV)
+    gy = torch.randn(B, O, *dims, generator=g).to(DEV)
+    assert ops.conv3x3x3_supported(x, w, (1, 1, 1), (1, 1, 1))
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv3d(xr, wr, None, 1, 1)
+    yr.backward(gy.double())
+    xp, wp = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yp = ops.conv_nd(xp, wp, (1, 1, 1), (1, 1, 1))
+    yp.backward(gy)
+    for name, got, want, tol in (("y", yp, yr, 2e-6), ("dx", xp.grad, xr.grad, 2e-6), ("dW", wp.grad, wr.grad, 1e-5)):
+        err = float((got.detach().double() - want.detach()).abs().max() / want.detach().abs().max())
+        assert err < tol, (name, err)
