@@ -306,9 +306,15 @@ size_t mlagg_conv3x3x3_workspace_bytes(int O, int I);
 int mlagg_conv3x3x3_fwd(const float *x, long x_batch, const float *w, int transposed, const float *bias, float *y, long y_batch,
                         void *workspace, int B, int O, int I, int D, int H, int W, void *stream);
 /* Weight gradient of the same convolution: dW (O, I, 3, 3) = sum_b sum_p dy (B, O, H, W) [.] x (B, I, H, W) shifted by the tap,
- * overwritten (inside `convolution_backward` of the layers above); W % 16 == 0 (mlagg_conv3x3_wgrad_supported); workspace:
+ * overwritten (inside `convolution_backward` of the layers above); W % 8 == 0 and H W % 16 == 0 (mlagg_conv3x3_wgrad_supported); workspace:
  * mlagg_conv3x3_wgrad_workspace_floats floats.  dy 16-byte aligned. */
 int mlagg_conv3x3_wgrad_supported(int O, int I, int H, int W);
+/* ... and of the 3 x 3 x 3 convolution: dW (O, I, 3, 3, 3) from dy (B, O, D, H, W) and x (B, I, D, H, W), unpadded volumes (one wave
+ * per kernel slice kz); W % 8 == 0 and D H W % 16 == 0 (mlagg_conv3x3x3_wgrad_supported), else the caller keeps K15. */
+int mlagg_conv3x3x3_wgrad_supported(int O, int I, int D, int H, int W);
+size_t mlagg_conv3x3x3_wgrad_workspace_floats(int B, int O, int I, int D, int H, int W);
+int mlagg_conv3x3x3_wgrad(const float *dy, long dy_batch, const float *x, long x_batch, float *dW, float *workspace, int B, int O,
+                          int I, int D, int H, int W, void *stream);
 size_t mlagg_conv3x3_wgrad_workspace_floats(int B, int O, int I, int H, int W);
 int mlagg_conv3x3_wgrad(const float *dy, long dy_batch, const float *x, long x_batch, float *dW, float *workspace, int B, int O,
                         int I, int H, int W, void *stream);

@@ -87,6 +87,9 @@ SIGNATURES = {
     "mlagg_conv3x3x3_supported": (_I, [_I, _I, _I, _I, _I]),
     "mlagg_conv3x3x3_workspace_bytes": (_SZ, [_I, _I]),
     "mlagg_conv3x3x3_fwd": (_I, [_F, ctypes.c_long, _F, _I, _F, _F, ctypes.c_long, _F, _I, _I, _I, _I, _I, _I, _S]),
+    "mlagg_conv3x3x3_wgrad_supported": (_I, [_I, _I, _I, _I, _I]),
+    "mlagg_conv3x3x3_wgrad_workspace_floats": (_SZ, [_I, _I, _I, _I, _I, _I]),
+    "mlagg_conv3x3x3_wgrad": (_I, [_F, ctypes.c_long, _F, ctypes.c_long, _F, _F, _I, _I, _I, _I, _I, _I, _S]),
     "mlagg_conv3x3_wgrad_supported": (_I, [_I, _I, _I, _I]),
     "mlagg_conv3x3_wgrad_workspace_floats": (_SZ, [_I, _I, _I, _I, _I]),
     "mlagg_conv3x3_wgrad": (_I, [_F, ctypes.c_long, _F, ctypes.c_long, _F, _F, _I, _I, _I, _I, _I, _S]),

@@ -253,7 +253,8 @@ conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ W
 // row for dx = -1 and the last one for dx = +1.  Partials [slab][tap][o][i] (coalesced stores), summed in a fixed order into the
 // (O, I, 3, 3) layout by a second launch.
 struct W3Geom {
-    int B, O, I, H, W, P;
+    int B, O, I, D, H, W, P;        // D = 1: 3 x 3 (nz = 1 kernel slice); D > 1: 3 x 3 x 3 (nz = 3: one wave per kernel slice kz)
+    int nz;
     long dy_batch, x_batch;
     int slab, nslabs;
     long x_last;                    // last float offset from x at which an 8-float load stays inside the operand
@@ -263,7 +264,8 @@ __global__ void __launch_bounds__(64)
 conv3x3_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ part, W3Geom g)
 {
     const int lane = threadIdx.x, col = lane & 31, kh = lane >> 5;
-    const int b = blockIdx.x / g.nslabs, s = blockIdx.x % g.nslabs;
+    const int kz = (int)(blockIdx.x % g.nz) + (g.nz == 1 ? 1 : 0);          // kernel slice of this wave (2-D: the middle one)
+    const int bs = blockIdx.x / g.nz, b = bs / g.nslabs, s = bs % g.nslabs;
     const int o0 = blockIdx.y * 32, i0 = blockIdx.z * 32;
     f32x16 acc[1][9];
 #pragma unroll
@@ -290,7 +292,7 @@ conv3x3_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ X, 
         }
         // clamped into the operand: a displaced address only occurs for a source row outside the image (skipped) or for the two
         // neighbours at the operand's very first / last float, which are the zero-padded ones
-        const long want = xrow + 16 * bc + (long)(ky - 1) * g.W;
+        const long want = xrow + 16 * bc + (long)(ky - 1) * g.W + (long)(kz - 1) * g.H * g.W;
         const long at = min(max(want, 0L), g.x_last);
         Bv[0] = *reinterpret_cast<const float4 *>(X + at);
         Bv[1] = *reinterpret_cast<const float4 *>(X + at + 4);
@@ -306,17 +308,21 @@ conv3x3_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ X, 
             bf16x3::split3(f[4], f[5], aq[0][0].z, aq[0][1].z, aq[0][2].z);
             bf16x3::split3(f[6], f[7], aq[0][0].w, aq[0][1].w, aq[0][2].w);
         }
-        const int p = pb + 16 * blk;                            // wave-uniform: the block lies in one image row
-        const int y = p / g.W, xb = p - y * g.W;
-        if ((unsigned)(y + ky - 1) >= (unsigned)g.H) return;     // source row outside the image: the three taps add nothing
-        const float left = (kh == 0 && xb == 0) ? 0.f : E[0];                               // left neighbour of the row's first pixel
-        const float right = (kh == 1 && xb + 16 == g.W) ? 0.f : E[1];                       // right neighbour of its last pixel
+        // the lane's 8-pixel run lies in one image row (W % 8 == 0); its two halves of a block may lie in different rows
+        const int p = pb + 16 * blk + 8 * kh;
+        const int x0 = p % g.W, yz = p / g.W, y = yz % g.H, z = yz / g.H;
+        const bool rok = (unsigned)(y + ky - 1) < (unsigned)g.H && (unsigned)(z + kz - 1) < (unsigned)g.D;
+        if (!__any(rok)) return;                                 // source rows of the whole block outside the image
+        const float left = (!rok || x0 == 0) ? 0.f : E[0];                                  // left neighbour of the row's first pixel
+        const float right = (!rok || x0 + 8 == g.W) ? 0.f : E[1];                           // right neighbour of its last pixel
+        float4 c0 = Bv[0], c1 = Bv[1];
+        if (!rok) c0 = c1 = make_float4(0.f, 0.f, 0.f, 0.f);
         unsigned d[3][5];                                        // [piece][pair]: (p-1, p), (p+1, p+2), (p+3, p+4), (p+5, p+6), (p+7, p+8)
-        bf16x3::split3(left, Bv[0].x, d[0][0], d[1][0], d[2][0]);
-        bf16x3::split3(Bv[0].y, Bv[0].z, d[0][1], d[1][1], d[2][1]);
-        bf16x3::split3(Bv[0].w, Bv[1].x, d[0][2], d[1][2], d[2][2]);
-        bf16x3::split3(Bv[1].y, Bv[1].z, d[0][3], d[1][3], d[2][3]);
-        bf16x3::split3(Bv[1].w, right, d[0][4], d[1][4], d[2][4]);
+        bf16x3::split3(left, c0.x, d[0][0], d[1][0], d[2][0]);
+        bf16x3::split3(c0.y, c0.z, d[0][1], d[1][1], d[2][1]);
+        bf16x3::split3(c0.w, c1.x, d[0][2], d[1][2], d[2][2]);
+        bf16x3::split3(c1.y, c1.z, d[0][3], d[1][3], d[2][3]);
+        bf16x3::split3(c1.w, right, d[0][4], d[1][4], d[2][4]);
         uint4 bq[3][3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -352,22 +358,23 @@ conv3x3_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ X, 
         }
     }
     // partial [slab][tap][O][I]: D row R -> output channel o0 + R, column = lane -> input channel i0 + col
-    float *prow = part + (size_t)blockIdx.x * ((size_t)9 * g.O * g.I);
+    const int ntaps = 9 * g.nz, t0 = g.nz == 1 ? 0 : 9 * kz;
+    float *prow = part + (size_t)bs * ((size_t)ntaps * g.O * g.I);
     const int i = i0 + col;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (o < g.O && i < g.I) prow[((size_t)t * g.O + o) * g.I + i] = acc[0][t][r];
+            if (o < g.O && i < g.I) prow[((size_t)(t0 + t) * g.O + o) * g.I + i] = acc[0][t][r];
         }
 }
 
 // dW[(o, i, t)] = sum over partial blocks of part[s][t][o][i], fixed order
 __global__ void __launch_bounds__(256)
-conv3x3_wgrad_reduce_kernel(const float *__restrict__ part, int nparts, int O, int I, float *__restrict__ dW)
+conv3x3_wgrad_reduce_kernel(const float *__restrict__ part, int nparts, int O, int I, int ntaps, float *__restrict__ dW)
 {
-    const int n = 9 * O * I;
+    const int n = ntaps * O * I;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;        // (t, o, i): the partial layout, coalesced reads
     if (idx >= n) return;
     float s0 = 0.f, s1 = 0.f;
@@ -378,18 +385,18 @@ conv3x3_wgrad_reduce_kernel(const float *__restrict__ part, int nparts, int O, i
     }
     if (sidx < nparts) s0 += part[(size_t)sidx * n + idx];
     const int i = idx % I, o = (idx / I) % O, t = idx / (I * O);
-    dW[((size_t)o * I + i) * 9 + t] = s0 + s1;
+    dW[((size_t)o * I + i) * ntaps + t] = s0 + s1;
 }
 
-int make_w3geom(W3Geom &g, int B, int O, int I, int H, int W, long dy_batch, long x_batch)
+int make_w3geom(W3Geom &g, int B, int O, int I, int D, int H, int W, long dy_batch, long x_batch)
 {
-    if (B <= 0 || O <= 0 || I <= 0 || H <= 0 || W <= 0 || (W & 15)) return MLAGG_E_UNSUPPORTED;
-    const long P = (long)H * W;
-    if (P >= (1L << 30) || dy_batch < (long)O * P || x_batch < (long)I * P || ((dy_batch | x_batch) & 3)) return MLAGG_E_UNSUPPORTED;
-    g = W3Geom{B, O, I, H, W, (int)P, dy_batch, x_batch, 0, 0, (long)(B - 1) * x_batch + (long)I * P - 8};
+    if (B <= 0 || O <= 0 || I <= 0 || D <= 0 || H <= 0 || W <= 0 || (W & 7)) return MLAGG_E_UNSUPPORTED;
+    const long P = (long)D * H * W;
+    if ((P & 15) || P >= (1L << 28) || dy_batch < (long)O * P || x_batch < (long)I * P || ((dy_batch | x_batch) & 3)) return MLAGG_E_UNSUPPORTED;
+    g = W3Geom{B, O, I, D, H, W, (int)P, D > 1 ? 3 : 1, dy_batch, x_batch, 0, 0, (long)(B - 1) * x_batch + (long)I * P - 8};
     const int og = (O + 31) / 32, ig = (I + 31) / 32;
     static const int target = [] { const char *e = getenv("MLAGG_K19W_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2048; }();
-    int per_sample = (target + B * og * ig - 1) / (B * og * ig);
+    int per_sample = (target + B * og * ig * g.nz - 1) / (B * og * ig * g.nz);
     if (per_sample < 1) per_sample = 1;
     int slab = (int)((P + per_sample - 1) / per_sample);
     slab = ((slab + 15) / 16) * 16;
@@ -491,28 +498,55 @@ extern "C" int mlagg_conv3x3x3_fwd(const float *x, long x_batch, const float *w,
     return conv_fwd(x, x_batch, w, transposed, bias, y, y_batch, workspace, B, O, I, D, H, W, stream);
 }
 
-extern "C" int mlagg_conv3x3_wgrad_supported(int O, int I, int H, int W) { return O > 0 && I > 0 && H > 0 && W >= 16 && (W % 16) == 0; }
+extern "C" int mlagg_conv3x3_wgrad_supported(int O, int I, int H, int W)
+{
+    return O > 0 && I > 0 && H > 0 && W >= 8 && (W % 8) == 0 && ((long)H * W) % 16 == 0;
+}
 
-extern "C" size_t mlagg_conv3x3_wgrad_workspace_floats(int B, int O, int I, int H, int W)
+extern "C" int mlagg_conv3x3x3_wgrad_supported(int O, int I, int D, int H, int W)
+{
+    return O > 0 && I > 0 && D > 1 && H > 0 && W >= 8 && (W % 8) == 0 && ((long)D * H * W) % 16 == 0;
+}
+
+namespace {
+size_t wgrad_ws(int B, int O, int I, int D, int H, int W)
 {
     W3Geom g;
-    if (make_w3geom(g, B, O, I, H, W, (long)O * H * W, (long)I * H * W)) return 0;
-    return (size_t)B * g.nslabs * 9 * O * I;
+    if (make_w3geom(g, B, O, I, D, H, W, (long)O * D * H * W, (long)I * D * H * W)) return 0;
+    return (size_t)B * g.nslabs * 9 * g.nz * O * I;
 }
+
+int wgrad3(const float *dy, long dy_batch, const float *x, long x_batch, float *dW, float *workspace, int B, int O, int I, int D, int H,
+           int W, void *stream)
+{
+    if (!dy || !x || !dW || !workspace) return MLAGG_E_NULLPTR;
+    W3Geom g;
+    if (int rc = make_w3geom(g, B, O, I, D, H, W, dy_batch, x_batch)) return rc;
+    if ((reinterpret_cast<uintptr_t>(dy) & 15) || (reinterpret_cast<uintptr_t>(x) & 3)) return MLAGG_E_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MLAGG_TIMED(K_CONV3X3, st);
+    const dim3 grid(B * g.nslabs * g.nz, (O + 31) / 32, (I + 31) / 32);
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(64), 0, st, dy, x, workspace, g);
+    const int ntaps = 9 * g.nz, n = ntaps * O * I;
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, workspace, B * g.nslabs, O, I, ntaps, dW);
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" size_t mlagg_conv3x3_wgrad_workspace_floats(int B, int O, int I, int H, int W) { return wgrad_ws(B, O, I, 1, H, W); }
+extern "C" size_t mlagg_conv3x3x3_wgrad_workspace_floats(int B, int O, int I, int D, int H, int W) { return D > 1 ? wgrad_ws(B, O, I, D, H, W) : 0; }
 
 // dW (O, I, 3, 3) = weight gradient of y = conv3x3(x, w, padding 1) from dy (B, O, H, W) and x (B, I, H, W); overwritten
 extern "C" int mlagg_conv3x3_wgrad(const float *dy, long dy_batch, const float *x, long x_batch, float *dW, float *workspace, int B,
                                    int O, int I, int H, int W, void *stream)
 {
-    if (!dy || !x || !dW || !workspace) return MLAGG_E_NULLPTR;
-    W3Geom g;
-    if (int rc = make_w3geom(g, B, O, I, H, W, dy_batch, x_batch)) return rc;
-    if ((reinterpret_cast<uintptr_t>(dy) & 15) || (reinterpret_cast<uintptr_t>(x) & 3)) return MLAGG_E_UNSUPPORTED;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    MLAGG_TIMED(K_CONV3X3, st);
-    const dim3 grid(B * g.nslabs, (O + 31) / 32, (I + 31) / 32);
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(64), 0, st, dy, x, workspace, g);
-    const int n = 9 * O * I;
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, workspace, B * g.nslabs, O, I, dW);
-    return (int)hipGetLastError();
+    return wgrad3(dy, dy_batch, x, x_batch, dW, workspace, B, O, I, 1, H, W, stream);
+}
+
+// dW (O, I, 3, 3, 3) of the 3 x 3 x 3 convolution on (B, C, D, H, W) volumes
+extern "C" int mlagg_conv3x3x3_wgrad(const float *dy, long dy_batch, const float *x, long x_batch, float *dW, float *workspace, int B,
+                                     int O, int I, int D, int H, int W, void *stream)
+{
+    if (D <= 1) return MLAGG_E_UNSUPPORTED;
+    return wgrad3(dy, dy_batch, x, x_batch, dW, workspace, B, O, I, D, H, W, stream);
 }

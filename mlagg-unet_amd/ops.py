@@ -1714,6 +1714,7 @@ def conv3x3(x, weight):
 
 
 K19_3D = _os.environ.get("MLAGG_K19_3D", "1") == "1"
+K19_3D_WGRAD = _os.environ.get("MLAGG_K19_3D_WGRAD", "1") == "1"
 
 
 def _conv3x3x3_k19(x, xb, w, transposed, O, I, dims):
@@ -1757,7 +1758,14 @@ class Conv3x3x3Fn(torch.autograd.Function):
                 dx = torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1, 1), (1, 1, 1), (1, 1, 1), False, (0, 0, 0), 1,
                                                          (True, False, False))[0]
         if ctx.needs_input_grad[1]:
-            dW = conv_weight_grad(x if x.is_contiguous() else x.contiguous(), dy, 3, 1).view(w.shape)
+            B = x.shape[0]
+            if K19_3D_WGRAD and lib.mlagg_conv3x3x3_wgrad_supported(O, I, *dims):
+                dW = torch.empty(O, I, 3, 3, 3, device=x.device, dtype=torch.float32)
+                ws = torch.empty(lib.mlagg_conv3x3x3_wgrad_workspace_floats(B, O, I, *dims), device=x.device, dtype=torch.float32)
+                _lib.check(lib.mlagg_conv3x3x3_wgrad(_ptr(dy), O * dims[0] * dims[1] * dims[2], _ptr(x), x.stride(0), _ptr(dW), _ptr(ws),
+                                                     B, O, I, *dims, _stream()), "mlagg_conv3x3x3_wgrad")
+            else:                                               # widths that are not multiples of 8: K15 on padded copies
+                dW = conv_weight_grad(x if x.is_contiguous() else x.contiguous(), dy, 3, 1).view(w.shape)
         return dx, dW
 
 

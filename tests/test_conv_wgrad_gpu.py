@@ -177,10 +177,11 @@ def test_conv3x3_matches_float64(monkeypatch, B, I, O, H, W, sliced):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,I,O,dims", [(1, 32, 32, (6, 10, 16)), (2, 16, 48, (5, 7, 9)), (1, 64, 32, (3, 8, 12)), (1, 32, 40, (2, 4, 12)),
-                                        (1, 32, 32, (24, 40, 40))])
+                                        (1, 32, 32, (24, 40, 40)), (2, 48, 33, (4, 6, 8)), (1, 16, 16, (2, 2, 24))])
 def test_conv3x3x3_matches_float64(B, I, O, dims):
     """K19 with nine kernel rows: 3 x 3 x 3 convolution straight on the unpadded NCDHW volume -- output, data gradient (the same
-    kernel on the transposed, tap-flipped weight) and weight gradient (K15 on padded copies made in backward) against float64 conv3d.
+    kernel on the transposed, tap-flipped weight) and weight gradient (K19's with one wave per kernel slice where W % 8 == 0 -- row
+    halves of a block in different image rows at W = 8, 24, 40 -- else K15 on padded copies made in backward) against float64 conv3d.
     Odd widths (one-pixel runs), two-slice volumes, output widths off the 32-channel tiles, a stage of BASELINE configs[3] at 1/64."""
     from mlagg_unet_amd import ops
     g = torch.Generator().manual_seed(I + O + dims[0])
