@@ -397,6 +397,9 @@ int make_w3geom(W3Geom &g, int B, int O, int I, int D, int H, int W, long dy_bat
     const int og = (O + 31) / 32, ig = (I + 31) / 32;
     static const int target = [] { const char *e = getenv("MLAGG_K19W_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2048; }();
     int per_sample = (target + B * og * ig * g.nz - 1) / (B * og * ig * g.nz);
+    // partial blocks are (taps x O x I) floats each: keep their total under 256 MB (wide layers have many channel tiles per slab anyway)
+    const long cap = (256L << 20) / (4L * 9 * g.nz * O * I) / B;
+    if (per_sample > cap) per_sample = (int)cap;
     if (per_sample < 1) per_sample = 1;
     int slab = (int)((P + per_sample - 1) / per_sample);
     slab = ((slab + 15) / 16) * 16;
