@@ -23,10 +23,10 @@ const char *const kNames[K_COUNT] = {
     "selscan_fwd_kernel<false>", "selscan_chunk_prefix", "selscan_fwd_kernel<true>", "selscan_bwd_local_kernel",
     "selscan_bwd_kernel", "selscan_reduce_partials", "local_attn_fwd_kernel", "local_attn_bwd_a_kernel",
     "local_attn_bwd_b_kernel", "pooled_attn_fwd_kernel", "pooled_attn_bwd1_kernel",
-    "pooled_attn_bwd2_kernel", "dwconv_tiled_kernel<fwd>", "dwconv_tiled_kernel<dgrad>", "dwconv_bwd_weight_kernel", "linear_wgrad_kernel", "layernorm_fwd_kernel",
+    "pooled_attn_bwd2_kernel", "dwconv_tiled_kernel<fwd>", "dwconv_tiled_kernel<dgrad>", "dwconv_bwd_weight_kernel", "linear weight gradient (K5w: linear_wgrad_kernel / linear_wgrad_x3_kernel + reduce)", "layernorm_fwd_kernel",
     "layernorm_bwd_kernel", "dwconv_nchw_fwd_kernel", "dwconv_nchw_bwd (data+weight+reduce)",
     "cross_scan_kernel<false>", "cross_scan_kernel<true>", "gate_fwd_kernel", "gate_bwd_kernel",
-    "linear_mfma_kernel<true>", "linear_mfma_kernel<false>", "row_scale_kernel", "dice_ce_stats_kernel", "dice_ce_grad_kernel", "transpose_tile_kernel", "bias gradient (plane_sum / column_sum)", "plane_norm_fwd_kernel", "plane_norm_bwd_kernel", "adamw (sumsq + update)", "flash_fwd_kernel", "flash_bwd (dq + dk/dv)", "channel_epilogue (bias + residual + GELU)",
+    "linear forward (K5: linear_mfma_kernel<true> / linear_lp_kernel<true, MODE>; with x3 also the data gradient on W^T)", "linear data gradient (K5: linear_mfma_kernel<false> / linear_lp_kernel<false, MODE>)", "row_scale_kernel", "dice_ce_stats_kernel", "dice_ce_grad_kernel", "transpose_tile_kernel", "bias gradient (plane_sum / column_sum)", "plane_norm_fwd_kernel", "plane_norm_bwd_kernel", "adamw (sumsq + update)", "flash_fwd_kernel", "flash_bwd (dq + dk/dv)", "channel_epilogue (bias + residual + GELU)",
     "sel1_fwd_kernel<2, false>", "sel1_fwd_kernel<2, true>", "sel1_bwd_local_kernel<2>", "sel1_bwd_kernel<2>",
     "sel1_fwd_kernel<R != 2, false>", "sel1_fwd_kernel<R != 2, true>", "sel1_bwd_local_kernel<R != 2>", "sel1_bwd_kernel<R != 2>",
     "sel1_prefix_kernel", "sel1 reductions (step partials + per-chunk rows)",
