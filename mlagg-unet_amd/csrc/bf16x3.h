@@ -21,7 +21,9 @@ __device__ __forceinline__ unsigned pack2(float a, float b)
 
 // (a, b) -> three dwords, each holding one bf16 piece of a (low half) and of b (high half).  Pieces by TRUNCATION: hi = the top 16
 // bits of x, r = x - hi (exact), mid = the top 16 bits of r, lo = the top 16 bits of r - mid.  A 24-bit significand splits into
-// 8 + 8 + 8 bits without remainder (truncation never borrows), so hi + mid + lo == x exactly for normal numbers.  11 full-rate
+// 8 + 8 + 8 bits without remainder (truncation never borrows), so hi + mid + lo == x exactly for normal numbers.  Non-finite
+// operands: a NaN stays a NaN; an infinity gives hi = inf and a NaN residual, i.e. the product is NaN where the fp32 instruction
+// would return +-inf (both poison the step the same way; the fp32 train step has no scaler that relies on telling them apart).  11 full-rate
 // instructions per pair (3 v_perm_b32, 4 v_and, 4 v_sub); rounding each piece with v_cvt_pk_bf16_f32 cost 18 (the compiler
 // converts the two values separately and re-packs them with SDWA ors).
 __device__ __forceinline__ void split3(float a, float b, unsigned &hi, unsigned &mid, unsigned &lo)
