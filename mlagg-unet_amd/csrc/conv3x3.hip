@@ -1,17 +1,23 @@
-// K19 -- dense 3 x 3 convolutions (stride 1, zero padding 1) on channel-major (NCHW) maps as nine shifted GEMMs on the 16-bit
-// matrix instructions with fp32 accuracy (bf16x3.h):
+// K19 -- dense 3 x 3 (and 3 x 3 x 3) convolutions (stride 1, zero padding 1) on channel-major (NCHW / NCDHW) maps as nine (27) shifted
+// GEMMs on the 16-bit matrix instructions with fp32 accuracy (bf16x3.h):
 //   y[b][o][p] = sum_t sum_i w[o][i][t] x[b][i][p + off_t],   off_t = (ty - 1) W + (tx - 1),  zero outside the image
 // -- the forward of the convolutional stem / decoder blocks (nnUNetTrainer_MLAgg_2D_dt_MS.py:1340-1368 UnetrBasicBlock / UnetrUpBlock
 // -> UnetResBlock conv1 / conv2, :972-1001 Project, MambaSkip.py:706-712 conv branches) and, on the transposed weight with the taps
 // flipped, their data gradient.  MIOpen runs these as fp32 Winograd kernels at 64-104 TFLOP/s (2.8 ms forward + 2.5 ms data
 // gradient per 256 x 256 step); six bf16 MFMAs per 16-deep block cost 0.375 of the eight fp32 ones.
 //
-// No padded copy, no LDS, no layout change (the structure of K18's forward): D rows = output channels, D columns = pixels; per
-// 16-channel block and tap a lane issues eight loads (its T consecutive pixels, shifted by the tap, of eight input channels; all
-// but the first tap of a block hit L1 / L2), zeroes what falls outside the image (2-bit per-pixel source codes made once per lane), splits the
-// values into bf16 pieces and feeds 6 TO TP MFMAs.  The weights are pre-split once per launch by a tiny kernel into three bf16
-// images [tap][o][i] (i contiguous: a lane's A operand is one 16-byte load per image) -- for the data gradient that kernel also
-// transposes (o <-> i) and flips the taps.  One wave per workgroup, every load unconditional (clamped address, masked value).
+// No padded copy and no layout change.  Forward / data gradient: D rows = output channels, D columns = pixels, contraction = input
+// channel.  A lane owns TP consecutive pixels of ONE image row; per 16-channel block and kernel ROW (ky; (kz, ky) for 3 x 3 x 3
+// volumes: nine rows) it loads that run and its two neighbours for eight channels, zeroes what is padding (a row flag and two edge
+// flags made once per lane), splits these TP + 2 source elements ONCE into bf16 pieces and serves the row's three taps from them
+// (tap kx, pixel j reads element j + kx).  The weights are pre-split once per launch by a tiny kernel into three bf16 images
+// [tap][o][i] -- for the data gradient that kernel also transposes (o <-> i) and flips the taps -- and a 4-wave workgroup shares the
+// three taps of the current kernel row in LDS (double-buffered).  Weight gradient: the pixel is the contraction (K18's weight
+// gradient with nine shifted B operands); a wave owns 32 x 32 channels x 9 taps (one kernel slice kz for volumes); per 16-pixel
+// block and kernel row it loads the aligned 8-pixel run of its x row and the two neighbours, splits the ten values once -- the
+// pairs (p-1, p) .. (p+7, p+8) are the dx = -1 / +1 operands, the centre tap's pairs are one v_alignbit_b32 each.  Every load is
+// unconditional (clamped address, masked value); partial blocks are summed in a fixed order (no atomics).  History of the forms
+// and their measurements: DESIGN.md section 4i.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
