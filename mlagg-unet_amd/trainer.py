@@ -12,6 +12,7 @@ Mirrors the reference's trainer surface on the hot path:
 One process per GPU; ``torch.distributed`` backend "nccl" is RCCL on ROCm (xGMI inside a node).
 """
 import math
+import os
 from typing import List
 
 import torch
@@ -282,17 +283,112 @@ def split_batch_size(global_batch, world_size):
     return [base + (1 if r < rem else 0) for r in range(world_size)]
 
 
+class BucketedGradSync:
+    """Data-parallel gradient exchange for device parameters without DistributedDataParallel's per-parameter kernels.
+
+    torch's DDP copies every gradient into its bucket with its own kernel (and scales it there): 456 launches of ~4 us per step for
+    the 524 gradients of this network (profiles/round3_j_ddp_single_rank_trace.md: 1.8 ms of a 38 ms step, before a single byte is
+    exchanged).  Here the parameters are cut into buckets in reverse registration order (the order backward produces them; a small
+    first bucket so that the exchange starts early); when the last gradient of a bucket has been accumulated
+    (``register_post_accumulate_grad_hook``) the bucket's gradients are gathered into its flat buffer by ONE multi-tensor copy,
+    scaled by 1 / world once, and all-reduced asynchronously (RCCL on its own stream, overlapped with the rest of backward).
+    ``finish()`` -- called by ``train_step`` after backward -- waits for the exchanges and points every ``p.grad`` at its slice of
+    the averaged buffer (no scatter copy: the optimizer reads the gradients where the collective left them)."""
+
+    def __init__(self, module, bucket_cap_mb=25, first_bucket_mb=1, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group)
+        params = [p for p in module.parameters() if p.requires_grad]
+        if not params:
+            raise RuntimeError("BucketedGradSync: no trainable parameters")
+        if any(p.dtype != torch.float32 for p in params) or len({p.device for p in params}) != 1:
+            raise RuntimeError("BucketedGradSync: fp32 parameters on one device expected")
+        # replicas start from rank 0's parameters (what DDP's constructor does), in one coalesced broadcast
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1) for p in params])
+            dist.broadcast(flat, 0, group=group)
+            off = 0
+            for p in params:
+                p.copy_(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        self.buckets, cur, n = [], [], 0
+        cap = int(first_bucket_mb * (1 << 20)) // 4
+        for p in reversed(params):
+            cur.append(p)
+            n += p.numel()
+            if n >= cap:
+                self._close(cur, n)
+                cur, n, cap = [], 0, int(bucket_cap_mb * (1 << 20)) // 4
+        if cur:
+            self._close(cur, n)
+        self._where = {}
+        for bi, b in enumerate(self.buckets):
+            for p in b["params"]:
+                self._where[p] = bi
+                p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def _close(self, params, n):
+        flat = torch.zeros(n, device=params[0].device, dtype=torch.float32)
+        views, off = [], 0
+        for p in params:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.buckets.append({"params": list(params), "flat": flat, "views": views, "ready": 0, "handle": None})
+
+    def _on_grad(self, p):
+        b = self.buckets[self._where[p]]
+        b["ready"] += 1
+        if b["ready"] == len(b["params"]):
+            torch._foreach_copy_(b["views"], [q.grad for q in b["params"]])
+            if self.world > 1:
+                b["flat"].mul_(1.0 / self.world)
+            b["handle"] = self.dist.all_reduce(b["flat"], group=self.group, async_op=True)
+
+    def finish(self):
+        """After backward: wait for every bucket's exchange and hand the averaged gradients to the parameters."""
+        for b in self.buckets:
+            if b["ready"] != len(b["params"]):
+                missing = len(b["params"]) - b["ready"]
+                b["ready"] = 0
+                raise RuntimeError(f"BucketedGradSync: {missing} parameter(s) of a bucket received no gradient in this backward "
+                                   "(every trainable parameter must take part in every step)")
+            b["handle"].wait()
+            b["handle"], b["ready"] = None, 0
+            for p, v in zip(b["params"], b["views"]):
+                p.grad = v
+
+
+GRAD_SYNC = os.environ.get("MLAGG_GRAD_SYNC", "bucketed")     # "ddp": torch's DistributedDataParallel on the device too
+
+
 def wrap_ddp(model, device_index=None, bucket_cap_mb=25):
-    """DistributedDataParallel over RCCL with gradient buckets overlapped with backward.  The
-    never-used ``dummy_tensor`` (reference T:1362) is frozen (``requires_grad`` False: DDP registers only
-    parameters that require a gradient), so ``find_unused_parameters`` can stay False (SURVEY finding 7a)."""
-    from torch.nn.parallel import DistributedDataParallel as DDP
+    """The data-parallel wrapper of the train step (reference nnUNetTrainer.py:205-207).  The never-used ``dummy_tensor``
+    (reference T:1362) is frozen (``requires_grad`` False: only parameters that require a gradient are exchanged), so no
+    unused-parameter search is needed (SURVEY finding 7a).
+    Device parameters: the network itself comes back with a ``BucketedGradSync`` attached (``network._mlagg_grad_sync``; ``.module``
+    is the network, as the reference's code expects of a DDP wrapper) -- ``train_step`` calls its ``finish()`` after backward.
+    Host parameters (the gloo tier) and MLAGG_GRAD_SYNC=ddp: torch's DistributedDataParallel with gradient buckets as views."""
     dummy = getattr(model, "dummy_tensor", None)
     if isinstance(dummy, torch.nn.Parameter):
         dummy.requires_grad_(False)
+    on_device = all(p.is_cuda for p in model.parameters())
+    if on_device and GRAD_SYNC != "ddp":
+        sync = BucketedGradSync(model, bucket_cap_mb=bucket_cap_mb)
+        object.__setattr__(model, "_mlagg_grad_sync", sync)
+        object.__setattr__(model, "module", model)          # not a registered sub-module: state_dict keys stay the network's own
+        return model
+    from torch.nn.parallel import DistributedDataParallel as DDP
     ids = None if device_index is None else [device_index]
     return DDP(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True,
                broadcast_buffers=False)
+
+
+def finish_grad_sync(network):
+    """Wait for the bucketed gradient exchange of ``wrap_ddp`` (a no-op for plain and DistributedDataParallel networks)."""
+    sync = getattr(network, "_mlagg_grad_sync", None)
+    if sync is not None:
+        sync.finish()
 
 
 def set_deterministic(enabled=True):
@@ -326,6 +422,7 @@ def train_step(network, optimizer, data, target: List[torch.Tensor], batch_dice=
     loss = deep_supervision_loss(output, target, batch_dice, ddp) if loss_fn is None else loss_fn(output, target)
     if grad_scaler is not None:
         grad_scaler.scale(loss).backward()
+        finish_grad_sync(network)
         grad_scaler.unscale_(optimizer)
         if isinstance(optimizer, ClipAdamW):
             grad_scaler.step(optimizer, max_norm=clip)
@@ -335,6 +432,7 @@ def train_step(network, optimizer, data, target: List[torch.Tensor], batch_dice=
         grad_scaler.update()
         return loss.detach()
     loss.backward()
+    finish_grad_sync(network)
     if isinstance(optimizer, ClipAdamW):
         optimizer.step(max_norm=clip)                      # norm, clip coefficient and AdamW on the device, two launches
     else:
@@ -354,7 +452,7 @@ class GraphedTrainStep:
     profiles/round3_ddp_graph_capture_segfault.log), so a DistributedDataParallel network is refused here."""
 
     def __init__(self, network, optimizer, data, target, batch_dice=True, clip=12.0, warmup=3):
-        if isinstance(network, torch.nn.parallel.DistributedDataParallel):
+        if isinstance(network, torch.nn.parallel.DistributedDataParallel) or getattr(network, "_mlagg_grad_sync", None) is not None:
             raise RuntimeError("GraphedTrainStep: a DistributedDataParallel network cannot be captured on this build "
                                "(segmentation fault inside the capture); run the data-parallel step eagerly")
         self.data = data.clone()

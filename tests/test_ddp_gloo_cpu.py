@@ -218,3 +218,50 @@ def test_validation_epoch_end_reduces_counts_over_ranks():
     for mean, per_class, loss in res:
         assert abs(mean - single["mean_fg_dice"]) < 1e-12 and abs(loss - 1.5) < 1e-12
         assert per_class == single["dice_per_class_or_region"]
+
+
+def _bucketed_case(rank, world):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import mlagg_unet_amd  # noqa: F401
+    from mlagg_unet_amd import trainer
+    torch.manual_seed(rank)                                     # replicas start DIFFERENT: the constructor must broadcast rank 0's
+    net = torch.nn.Sequential(torch.nn.Linear(6, 300), torch.nn.Tanh(), torch.nn.Linear(300, 300), torch.nn.Tanh(),
+                              torch.nn.Linear(300, 4))
+    frozen = torch.nn.Parameter(torch.ones(3), requires_grad=False)
+    net.register_parameter("dummy_tensor", frozen)
+    sync = trainer.BucketedGradSync(net, bucket_cap_mb=0.2, first_bucket_mb=0.001)      # 92 k parameters: several buckets
+    start = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], 0.05)
+    g = torch.Generator().manual_seed(10 + rank)
+    errs = []
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        x = torch.randn(7, 6, generator=g)
+        net(x).square().mean().backward()
+        local = [p.grad.clone() for p in net.parameters() if p.requires_grad]
+        sync.finish()
+        for p, l in zip([p for p in net.parameters() if p.requires_grad], local):
+            want = l.clone()
+            dist.all_reduce(want)
+            errs.append(float((p.grad - want / world).abs().max()))
+            assert p.grad.is_contiguous() and p.grad.shape == p.shape
+        opt.step()
+    # a step in which a parameter gets no gradient is an error, not a silent stale exchange
+    opt.zero_grad(set_to_none=True)
+    net[0](torch.randn(2, 6)).sum().backward()
+    try:
+        sync.finish()
+        partial = "no error"
+    except RuntimeError as e:
+        partial = str(e)
+    return [start, torch.cat([p.detach().reshape(-1) for p in net.parameters()]), max(errs), len(sync.buckets), partial]
+
+
+def test_bucketed_grad_sync_averages_like_ddp():
+    res = _run(_bucketed_case)
+    assert torch.equal(res[0][0], res[1][0])                   # rank 0's parameters everywhere after construction
+    assert torch.equal(res[0][1], res[1][1])                   # replicas identical after 3 steps
+    for _, _, err, nb, partial in res:
+        assert err < 1e-7 and nb >= 3
+        assert "received no gradient" in partial
