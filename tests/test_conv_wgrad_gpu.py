@@ -198,3 +198,31 @@ def test_conv3x3x3_matches_float64(B, I, O, dims):
     for name, got, want, tol in (("y", yp, yr, 2e-6), ("dx", xp.grad, xr.grad, 2e-6), ("dW", wp.grad, wr.grad, 1e-5)):
         err = float((got.detach().double() - want.detach()).abs().max() / want.detach().abs().max())
         assert err < tol, (name, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,I,O,H", [("3x3", 48, 48, 256), ("3x3", 96, 48, 256), ("3x3", 96, 96, 128), ("1x1", 96, 192, 128), ("1x1", 96, 48, 256)])
+def test_split_bf16_convolutions_at_the_headline_sizes(kind, I, O, H):
+    """K18 / K19 at the full batch-10 shapes of BASELINE configs[1], where float64 on the host is too slow to be the checker: against
+    the library's fp32 convolution on the same inputs (two independent fp32 implementations: 2e-5 of the maximum) and through
+    linearity in the input (conv(a x1 + x2) = a conv(x1) + conv(x2)), forward, data gradient and weight gradient."""
+    from mlagg_unet_amd import ops
+    g = torch.Generator().manual_seed(H + I + O)
+    k = 3 if kind == "3x3" else 1
+    x1 = torch.randn(10, I, H, H, generator=g).to(DEV)
+    x2 = torch.randn(10, I, H, H, generator=g).to(DEV)
+    w = (torch.randn(O, I, k, k, generator=g) * (k * k * I) ** -0.5).to(DEV)
+    gy = torch.randn(10, O, H, H, generator=g).to(DEV)
+    fn = ops.conv3x3 if kind == "3x3" else ops.conv1x1
+    xs, ws = x1.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = fn(xs, ws)
+    y.backward(gy)
+    xr, wr = x1.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 1, k // 2)
+    yr.backward(gy)
+    for name, got, want in (("y", y, yr), ("dx", xs.grad, xr.grad), ("dW", ws.grad, wr.grad)):
+        err = float((got.detach() - want.detach()).abs().max() / want.detach().abs().max())
+        assert err < 2e-5, (name, err)
+    with torch.no_grad():
+        lin = fn(1.5 * x1 + x2, w) - (1.5 * y.detach() + fn(x2, w))
+        assert float(lin.abs().max()) < 2e-5 * float(y.detach().abs().max())
