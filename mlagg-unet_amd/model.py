@@ -677,7 +677,7 @@ class ConvolutionalGLU(nn.Module):  # reference M:559-577
         self.fc2 = Linear(hidden, dim)
 
     def forward(self, x, H, W):
-        xg, vg = self.fc1(x).split([self.hidden, self.hidden], dim=-1)
+        xg, vg = ops.split_cols(self.fc1(x), (self.hidden, self.hidden))      # the depthwise convolution's backward writes its half in place
         g = ops.dwconv3x3_nlc(xg, self.dwconv.dwconv.weight, self.dwconv.dwconv.bias, H, W, silu=True)
         return self.fc2(g * vg)
 
