@@ -16,6 +16,7 @@ stage (the reference flips NCHW <-> NLC per block and again around every depthwi
 produced once per stage for the MIOpen convolutions that consume the stage output.
 """
 import math
+import os
 from typing import Sequence
 
 import torch
@@ -244,6 +245,77 @@ class RMSNormWeight(nn.Module):
         self.weight = nn.Parameter(torch.ones(dim))
 
 
+WEIGHT_STACKS = os.environ.get("MLAGG_WEIGHT_STACKS", "1") == "1"      # 0: torch.cat per use (the round-2 form)
+
+
+class _StackFn(torch.autograd.Function):
+    """The stacked matrix as a function of its sources: forward hands out the (already refreshed) buffer, backward cuts the gradient
+    into the sources' row blocks (views: what ``torch.cat``'s backward does)."""
+
+    @staticmethod
+    def forward(ctx, buf, *srcs):
+        ctx.rows = [int(t.shape[0]) for t in srcs]
+        return buf.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        out, off = [None], 0
+        for r in ctx.rows:
+            out.append(g[off:off + r])
+            off += r
+        return tuple(out)
+
+
+class _Stack:
+    """Several parameters (or row slices of parameters) stacked along dim 0 for ONE projection.  ``torch.cat`` per use cost 48
+    launches per forward of the 256 x 256 network (24 weight + 24 bias stacks: 0.28 ms of device time and as much host time); here
+    every stack owns a buffer, the network refreshes ALL of them with one multi-tensor copy at the start of a forward
+    (``refresh_stacks``), and a stack used outside that (a block called on its own) refreshes itself.  Not parameters, not
+    buffers: state_dict keys are untouched."""
+
+    def __init__(self, sources):
+        self.sources, self.buf, self.fresh = sources, None, False          # sources: bound method -> list of tensors
+
+    def _views(self, srcs):
+        rows = sum(int(t.shape[0]) for t in srcs)
+        shape = (rows,) + tuple(srcs[0].shape[1:])
+        if self.buf is None or self.buf.device != srcs[0].device or tuple(self.buf.shape) != shape:
+            self.buf = torch.empty(shape, device=srcs[0].device, dtype=srcs[0].dtype)
+            self.fresh = False
+        out, off = [], 0
+        for t in srcs:
+            out.append(self.buf[off:off + t.shape[0]])
+            off += int(t.shape[0])
+        return out
+
+    def get(self):
+        srcs = self.sources()
+        if not WEIGHT_STACKS:
+            return torch.cat(srcs)
+        views = self._views(srcs)
+        if not self.fresh:
+            with torch.no_grad():
+                torch._foreach_copy_(views, [t.detach() for t in srcs])
+        self.fresh = False                                      # consumed: the next use without a network refresh copies again
+        return _StackFn.apply(self.buf, *srcs)
+
+
+def refresh_stacks(stacks):
+    """One multi-tensor copy for every stack of a network (called at the start of its forward)."""
+    if not WEIGHT_STACKS:
+        return
+    dst, src = [], []
+    for st in stacks:
+        srcs = st.sources()
+        dst += st._views(srcs)
+        src += [t.detach() for t in srcs]
+    if dst:
+        with torch.no_grad():
+            torch._foreach_copy_(dst, src)
+    for st in stacks:
+        st.fresh = True
+
+
 class AggregatedAttention(nn.Module):
     """Reference T:625-784 on token-major input.  ``variant`` "B": logit scale head_dim^-0.5 (fp32 path,
     T:762-777); "A": 1/head_dim, the shipped flash path's double scaling (T:688 + T:745-750)."""
@@ -267,6 +339,18 @@ class AggregatedAttention(nn.Module):
         self.q = Linear(dim, dim)
         self.kv = Linear(dim, 2 * dim)
         self.lepe = Conv2d(dim, dim, 3, padding=1, groups=dim)
+        self._w_stack, self._b_stack = _Stack(self._stacked_weights), _Stack(self._stacked_biases)
+
+    def _stacked_weights(self):
+        if self.local:
+            return [self.q.weight, self.kv.weight]
+        d = self.q.weight.shape[0]
+        return [self.q.weight, self.kv.weight[d:], self.sr.weight.view(d, d)]
+
+    def _stacked_biases(self):
+        if self.local:
+            return [self.q.bias, self.kv.bias]
+        return [self.q.bias, self.kv.bias[self.q.bias.shape[0]:], self.sr.bias]
 
     def lambda_full(self):
         return ops.diff_lambda(self.lambda_q1, self.lambda_k1, self.lambda_q2, self.lambda_k2, LAMBDA_INIT)
@@ -278,16 +362,14 @@ class AggregatedAttention(nn.Module):
         if self.local:
             # q and kv in ONE GEMM over stacked weights (one read of x, one gradient into x); the kernel
             # takes the q / kv column blocks of the (B, N, 3d) result as strided views
-            qkv = ops.linear(x, torch.cat([self.q.weight, self.kv.weight]), torch.cat([self.q.bias, self.kv.bias]))
+            qkv = ops.linear(x, self._w_stack.get(), self._b_stack.get())
             # split_cols: the q / kv backward kernels write into one (B, N, 3d) gradient buffer (no concatenation)
             q, kv = ops.split_cols(qkv, (d, 2 * d))
             return ops.local_diff_attn(q, kv, lam, self.subln.weight, self.lepe.weight, self.lepe.bias,
                                        self.H, self.W, self.num_heads, self.scale)
         # q, the value half of kv (LePE input; k is discarded at full resolution, T:719) and the 1x1 `sr`
         # conv in ONE GEMM
-        w3 = torch.cat([self.q.weight, self.kv.weight[d:], self.sr.weight.view(d, d)])
-        b3 = torch.cat([self.q.bias, self.kv.bias[d:], self.sr.bias])
-        qvs = ops.linear(x, w3, b3)
+        qvs = ops.linear(x, self._w_stack.get(), self._b_stack.get())
         q, v_full, s_pre = ops.split_cols(qvs, (d, d, d))
         if self.H % self.sr_ratio == 0 and self.W % self.sr_ratio == 0:
             r = self.sr_ratio
@@ -321,6 +403,13 @@ class MLLABlock(nn.Module):
         self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
         self.norm2 = LayerNorm(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
+        self._w_stack, self._b_stack = _Stack(self._stacked_weights), _Stack(self._stacked_biases)
+
+    def _stacked_weights(self):
+        return [self.act_proj.weight, self.in_proj.weight]
+
+    def _stacked_biases(self):
+        return [self.act_proj.bias, self.in_proj.bias]
 
     def forward_tokens(self, x, xn=None, next_norm=None):
         """x -> block(x).  ``xn``: norm1(x) when the caller already has it; ``next_norm``: the LayerNorm the caller applies to the
@@ -331,8 +420,7 @@ class MLLABlock(nn.Module):
         if xn is None:
             xn = self.norm1(x)
         # act_proj and in_proj in ONE GEMM over stacked weights: (B, N, 2C) = [act | in]
-        ai = ops.linear(xn, torch.cat([self.act_proj.weight, self.in_proj.weight]),
-                        torch.cat([self.act_proj.bias, self.in_proj.bias]))
+        ai = ops.linear(xn, self._w_stack.get(), self._b_stack.get())
         h = C // 2
         act_pre, xa_in, za_in = ops.split_cols(ai, (C, h, h))
         # depthwise conv per channel half: the halves come out contiguous for the branch projections
@@ -779,7 +867,11 @@ class MLLA_Uper(nn.Module):  # reference T:1183-1407
             finally:
                 self._dp_pool.end()
 
+    def _stacks(self):
+        return [st for m in self.modules() for st in (getattr(m, "_w_stack", None), getattr(m, "_b_stack", None)) if isinstance(st, _Stack)]
+
     def _forward(self, x_in):
+        refresh_stacks(self._stacks())                      # every stacked projection weight / bias in one multi-tensor copy
         hs = self.mlla(x_in)
         hs[1:] = self.mambaskip(hs[1:])
         ds = self.deep_supervision

@@ -49,3 +49,31 @@ def test_residual_norm_off_the_device_is_residual_then_norm():
     x, n = dp.residual_norm(skip, branch, norm)
     assert torch.equal(x, skip + branch)
     assert torch.allclose(n, torch.nn.functional.layer_norm(skip + branch, (96,), norm.weight, norm.bias, norm.eps))
+
+
+def test_stacked_projection_weights_refresh_route_gradients_and_survive_deepcopy():
+    """model._Stack: values = torch.cat of the sources (a row slice of kv.weight and the 1 x 1 convolution's weight among them),
+    gradients land in the sources, a refreshed stack is consumed once, a copy of the module stacks ITS parameters, and the
+    state_dict has the reference's keys only."""
+    import copy
+    att = PM.AggregatedAttention(96, (8, 8), 2, False, 2, "B")
+    d = 96
+    w, b = att._w_stack.get(), att._b_stack.get()
+    assert torch.equal(w, torch.cat([att.q.weight, att.kv.weight[d:], att.sr.weight.view(d, d)]))
+    assert torch.equal(b, torch.cat([att.q.bias, att.kv.bias[d:], att.sr.bias]))
+    (w.sum() * 2 + b.sum()).backward()
+    assert torch.equal(att.q.weight.grad, torch.full_like(att.q.weight, 2.0))
+    assert float(att.kv.weight.grad[:d].abs().max()) == 0 and torch.equal(att.kv.weight.grad[d:], torch.full((d, d), 2.0))
+    assert torch.equal(att.sr.weight.grad, torch.full_like(att.sr.weight, 2.0)) and torch.equal(att.sr.bias.grad, torch.ones(d))
+    with torch.no_grad():
+        att.q.weight.add_(1.0)                                  # an optimizer step
+    assert torch.equal(att._w_stack.get()[:d].detach(), att.q.weight.detach())      # a stack nobody refreshed copies on use
+    PM.refresh_stacks([att._w_stack])
+    assert att._w_stack.fresh
+    att._w_stack.get()
+    assert not att._w_stack.fresh                              # consumed: the next forward refreshes again
+    c = copy.deepcopy(att)
+    with torch.no_grad():
+        c.q.weight.zero_()
+    assert float(c._w_stack.get()[:d].abs().max()) == 0 and float(att._w_stack.get()[:d].abs().max()) > 0
+    assert sorted(att.state_dict()) == sorted(k for k in att.state_dict() if "stack" not in k) and len(att.state_dict()) == 15
