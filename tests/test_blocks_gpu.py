@@ -875,3 +875,20 @@ def test_linear_wgrad_bf16x3_matches_float64(M, O, I):
     assert e3 < 2e-6 and e3 < 1.5 * e1 + 1e-7, (e3, e1)
     bref = dy.double().sum(0)
     assert float((out["x3"][1].double() - bref).abs().max()) < 1e-3 * max(1.0, float(bref.abs().max()))
+
+
+@gpu
+@pytest.mark.parametrize("M,O,I", [(16384, 192, 96), (9000, 140, 96), (8200, 52, 100)])
+def test_linear_lp_dgrad_abi_in_split_bf16_mode(M, O, I):
+    """`mlagg_linear_lp_dgrad(..., MLAGG_DTYPE_BF16X3)`: the data gradient on the UNtransposed weight (the entry point a binding may
+    call directly; the model itself runs the forward kernel on W^T) against float64, ragged M / O / I."""
+    from mlagg_unet_amd import _lib
+    lib = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(M + O)
+    dy = torch.randn(M, O, generator=g).to(DEV)
+    w = (torch.randn(O, I, generator=g) * O ** -0.5).to(DEV)
+    dx = torch.full((M, I), float("nan"), device=DEV)
+    _lib.check(lib.mlagg_linear_lp_dgrad(dy.data_ptr(), O, w.data_ptr(), dx.data_ptr(), I, M, O, I, 3, st), "dgrad x3")
+    ref = dy.double() @ w.double()
+    assert float((dx.double() - ref).abs().max() / ref.abs().max()) < 3e-6
