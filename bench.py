@@ -300,7 +300,7 @@ def main():
     gemm_db = gemm_tuning.use_tuned_gemms(enabled=mode == "auto" and args.precision is None and args.config == 2)
     torch.manual_seed(0)
     net = model.build_network_architecture(IMG, cfg["in_ch"], N_CLASSES, True, cfg["variant"], cfg["precision"]).to(dev).train()
-    use_graph = args.graph and not ddp and not args.no_graph and cfg["precision"] == "fp32"      # DDP: eager (trainer.GraphedTrainStep)
+    use_graph = args.graph and not ddp and not args.no_graph and cfg["precision"] != "fp16"      # DDP: eager (trainer.GraphedTrainStep)
     opt, sched = trainer.configure_optimizers(net, capturable=use_graph)
     sched.step(0)
     step_net = trainer.wrap_ddp(net, dev_index) if ddp else net
@@ -357,6 +357,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the path nnUNetv2_train drives reads the loss back every step (`l.detach().cpu().numpy()`, reference B:863; the plugin's
+    # train_step mirrors it): the same steps once more with that host synchronisation, reported beside the headline
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        float(one_step().cpu())
+    dt_synced = time.perf_counter() - t1
+
     if not args.no_roofline and dominant is not None:
         if use_graph:
             # events cannot be read back per replay from inside a graph: time the dominant kernel live over
@@ -394,6 +402,10 @@ def main():
                        "parallelism": f"dp{world}" + (" (single-rank RCCL rehearsal of the DDP path)" if ddp and world == 1 else ""),
                        "final_loss": round(float(loss), 5),
                        "launch": "hipGraph replay of the whole step" if use_graph else "eager",
+                       "ms_per_step_with_loss_readback": round(1e3 * dt_synced / args.steps, 3),
+                       "images_per_sec_with_loss_readback": round(args.batch * world * args.steps / dt_synced, 3),
+                       "distributed": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank0_device": str(dev),
+                                        "grad_sync": trainer.GRAD_SYNC} if ddp else None),
                        "miopen": "tuned find-db (mlagg-unet_amd/miopen_db)" if miopen_db else "immediate mode",
                        "library_gemm": "TunableOp table (mlagg-unet_amd/gemm_db), tuning off" if gemm_db else "library default",
                        "matrix_arithmetic": matrix_arithmetic(cfg["precision"])},

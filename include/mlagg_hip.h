@@ -546,6 +546,11 @@ int mlagg_conv_wgrad_taps(const float *A, long a_batch, long a_row, const float 
 int mlagg_adamw_chunk_elements(void);
 int mlagg_adamw_clip_step(const void *tensor_table, const void *work_list, int n_work, double *sumsq, float lr, float beta1,
                           float beta2, float eps, float weight_decay, float max_norm, int step, void *stream);
+/* The same step for a hipGraph capture of the whole train step (B:833-863 replayed as one graph): nothing that changes between steps
+ * is a launch argument.  lr_dev: one device float (the cosine schedule writes it between replays, B:825); step_dev: one device int32,
+ * advanced by this call before the bias corrections read it.  With max_norm <= 0 the norm pass is skipped, the counter still moves. */
+int mlagg_adamw_clip_step_dev(const void *tensor_table, const void *work_list, int n_work, double *sumsq, const float *lr_dev,
+                              int *step_dev, float beta1, float beta2, float eps, float weight_decay, float max_norm, void *stream);
 
 #ifdef __cplusplus
 }

@@ -62,8 +62,10 @@ adamw_sumsq_kernel(const TensorRow *__restrict__ table, const int2 *__restrict__
 }
 
 __global__ void __launch_bounds__(OPT_TPB)
-adamw_sumsq_reduce_kernel(double *__restrict__ sumsq, int n_work)
+adamw_sumsq_reduce_kernel(double *__restrict__ sumsq, int n_work, int *__restrict__ step_dev)
 {
+    // device-resident step counter (the hipGraph form of the step): advanced here, read by the update kernel behind this one
+    if (step_dev && threadIdx.x == 0) *step_dev += 1;
     __shared__ double red[OPT_TPB];
     double s = 0.0;
     for (int i = threadIdx.x; i < n_work; i += OPT_TPB) s += sumsq[1 + i];
@@ -92,8 +94,16 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
 
 __global__ void __launch_bounds__(OPT_TPB)
 adamw_update_kernel(const TensorRow *__restrict__ table, const int2 *__restrict__ work, const double *__restrict__ sumsq,
-                    AdamArgs a)
+                    AdamArgs a, const float *__restrict__ lr_dev, const int *__restrict__ step_dev)
 {
+    if (lr_dev) {
+        // learning rate and step live on the device (a captured launch cannot carry them as arguments): the same double-precision
+        // bias corrections the host form passes in
+        const double step = (double)*step_dev;
+        a.lr = *lr_dev;
+        a.bias_c1 = (float)(1.0 - pow((double)a.beta1, step));
+        a.bias_c2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, step));
+    }
     const int2 w = work[blockIdx.x];
     const TensorRow t = table[w.x];
     const long long lo = (long long)w.y * CHUNK, hi = min(lo + CHUNK, t.n);
@@ -142,8 +152,31 @@ extern "C" int mlagg_adamw_clip_step(const void *tensor_table, const void *work_
     MLAGG_TIMED(K_ADAMW, st);
     if (max_norm > 0.f) {
         hipLaunchKernelGGL(adamw_sumsq_kernel, dim3(n_work), dim3(OPT_TPB), 0, st, table, work, sumsq);
-        hipLaunchKernelGGL(adamw_sumsq_reduce_kernel, dim3(1), dim3(OPT_TPB), 0, st, sumsq, n_work);
+        hipLaunchKernelGGL(adamw_sumsq_reduce_kernel, dim3(1), dim3(OPT_TPB), 0, st, sumsq, n_work, (int *)nullptr);
     }
-    hipLaunchKernelGGL(adamw_update_kernel, dim3(n_work), dim3(OPT_TPB), 0, st, table, work, sumsq, a);
+    hipLaunchKernelGGL(adamw_update_kernel, dim3(n_work), dim3(OPT_TPB), 0, st, table, work, sumsq, a, (const float *)nullptr,
+                       (const int *)nullptr);
+    return (int)hipGetLastError();
+}
+
+// The same step with the learning rate and the step counter RESIDENT ON THE DEVICE (lr_dev: one float the schedule writes between
+// steps; step_dev: one int32, advanced by this call before it is used), so that the call can be captured into a hipGraph and
+// replayed: nothing that changes from step to step is a launch argument.
+extern "C" int mlagg_adamw_clip_step_dev(const void *tensor_table, const void *work_list, int n_work, double *sumsq,
+                                         const float *lr_dev, int *step_dev, float beta1, float beta2, float eps,
+                                         float weight_decay, float max_norm, void *stream)
+{
+    if (!tensor_table || !work_list || !sumsq || !lr_dev || !step_dev) return MLAGG_E_NULLPTR;
+    if (n_work <= 0) return MLAGG_E_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const TensorRow *table = static_cast<const TensorRow *>(tensor_table);
+    const int2 *work = static_cast<const int2 *>(work_list);
+    AdamArgs a{0.f, beta1, beta2, eps, weight_decay, max_norm, 1.f, 1.f};
+    MLAGG_TIMED(K_ADAMW, st);
+    if (max_norm > 0.f) hipLaunchKernelGGL(adamw_sumsq_kernel, dim3(n_work), dim3(OPT_TPB), 0, st, table, work, sumsq);
+    // without clipping the reduce launch still runs (over zero partials) to advance the step counter
+    hipLaunchKernelGGL(adamw_sumsq_reduce_kernel, dim3(1), dim3(OPT_TPB), 0, st, sumsq, max_norm > 0.f ? n_work : 0, step_dev);
+    hipLaunchKernelGGL(adamw_update_kernel, dim3(n_work), dim3(OPT_TPB), 0, st, table, work, sumsq, a, lr_dev,
+                       (const int *)step_dev);
     return (int)hipGetLastError();
 }

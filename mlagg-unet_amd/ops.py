@@ -624,7 +624,7 @@ def pooled_diff_attn(q, k_pool, v_pool, lam, subln_w, nh, scale):
 # v_mfma_f32_32x32x2_f32.
 K5_X3 = _os.environ.get("MLAGG_K5_X3", "1") == "1"
 _DTYPE_BF16X3 = 3
-WGRAD_MIN_ROWS = 8192      # below this many tokens the library GEMM is no longer the split-K corner case
+WGRAD_MIN_ROWS = int(_os.environ.get("MLAGG_WGRAD_MIN_ROWS", "8192"))      # below this many tokens the library GEMM is no longer the split-K corner case
 K5_MIN_ROWS = int(_os.environ.get("MLAGG_K5_MIN_ROWS", "16384"))     # fp32 forward / dx: K5 from this many tokens on (at 10240 tokens the
 #                            library's split-K kernels win: 80-320 K5 workgroups do not fill 256 CUs evenly; A/B on the step: +0.9 %)
 

@@ -140,13 +140,21 @@ class ClipAdamW(torch.optim.Optimizer):
     ``state_dict`` layout (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``) as ``torch.optim.AdamW``; the clip
     coefficient is computed on the device (no host synchronisation) and the gradients in memory stay unscaled."""
 
-    def __init__(self, params, lr=5e-4, betas=(0.9, 0.999), eps=1e-4, weight_decay=3e-5):
+    def __init__(self, params, lr=5e-4, betas=(0.9, 0.999), eps=1e-4, weight_decay=3e-5, capturable=False):
+        params = list(params)
+        if capturable:
+            # hipGraph form (GraphedTrainStep): the learning rate and the step counter live on the device, as torch's
+            # ``capturable`` optimizers keep them; the schedule writes the tensor between replays
+            lr = torch.tensor(float(lr), device=params[0].device, dtype=torch.float32)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         if len(self.param_groups) != 1:
             # the clip norm is the norm over ALL parameters (clip_grad_norm_(network.parameters(), 12), B:855): one group
             raise RuntimeError("ClipAdamW: one parameter group (the reference passes network.parameters(), T:138)")
+        self.capturable = bool(capturable)
+        self._step_dev = torch.zeros(1, dtype=torch.int32, device=params[0].device) if capturable else None
         self._steps = 0
         self._work = {}
+        self._tables = {}                             # capturable: per parameter set (pinned host table, device table)
         self._sumsq = None
         self._stepped = None                          # ids of the parameters of the first step
 
@@ -158,18 +166,32 @@ class ClipAdamW(torch.optim.Optimizer):
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
         return st
 
+    def steps_done(self):
+        """Optimisation steps so far (capturable: read from the device counter the replays advance; that synchronises)."""
+        return int(self._step_dev.item()) if self.capturable else self._steps
+
     def state_dict(self):
+        n = float(self.steps_done())
         for st in self.state.values():
             if st:
-                st["step"] = torch.tensor(float(self._steps))
+                st["step"] = torch.tensor(n)
         return super().state_dict()
 
     def load_state_dict(self, sd):
+        lr = self.param_groups[0]["lr"]
         super().load_state_dict(sd)
+        if self.capturable:
+            # the device-resident learning rate keeps its ADDRESS (a captured graph reads it): take the value, not the object
+            new = self.param_groups[0]["lr"]
+            lr.fill_(float(new))
+            self.param_groups[0]["lr"] = lr
         self._work.clear()                            # the moment tensors were replaced: cached addresses are stale
+        self._tables.clear()
         self._stepped = None
         steps = [int(st["step"]) for st in self.state.values() if st and "step" in st]
         self._steps = max(steps) if steps else 0
+        if self.capturable:
+            self._step_dev.fill_(self._steps)
 
     @torch.no_grad()
     def step(self, closure=None, max_norm=0.0):
@@ -213,10 +235,27 @@ class ClipAdamW(torch.optim.Optimizer):
             for p in ps:
                 if not (p.grad.is_contiguous() and p.grad.dtype == torch.float32):
                     raise RuntimeError("ClipAdamW: fp32 contiguous gradients expected")
-            table = host.pin_memory().to(dev, non_blocking=True)
             if self._sumsq is None or self._sumsq.device != dev or self._sumsq.numel() != 1 + work.shape[0]:
                 self._sumsq = torch.zeros(1 + work.shape[0], dtype=torch.float64, device=dev)       # [0]: total; one partial per work item
             b1, b2 = group["betas"]
+            if self.capturable:
+                # a table that OUTLIVES the call (a replayed graph reads it): one pinned host copy + one device copy per parameter
+                # set, re-uploaded only when a gradient address changed.  Inside a capture the upload becomes a copy node out of
+                # the pinned buffer, whose content then no longer changes (captured gradients sit at fixed addresses)
+                if key not in self._tables:
+                    self._tables[key] = (torch.full_like(host, -1).pin_memory(), torch.empty_like(host, device=dev))
+                pinned, table = self._tables[key]
+                if not torch.equal(pinned, host):
+                    if not torch.cuda.is_current_stream_capturing():
+                        torch.cuda.current_stream().synchronize()      # an earlier upload may still be reading the pinned buffer
+                    pinned.copy_(host)
+                    table.copy_(pinned, non_blocking=True)
+                _lib.check(lib.mlagg_adamw_clip_step_dev(table.data_ptr(), work.data_ptr(), work.shape[0], self._sumsq.data_ptr(),
+                                                         group["lr"].data_ptr(), self._step_dev.data_ptr(), float(b1), float(b2),
+                                                         float(group["eps"]), float(group["weight_decay"]), float(max_norm),
+                                                         torch.cuda.current_stream().cuda_stream), "mlagg_adamw_clip_step_dev")
+                continue
+            table = host.pin_memory().to(dev, non_blocking=True)
             lr = float(group["lr"])
             _lib.check(lib.mlagg_adamw_clip_step(table.data_ptr(), work.data_ptr(), work.shape[0], self._sumsq.data_ptr(), lr,
                                                  float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
@@ -238,9 +277,9 @@ def configure_optimizers(model, initial_lr=5e-4, weight_decay=3e-5, fused=None, 
     params = list(model.parameters())
     if fused is None:
         fused = all(p.is_cuda for p in params)
-    if not capturable and fused and all(p.is_cuda for p in params):
-        # eager steps on the device: clip + AdamW of all parameters in two launches (K11)
-        opt = ClipAdamW(params, initial_lr, weight_decay=weight_decay, eps=1e-4)
+    if fused and all(p.is_cuda for p in params):
+        # on the device: clip + AdamW of all parameters in three launches (K11); capturable: lr and step counter device-resident
+        opt = ClipAdamW(params, initial_lr, weight_decay=weight_decay, eps=1e-4, capturable=capturable)
         return opt, CosineLRSchedule(opt, t_initial=500, lr_min=1e-6, warmup_t=10, warmup_lr_init=1e-4)
     lr = torch.tensor(initial_lr, device=params[0].device, dtype=torch.float32) if capturable else initial_lr
     opt = torch.optim.AdamW(params, lr, weight_decay=weight_decay, eps=1e-4, fused=fused, capturable=capturable)
@@ -464,6 +503,7 @@ class GraphedTrainStep:
             for _ in range(warmup):
                 body()
         torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()                      # nothing of the warm-up is in flight when the capture rewrites host tables
         optimizer.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):

@@ -546,6 +546,57 @@ def test_clip_adamw_matches_torch(max_norm):
 
 
 @gpu
+@pytest.mark.parametrize("max_norm", [12.0, 0.0])
+def test_capturable_clip_adamw_is_bit_identical_to_the_eager_form_and_replays(max_norm):
+    """The hipGraph form of K11 (learning rate and step counter device-resident, mlagg_adamw_clip_step_dev): bit-identical parameters to
+    the launch-argument form over eager steps, a captured step replays with a NEW learning rate and advancing bias corrections, and the
+    state_dict carries the device counter."""
+    from mlagg_unet_amd import trainer as TR
+    g = torch.Generator().manual_seed(21)
+    shapes = [(7,), (33, 5), (300, 257), (70001,)]
+    pa = [torch.nn.Parameter(torch.randn(s, generator=g).to(DEV)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = TR.ClipAdamW(pa, 5e-4, eps=1e-4, weight_decay=3e-5, capturable=True)
+    ob = TR.ClipAdamW(pb, 5e-4, eps=1e-4, weight_decay=3e-5)
+    assert torch.is_tensor(oa.param_groups[0]["lr"]) and oa.param_groups[0]["lr"].is_cuda
+    static = [torch.zeros(s, device=DEV) for s in shapes]                        # gradients at fixed addresses, as inside a graph
+    for p, st in zip(pa, static):
+        p.grad = st
+    grads = [[torch.randn(s, generator=g).to(DEV) * (0.5 + it) for s in shapes] for it in range(6)]
+    lrs = [5e-4, 5e-4, 3e-4, 3e-4, 1e-4, 7e-5]
+
+    def feed(it):
+        for st, q, gr in zip(static, pb, grads[it]):
+            st.copy_(gr)
+            q.grad = gr.clone()
+        oa.param_groups[0]["lr"].fill_(lrs[it])
+        ob.param_groups[0]["lr"] = lrs[it]
+
+    for it in range(2):                                                          # eager calls of the capturable form
+        feed(it)
+        oa.step(max_norm=max_norm)
+        ob.step(max_norm=max_norm)
+    for p, q in zip(pa, pb):
+        assert torch.equal(p, q)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    feed(2)
+    with torch.cuda.graph(graph):
+        oa.step(max_norm=max_norm)
+    ob_steps = 2
+    # the capture itself executes nothing: parameters unchanged until the first replay
+    for it in range(2, 6):
+        feed(it)
+        graph.replay()
+        ob.step(max_norm=max_norm)
+        ob_steps += 1
+        for p, q in zip(pa, pb):
+            assert torch.equal(p, q), it
+    assert oa.steps_done() == ob_steps == 6
+    assert float(oa.state_dict()["state"][0]["step"]) == 6.0
+
+
+@gpu
 def test_clip_adamw_checkpoint_round_trip_and_failure_modes():
     """state_dict after 2 steps loads into a fresh ClipAdamW AND into torch.optim.AdamW (the reference's checkpoint format,
     nnUNetTrainer.save_checkpoint B:1023-1043); one more step in each lands on the same parameters.  A non-finite gradient

@@ -265,3 +265,34 @@ def test_bucketed_grad_sync_averages_like_ddp():
     for _, _, err, nb, partial in res:
         assert err < 1e-7 and nb >= 3
         assert "received no gradient" in partial
+
+
+def _graph_refusal_case(rank, world):
+    """GraphedTrainStep must refuse a data-parallel network BEFORE it touches a device: torch's DistributedDataParallel wrapper and
+    this package's BucketedGradSync marker alike (capturing the RCCL exchange faulted on this build: DESIGN section 5)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import mlagg_unet_amd  # noqa: F401
+    from mlagg_unet_amd import trainer
+    net = torch.nn.Linear(4, 4)
+    opt = torch.optim.SGD(net.parameters(), 0.1)
+    data, target = torch.zeros(1, 4), [torch.zeros(1, 4)]
+    msgs = []
+    wrapped = trainer.wrap_ddp(torch.nn.Linear(4, 4))                         # host parameters: torch's DDP over gloo
+    assert isinstance(wrapped, torch.nn.parallel.DistributedDataParallel)
+    for candidate in (wrapped, _with_marker(net)):
+        try:
+            trainer.GraphedTrainStep(candidate, opt, data, target)
+        except RuntimeError as e:
+            msgs.append(str(e))
+    return msgs
+
+
+def _with_marker(net):
+    object.__setattr__(net, "_mlagg_grad_sync", object())                     # what wrap_ddp leaves on a device network
+    return net
+
+
+def test_graphed_train_step_refuses_data_parallel_networks():
+    for msgs in _run(_graph_refusal_case):
+        assert len(msgs) == 2 and all("DistributedDataParallel" in m and "eagerly" in m for m in msgs), msgs

@@ -18,7 +18,7 @@ def test_graph_replay_follows_the_eager_trajectory():
     net = model.build_network_architecture((64, 64), 1, 14, True, "B").cuda().eval()      # eval: no DropPath draws to align
     twin = copy.deepcopy(net)
     opt, _ = trainer.configure_optimizers(net, capturable=True)
-    opt_t, _ = trainer.configure_optimizers(twin, capturable=True)
+    opt_t, _ = trainer.configure_optimizers(twin)                                          # the eager, launch-argument form of K11
     batches = [trainer.synthetic_batch(2, 1, 64, 64, 14, seed=40 + i, device="cuda") for i in range(3)]
     # the graph's own warm-up steps (3, on its first batch) are part of the trajectory: mirror them on the twin
     graphed = trainer.GraphedTrainStep(net, opt, *batches[0], batch_dice=True, warmup=3)
