@@ -386,6 +386,33 @@ int mlagg_index_merge(const float *seq, const int *idx, float *tok, long tok_str
 int mlagg_block_sum(const float *wide, float *out, long rows, int K, int CB, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K1f: the whole of SS2D_skip.forward_corev0 behind x_proj (reference MambaSkip.py:405-473) + the four-way sum of M:534 on
+ * TOKEN-MAJOR tensors: the four scan orders of every scale (M:414-422), the dt einsum (M:430-436), `selective_scan_fn(xs, dts,
+ * As, Bs, Cs, Ds, z=None, delta_bias, delta_softplus=True)` (M:445-451) and the inverse re-orderings (M:455-471) in the scan
+ * kernels' own address arithmetic -- no scan-order copy of x, of the projections or of any gradient exists.
+ * Fixed shape (every MLAgg-UNet configuration): 4 directions, d_inner 96, d_state 16, dt_rank 3; L % 4 == 0
+ * (mlagg_msmm_scan_supported says whether a shape qualifies; others take mlagg_cross_scan + mlagg_selscan_lowrank_*).
+ *   xc    (B, L, 96)   conv outputs of all scales concatenated, natural token order (u of all four directions)
+ *   xdbl  (B, L, 144)  x_proj output with the weight rows laid out per direction as [dt0 dt1 dt2 0 | B(16) | C(16)]
+ *   idx   (4, L) int32 token visited by direction k at scan position t (k = 0: row-major, 1: column-major, 2 / 3: their reversals
+ *         inside every scale; scales concatenated in the same order for every direction); every entry must be in [0, L)
+ *   Wdt (384, 3) dt_projs_weight; A (384, 16) = -exp(A_logs); D (384) or NULL; delta_bias (384) or NULL
+ *   y     (B, L, 96)   sum over the four directions at the token's natural position
+ *   state saved for backward (mlagg_msmm_scan_state_floats); workspace: the per-direction outputs before the sum
+ * Backward overwrites dxc (B, L, 96), dxdbl (B, L, 144: every column, the pad columns with zeros), dWdt, dA and, when non-NULL,
+ * dD, ddelta_bias.  No atomics: bit-reproducible.
+ * ------------------------------------------------------------------------------------------ */
+int mlagg_msmm_scan_supported(int d_inner, int d_state, int dt_rank, int directions, int L);
+size_t mlagg_msmm_scan_state_floats(int batch, int L);
+size_t mlagg_msmm_scan_fwd_workspace_floats(int batch, int L);
+size_t mlagg_msmm_scan_bwd_workspace_floats(int batch, int L);
+int mlagg_msmm_scan_fwd(const float *xc, const float *xdbl, const int *idx, const float *Wdt, const float *A, const float *D,
+                        const float *delta_bias, float *y, float *state, float *workspace, int batch, int L, void *stream);
+int mlagg_msmm_scan_bwd(const float *xc, const float *xdbl, const int *idx, const float *Wdt, const float *A, const float *D,
+                        const float *delta_bias, const float *dy, const float *state, float *dxc, float *dxdbl, float *dWdt,
+                        float *dA, float *dD, float *ddelta_bias, float *workspace, int batch, int L, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * K1s: selective scan with ONE state per channel on token-major volumes, scan orders applied inside the kernels.
  * Replaces, for the reference's 3-D network (variants/mamba/UMambaEnc_SS3D.py: `SS3D` built with d_state = 1 at :640-655),
  * everything of `SS3D.forward_corev0` (:244-296) behind x_proj: the copies that build the K = 12 scan sequences of u

@@ -31,6 +31,12 @@ SIGNATURES = {
     "mlagg_selscan_bwd": (_I, [_F] * 17 + [_I] * 6 + [_S]),
     "mlagg_selscan_lowrank_fwd": (_I, [_F] * 3 + [_I] + [_F] * 7 + [_I] * 6 + [_S]),
     "mlagg_selscan_lowrank_bwd": (_I, [_F] * 3 + [_I] + [_F] * 16 + [_I] * 6 + [_S]),
+    "mlagg_msmm_scan_supported": (_I, [_I] * 5),
+    "mlagg_msmm_scan_state_floats": (_SZ, [_I, _I]),
+    "mlagg_msmm_scan_fwd_workspace_floats": (_SZ, [_I, _I]),
+    "mlagg_msmm_scan_bwd_workspace_floats": (_SZ, [_I, _I]),
+    "mlagg_msmm_scan_fwd": (_I, [_F] * 10 + [_I, _I, _S]),
+    "mlagg_msmm_scan_bwd": (_I, [_F] * 16 + [_I, _I, _S]),
     "mlagg_local_attn_fwd": (_I, [_F, _I, _F, _I, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _FL, _S]),
     "mlagg_local_attn_bwd_workspace_floats": (_SZ, [_I, _I, _I, _I]),
     "mlagg_local_attn_bwd": (_I, [_F, _I, _F, _I, _F, _F, _F, _F, _I, _F, _I, _F, _I, _F, _F, _F, _F, _F,

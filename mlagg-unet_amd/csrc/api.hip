@@ -21,7 +21,7 @@ std::vector<Rec> g_recs;         // event pairs, reused across collect() calls
 size_t g_used = 0;
 const char *const kNames[K_COUNT] = {
     "selscan_fwd_kernel<false>", "selscan_chunk_prefix", "selscan_fwd_kernel<true>", "selscan_bwd_local_kernel",
-    "selscan_bwd_kernel", "selscan_reduce_partials", "local_attn_fwd_kernel", "local_attn_bwd_a_kernel",
+    "selscan_bwd_group_kernel", "selscan_reduce_partials", "local_attn_fwd_kernel", "local_attn_bwd_a_kernel",
     "local_attn_bwd_b_kernel", "pooled_attn_fwd_kernel", "pooled_attn_bwd1_kernel",
     "pooled_attn_bwd2_kernel", "dwconv_tiled_kernel<fwd>", "dwconv_tiled_kernel<dgrad>", "dwconv_bwd_weight_kernel", "linear weight gradient (K5w: linear_wgrad_kernel / linear_wgrad_x3_kernel + reduce)", "layernorm_fwd_kernel",
     "layernorm_bwd_kernel", "dwconv_nchw_fwd_kernel", "dwconv_nchw_bwd (data+weight+reduce)",
@@ -32,7 +32,8 @@ const char *const kNames[K_COUNT] = {
     "sel1_prefix_kernel", "sel1 reductions (step partials + per-chunk rows)",
     "volume_pad_kernel (+ guard fill)", "conv_wgrad_taps_kernel", "conv_wgrad_reduce_kernel", "conv_taps_kernel (forward / data gradient)",
     "gelu_pool (forward + backward)", "conv1x1 (forward / data gradient / weight gradient)",
-    "conv3x3 (forward / data gradient, incl. weight image)"};
+    "conv3x3 (forward / data gradient, incl. weight image)",
+    "tok_fwd_kernel<false>", "tok_fwd_kernel<true>", "tok_bwd_local_kernel", "tok_bwd_group_kernel"};
 }  // namespace
 
 // begin/end pairs of one kernel are issued back to back from one host thread (the launcher), so the

@@ -731,6 +731,12 @@ class SS2D_skip(nn.Module):
         B, Lc, dI = xc.shape
         K, R, N = 4, self.dt_rank, self.d_state
         per = R + 2 * N
+        if ops.msmm_scan_supported(xc, N, R):
+            # K1f: one token-major 96 -> 4 * 36 Linear (a zero row keeps every direction's B / C block 16-byte aligned), then the scan
+            # kernels apply the four scan orders in their own address arithmetic: nothing is re-ordered, stacked or summed outside
+            xdbl = ops.linear(xc, ops.pad_x_proj(self.x_proj_weight))                     # (B, L, 4 * 36)
+            return ops.msmm_scan(xc, xdbl, ops.msmm_scan_index(HW, xc.device), self.dt_projs_weight.reshape(K * dI, R),
+                                 -torch.exp(self.A_logs), self.Ds, self.dt_projs_bias.reshape(-1))
         xdbl = ops.linear(xc, self.x_proj_weight.reshape(K * per, dI))                     # (B, L, 4*35)
         dtr, Bs, Cs = ops.cross_scan_bc(xdbl, HW, R, N)               # (B, 4, 3, L) | (B, 4, 16, L) | (B, 4, 16, L)
         xs = ops.cross_scan(xc, HW, dI, 1)                                                  # (B, 4*96, L)

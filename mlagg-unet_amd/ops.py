@@ -196,6 +196,110 @@ def selective_scan_lowrank_fn(u, dtr, Wdt, A, B, C, D=None, delta_bias=None, del
     return SelectiveScanLowRankFn.apply(u, dtr, Wdt, A, B, C, D, delta_bias, delta_softplus)
 
 
+# ------------------------------------------------------------------------------------------------
+# K1f: the MSMM scan on token-major tensors (csrc/selscan_tok.hip) -- SS2D_skip.forward_corev0 behind x_proj + the four-way sum
+# (reference MambaSkip.py:405-473, 534) as ONE op; MLAGG_MSMM_FUSED=0: the round-3 chain (K1' cross_scan / cross_merge around K1)
+# ------------------------------------------------------------------------------------------------
+MSMM_FUSED = _os.environ.get("MLAGG_MSMM_FUSED", "1") == "1"
+MSMM_XB = 36                      # floats per direction of a padded x_proj row: [dt0 dt1 dt2 0 | B(16) | C(16)]
+_SCAN_INDEX = {}
+
+
+def msmm_scan_index(HW, device):
+    """(4, L_cat) int32: the token direction k visits at scan position t -- the orders of reference M:419-422 (k = 0 row-major,
+    1 column-major, 2 / 3 their reversals inside every scale; scales concatenated in the same order for every direction)."""
+    key = (tuple((int(h), int(w)) for h, w in HW), str(device))
+    if key not in _SCAN_INDEX:
+        rows, off = [[], [], [], []], 0
+        for H, W in key[0]:
+            n = H * W
+            p = torch.arange(n, dtype=torch.int64)
+            col = (p % H) * W + p // H                       # position p of the column-major walk -> token y * W + x
+            for k, tok in enumerate((p, col, n - 1 - p, col.flip(0))):
+                rows[k].append(tok + off)
+            off += n
+        table = torch.stack([torch.cat(r) for r in rows]).to(torch.int32)
+        if not all(bool((table[k].sort().values == torch.arange(off, dtype=torch.int32)).all()) for k in range(4)):
+            raise RuntimeError("msmm_scan_index: a direction is not a permutation of the tokens")
+        _SCAN_INDEX[key] = table.to(device)
+    return _SCAN_INDEX[key]
+
+
+class PadXProjFn(torch.autograd.Function):
+    """x_proj_weight (4, R + 2N, d) -> (4 * 36, d) with a zero row behind the three dt rows of every direction, so that the B / C
+    blocks of a projection row start on 16-byte boundaries; backward drops the pad rows' (exactly zero) gradient."""
+
+    @staticmethod
+    def forward(ctx, w):
+        K, per, dI = w.shape
+        ctx.per = per
+        out = w.new_zeros(K, MSMM_XB, dI)
+        out[:, :3] = w[:, :3]
+        out[:, 4:] = w[:, 3:]
+        return out.view(K * MSMM_XB, dI)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.view(-1, MSMM_XB, g.shape[-1])
+        return torch.cat([g[:, :3], g[:, 4:]], dim=1)
+
+
+def pad_x_proj(w):
+    return PadXProjFn.apply(w)
+
+
+class MsmmScanFn(torch.autograd.Function):
+    """K1f.  xc (B, L, 96), xdbl (B, L, 144), idx (4, L) int32, Wdt (384, 3), A (384, 16), D (384), bias (384) -> y (B, L, 96)."""
+
+    @staticmethod
+    def forward(ctx, xc, xdbl, idx, Wdt, A, D, bias):
+        xc = _require(xc.contiguous(), "xc")
+        B, L, dI = xc.shape
+        xdbl = _require(xdbl.contiguous(), "x_dbl", (B, L, 4 * MSMM_XB))
+        if idx.dtype != torch.int32 or tuple(idx.shape) != (4, L) or not idx.is_cuda or not idx.is_contiguous():
+            raise RuntimeError("msmm_scan: idx must be a contiguous int32 (4, L) device table")
+        lib = _lib.lib()
+        if not lib.mlagg_msmm_scan_supported(dI, int(A.shape[1]), int(Wdt.shape[1]), 4, L):
+            raise RuntimeError(f"msmm_scan: shape (d_inner {dI}, d_state {A.shape[1]}, rank {Wdt.shape[1]}, L {L}) is outside K1f")
+        Wdt = _require(Wdt.contiguous(), "Wdt", (4 * dI, 3))
+        A = _require(A.contiguous(), "A", (4 * dI, 16))
+        D = None if D is None else _require(D.contiguous(), "D", (4 * dI,))
+        bias = None if bias is None else _require(bias.contiguous(), "delta_bias", (4 * dI,))
+        y = torch.empty(B, L, dI, device=xc.device, dtype=torch.float32)
+        state = torch.empty(lib.mlagg_msmm_scan_state_floats(B, L), device=xc.device, dtype=torch.float32)
+        ws = torch.empty(lib.mlagg_msmm_scan_fwd_workspace_floats(B, L), device=xc.device, dtype=torch.float32)
+        _lib.check(lib.mlagg_msmm_scan_fwd(_ptr(xc), _ptr(xdbl), _ptr(idx), _ptr(Wdt), _ptr(A), _ptr(D), _ptr(bias), _ptr(y), _ptr(state),
+                                           _ptr(ws), B, L, _stream()), "mlagg_msmm_scan_fwd")
+        ctx.save_for_backward(xc, xdbl, idx, Wdt, A, D, bias, state)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, xdbl, idx, Wdt, A, D, bias, state = ctx.saved_tensors
+        B, L, dI = xc.shape
+        dy = _require(dy.contiguous(), "dy", (B, L, dI))
+        lib = _lib.lib()
+        dev = xc.device
+        dxc, dxdbl = torch.empty_like(xc), torch.empty_like(xdbl)
+        dW, dA = torch.empty_like(Wdt), torch.empty_like(A)
+        dD = None if D is None else torch.empty_like(D)
+        dbias = None if bias is None else torch.empty_like(bias)
+        ws = torch.empty(lib.mlagg_msmm_scan_bwd_workspace_floats(B, L), device=dev, dtype=torch.float32)
+        _lib.check(lib.mlagg_msmm_scan_bwd(_ptr(xc), _ptr(xdbl), _ptr(idx), _ptr(Wdt), _ptr(A), _ptr(D), _ptr(bias), _ptr(dy), _ptr(state),
+                                           _ptr(dxc), _ptr(dxdbl), _ptr(dW), _ptr(dA), _ptr(dD), _ptr(dbias), _ptr(ws), B, L, _stream()),
+                   "mlagg_msmm_scan_bwd")
+        return dxc, dxdbl, None, dW, dA, dD, dbias
+
+
+def msmm_scan(xc, xdbl, idx, Wdt, A, D=None, delta_bias=None):
+    return MsmmScanFn.apply(xc, xdbl, idx, Wdt, A, D, delta_bias)
+
+
+def msmm_scan_supported(xc, d_state, dt_rank):
+    return bool(MSMM_FUSED and xc.is_cuda and xc.dim() == 3 and
+                _lib.lib().mlagg_msmm_scan_supported(int(xc.shape[2]), int(d_state), int(dt_rank), 4, int(xc.shape[1])))
+
+
 def _rows(t, name):
     """(B, N, C) view whose last dim is contiguous and whose batch/token dims collapse to one row
     stride (true for fresh Linear outputs and their channel slices); returns (tensor, row_stride)."""

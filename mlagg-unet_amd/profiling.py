@@ -43,7 +43,13 @@ def algorithmic_bytes(kernel, batch, img):
         "selscan_fwd_kernel<false>": 4 * l_cat * (D + G * R + G * N),                    # read u, dtr, B
         "selscan_fwd_kernel<true>": 4 * l_cat * (2 * D + G * R + 2 * G * N),             # K1 fwd op boundary (3632 L)
         "selscan_bwd_local_kernel": 4 * l_cat * (D + G * R + G * N),                     # read dtr, dy, C
-        "selscan_bwd_kernel": 4 * l_cat * (3 * D + 2 * G * R + 4 * G * N),               # K1 bwd op boundary (5728 L)
+        "selscan_bwd_group_kernel": 4 * l_cat * (3 * D + 2 * G * R + 4 * G * N),         # K1 bwd op boundary (5728 L)
+        # K1f (token-major, what the model runs since round 4): per direction and token u / dy / du are 96 floats, a projection
+        # row 36 (3 rank values + pad, B, C); every direction reads u and dy for itself and writes its own output block
+        "tok_fwd_kernel<false>": 4 * l_cat * G * (96 + 4 + N),                            # read u, rank row, B (1856 L)
+        "tok_fwd_kernel<true>": 4 * l_cat * G * (96 + 36 + 96),                           # read u, projection row; write y_k (3648 L)
+        "tok_bwd_local_kernel": 4 * l_cat * G * (96 + 4 + N),                             # read dy, rank row, C
+        "tok_bwd_group_kernel": 4 * l_cat * G * (3 * 96 + 2 * 36),                        # read u, dy, row; write du_k, d(row) (5760 L)
     }
     if kernel in scan:
         return scan[kernel] * batch

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.mlagg_selscan_state_floats(10, 384, 21760, 16) == 10 * 340 * 384 * (16 + 1 + 7 * 16)   # chunk states, sums, 8-step tile states
     assert lib.mlagg_local_attn_bwd_workspace_floats(2, 8, 8, 1) >= 2 * 64 * 76
     names = [lib.mlagg_profile_kernel_name(i).decode() for i in range(lib.mlagg_profile_kernel_count())]
-    assert "selscan_bwd_kernel" in names and len(set(names)) == len(names)
+    assert "selscan_bwd_group_kernel" in names and "tok_bwd_group_kernel" in names and len(set(names)) == len(names)
 
 
 def test_ops_refuse_cpu_tensors_and_unsupported_arguments():

@@ -54,7 +54,7 @@ def main():
     fwd_b = 4 * L * (2 * G * dI + G * R + 2 * G * N) * a.batch
     bwd_b = 4 * L * (3 * G * dI + 2 * G * R + 4 * G * N) * a.batch
     k = {n: round(v["ms"], 4) for n, v in table.items() if v["ms"] > 0}
-    scan_bwd = table.get("selscan_bwd_kernel", {"ms": 0})["ms"]
+    scan_bwd = table.get("selscan_bwd_group_kernel", {"ms": 0})["ms"]
     print(json.dumps({"workload": f"SS3D block fwd+bwd, batch {a.batch}, volume {D}x{H}x{W} = {L} tokens, d_model {a.d_model} "
                                   f"(12 directions x {dI} channels, dt_rank {R})",
                       "ms_per_fwd_bwd": round(ms, 3), "volumes_per_s": round(a.batch / ms * 1e3, 1),

@@ -19,7 +19,7 @@ import sys
 # rocprof's template spellings of the low-rank scan kernels -> the library's profile names (bench.py looks these up)
 LIB_NAMES = {"selscan_fwd_kernel<false, true>": "selscan_fwd_kernel<false>", "selscan_fwd_kernel<true, true>": "selscan_fwd_kernel<true>",
              "selscan_bwd_kernel<true>": "selscan_bwd_kernel", "selscan_bwd_local_kernel<true>": "selscan_bwd_local_kernel",
-             "selscan_bwd_group_kernel": "selscan_bwd_kernel"}     # round 2: the group-per-wave form serves the same entry point
+             "selscan_bwd_group_kernel": "selscan_bwd_group_kernel"}     # round 2: the group-per-wave form serves the same entry point
 
 
 def lib_name(base, targs):
@@ -31,7 +31,7 @@ def lib_name(base, targs):
     if base in ("selscan_bwd_local_kernel", "selscan_bwd_kernel"):
         return base
     if base == "selscan_bwd_group_kernel":
-        return "selscan_bwd_kernel"                       # round 2: the group-per-wave form serves the same entry point
+        return "selscan_bwd_group_kernel"                       # round 2: the group-per-wave form serves the same entry point
     name = base + (targs or "")
     return LIB_NAMES.get(name, name)
 

@@ -3,7 +3,7 @@
 
 The whole-process --stats table also contains MIOpen's first-use solver search (naive reference
 convolutions of tens of milliseconds) and the untimed warm-up, so it cannot be compared with bench.py's
-ms_per_step.  A train step is delimited by consecutive dispatches of `selscan_bwd_kernel` (exactly one
+ms_per_step.  A train step is delimited by consecutive dispatches of the scan's backward group kernel (`tok_bwd_group_kernel` / `selscan_bwd_group_kernel`: exactly one
 per step); the last `--steps` intervals are the timed region.
 
     python tools/summarize_trace.py gpurun_out/prof/runc/*_kernel_trace.csv --steps 10 > profiles/...md
@@ -17,7 +17,7 @@ import re
 def family(n):
     if n.startswith("Cijk_"):
         return "GEMM (rocBLAS/hipBLASLt)"
-    for key, lab in (("linear_lp", "HIP K5 projections (fwd, dx), 16-bit operands"), ("selscan", "HIP K1 selective scan"), ("sel1_", "HIP K1s one-state selective scan (3-D)"),
+    for key, lab in (("linear_lp", "HIP K5 projections (fwd, dx), 16-bit operands"), ("selscan", "HIP K1 selective scan"), ("tok_fwd", "HIP K1 selective scan"), ("tok_bwd", "HIP K1 selective scan"), ("sel1_", "HIP K1s one-state selective scan (3-D)"),
                      ("conv_taps_kernel", "HIP K16 convolution forward / data gradient (tap GEMM)"),
                      ("dwconv", "HIP K2 depthwise conv"), ("gelu_pool", "HIP K17 GELU + window mean"),
                      ("conv1x1_", "HIP K18 1x1 convolution (split bf16)"), ("conv3x3_", "HIP K19 3x3 convolution (split bf16)"),
@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--top", type=int, default=40)
     ap.add_argument("--aten", action="store_true", help="append every at::native / MIOpen helper kernel of the step (the library tail)")
-    ap.add_argument("--mark", default=r"selscan_bwd_(group_)?kernel",
+    ap.add_argument("--mark", default=r"(selscan|tok)_bwd_(group_)?kernel",
                     help="regex of the kernel dispatched exactly once per step (3-D network: 'sel1_bwd_kernel<2>')")
     a = ap.parse_args()
     rows = list(csv.DictReader(open(a.trace)))
