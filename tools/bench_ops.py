@@ -2,7 +2,7 @@
 """Micro-benchmark of the hand-written ops at BASELINE config-2 shapes (B = 10, 256x256), used under
 rocprofv3 (--kernel-trace / --pmc) to study one kernel family at a time.
 
-    python tools/bench_ops.py scan|local|pooled|dwconv|wgrad [--iters 10]
+    python tools/bench_ops.py scan|scanlr|msmm|local|pooled|dwconv|wgrad [--iters 10]
 """
 import argparse
 import os
@@ -51,6 +51,24 @@ def scanlr(B=10, L=21760, R=3):
 
     def step():
         ops.selective_scan_lowrank_fn(u, dtr, Wdt, A, Bm, Cm, Dv, bias, True).backward(gy)
+    return step
+
+
+def msmm(B=10, HW=((128, 128), (64, 64), (32, 32), (16, 16))):
+    """K1f as the model runs it since round 4: the token-major scan of all four directions (BASELINE config 2 MSMM shapes)."""
+    g = torch.Generator(device=DEV).manual_seed(0)
+    L = sum(h * w for h, w in HW)
+    xc = torch.randn(B, L, 96, device=DEV, generator=g).requires_grad_(True)
+    xdbl = torch.randn(B, L, 144, device=DEV, generator=g).requires_grad_(True)
+    Wdt = (torch.randn(384, 3, device=DEV, generator=g) * 0.3).requires_grad_(True)
+    A = (-torch.exp(torch.randn(384, 16, device=DEV, generator=g) * 0.3 + 1)).requires_grad_(True)
+    Dv = torch.randn(384, device=DEV, generator=g).requires_grad_(True)
+    bias = (torch.randn(384, device=DEV, generator=g) - 3).requires_grad_(True)
+    gy = torch.randn(B, L, 96, device=DEV, generator=g)
+    idx = ops.msmm_scan_index(HW, DEV)
+
+    def step():
+        ops.msmm_scan(xc, xdbl, idx, Wdt, A, Dv, bias).backward(gy)
     return step
 
 
@@ -111,7 +129,7 @@ def wgrad(M=163840, O=96, I=96):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["scan", "scanlr", "local", "pooled", "dwconv", "wgrad"])
+    ap.add_argument("what", choices=["scan", "scanlr", "msmm", "local", "pooled", "dwconv", "wgrad"])
     ap.add_argument("--iters", type=int, default=10)
     a = ap.parse_args()
     fn = globals()[a.what]()

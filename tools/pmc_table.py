@@ -1,12 +1,13 @@
 #!/usr/bin/env python
 """Per-kernel averages of rocprofv3 --pmc counter CSVs (one or more pass directories) as a markdown table.
 
-    python tools/pmc_table.py gpurun_out/pmc_a gpurun_out/pmc_b [--match selscan] > profiles/roundN_pmc_x.md
+    python tools/pmc_table.py gpurun_out/pmc_a gpurun_out/pmc_b [--match REGEX] > profiles/roundN_pmc_x.md
 """
 import argparse
 import collections
 import csv
 import glob
+import re
 
 ap = argparse.ArgumentParser()
 ap.add_argument("dirs", nargs="+")
@@ -16,7 +17,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in a.dirs:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if a.match in r["Kernel_Name"]:
+            if re.search(a.match, r["Kernel_Name"]):
                 acc[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 cols = sorted({c for v in acc.values() for c in v})
 print("| kernel | launches | " + " | ".join(cols) + " |")

@@ -30,6 +30,10 @@ def lib_name(base, targs):
         return f"selscan_fwd_kernel<{args[0]}>" if args else base
     if base in ("selscan_bwd_local_kernel", "selscan_bwd_kernel"):
         return base
+    if base == "tok_fwd_kernel":
+        return f"tok_fwd_kernel<{args[0]}>" if args else base
+    if base in ("tok_bwd_local_kernel", "tok_bwd_group_kernel"):
+        return base
     if base == "selscan_bwd_group_kernel":
         return "selscan_bwd_group_kernel"                       # round 2: the group-per-wave form serves the same entry point
     name = base + (targs or "")
@@ -56,7 +60,10 @@ for k, v in sorted(res.items()):
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         fetch, write = 2 * v["FETCH_SIZE"] * 1024, v["WRITE_SIZE"] * 1024
         kern[k] = {"fetch_bytes_corrected": round(fetch), "write_bytes": round(write), "traffic_bytes": round(fetch + write)}
-json.dump({"workload": "tools/bench_ops.py scanlr: B=10, D=384, N=16, G=4, R=3, L=21760 (BASELINE config 2 MSMM scan, low-rank delta form)",
+import os
+WORK = {"scanlr": "tools/bench_ops.py scanlr: B=10, D=384, N=16, G=4, R=3, L=21760 (BASELINE config 2 MSMM scan, (B, D, L) low-rank form)",
+        "msmm": "tools/bench_ops.py msmm: B=10, four directions x 96 channels, N=16, R=3, L_cat=21760 (BASELINE config 2 MSMM scan, token-major K1f)"}
+json.dump({"workload": WORK.get(os.environ.get("SCAN_OP", "msmm"), os.environ.get("SCAN_OP", "msmm")),
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, per-dispatch averages; "
-                     "FETCH_SIZE x2 (gfx950 counts wide coalesced reads at half), both KiB -> bytes",
+                     "FETCH_SIZE x2 (gfx950 counts wide coalesced reads at half; an upper bound where a kernel issues narrower loads), both KiB -> bytes",
            "kernels": kern}, sys.stdout, indent=1)

@@ -15,7 +15,7 @@ python3 tools/summarize_trace.py "$T" --steps 10 > $O/kernel_trace_timed_region.
 cp $(find $RAW/trace -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_whole_process.csv
 pmc() {  # name, counters...
     n=$1; shift
-    rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $RAW/$n -o run -- python3 tools/bench_ops.py scanlr --iters 5 > $O/$n.log 2>&1
+    rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $RAW/$n -o run -- python3 tools/bench_ops.py ${SCAN_OP:-msmm} --iters 5 > $O/$n.log 2>&1
     echo "$n rc=$?"
 }
 pmc pmc_sq1 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES
@@ -25,7 +25,7 @@ pmc pmc_WRITE_SIZE WRITE_SIZE
 pmc pmc_tcc TCC_HIT_sum TCC_MISS_sum
 pmc pmc_ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
 pmc pmc_req TCC_REQ_sum TCC_READ_sum
-python3 tools/pmc_table.py $RAW/pmc_sq1 $RAW/pmc_sq2 $RAW/pmc_tcc $RAW/pmc_ea $RAW/pmc_req --match selscan > $O/pmc_selscan.md
+python3 tools/pmc_table.py $RAW/pmc_sq1 $RAW/pmc_sq2 $RAW/pmc_tcc $RAW/pmc_ea $RAW/pmc_req --match "selscan|tok_" > $O/pmc_selscan.md
 python3 tools/pmc_to_json.py $RAW/pmc_FETCH_SIZE $RAW/pmc_WRITE_SIZE > $O/pmc_traffic.json
 grep -h "per fwd+bwd" $O/*.log
 ls -la $O
