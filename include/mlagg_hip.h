@@ -561,6 +561,27 @@ int mlagg_conv_wgrad_taps(const float *A, long a_batch, long a_row, const float 
                           int ntaps, long Q, int O, int I, int batch, float *dW, int accumulate, float *workspace, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K5, round-4 form (csrc/linear_x3.hip): y (M, N) = x (M, K) . W (N, K)^T for token-major activations, fp32 in / out, split-bf16
+ * products (three exact bf16 pieces per operand, six partial products, fp32 accumulation: the error of an fp32 GEMM).  Replaces the
+ * forward and data-gradient GEMMs behind every token-major nn.Linear of the path (nnUNetTrainer_MLAgg_2D_dt_MS.py:176-192, 687-690,
+ * 719-723, 887-907; MambaSkip.py:518, 538, 559-577) at every token count.
+ * The weight operand is an IMAGE: mlagg_weight_image lays the three bf16 pieces of W (N, K) out as img[piece][n][k] with rows padded
+ * with zeros to a multiple of 32 (mlagg_weight_image_bytes(N, K) bytes) and, if img_t is non-NULL, the same for W^T (K, N)
+ * (mlagg_weight_image_bytes(K, N) bytes): the operand of the data gradient dx (M, K) = dy (M, N) . W = mlagg_linear_x3(dy, img_t, ...,
+ * N_gemm = K, K_gemm = N).  mlagg_weight_images builds the images of a whole network in one launch from a device table of rows
+ * {const float *w; void *img; void *img_t; int32 N, K, w_stride, pad} (32 bytes each); max_tiles >= ceil(N / 32) * ceil(K / 32) of
+ * every row.  K % 8 == 0 (mlagg_linear_x3_supported).
+ * epilogue 0: y = x W^T + bias (bias may be NULL); 1: y = x W^T + bias AND y_act = GELU(y) (exact, erf: Mlp fc1 + nn.GELU, T:188-190);
+ * 2: y = (x W^T) * GELU'(pre) (the data gradient that flows back through that GELU; bias ignored).
+ * ------------------------------------------------------------------------------------------ */
+size_t mlagg_weight_image_bytes(int rows, int cols);
+int mlagg_weight_image(const float *w, int w_stride, void *img, void *img_t, int N, int K, void *stream);
+int mlagg_weight_images(const void *jobs, int n_jobs, int max_tiles, void *stream);
+int mlagg_linear_x3_supported(int M, int N, int K);
+int mlagg_linear_x3(const float *x, int x_stride, const void *w_image, const float *bias, float *y, int y_stride, float *y_act,
+                    const float *pre, int pre_stride, int M, int N, int K, int epilogue, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * K11: clip_grad_norm_ + AdamW.step() of the train step (nnUNetTrainer.py:855-857; optimizer of
  * nnUNetTrainer_MLAgg_2D_dt_MS.py:137-147) for every parameter in two launches.
  * tensor_table: device array of rows {param*, grad*, exp_avg*, exp_avg_sq*, int64 numel} (5 x 8 bytes each);

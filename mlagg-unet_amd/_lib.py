@@ -112,6 +112,11 @@ SIGNATURES = {
     "mlagg_linear_dgrad": (_I, [_F, _I, _F, _F, _I, _I, _I, _I, _S]),
     "mlagg_linear_lp_fwd": (_I, [_F, _I, _F, _F, _F, _I, _I, _I, _I, _I, _S]),
     "mlagg_linear_lp_dgrad": (_I, [_F, _I, _F, _F, _I, _I, _I, _I, _I, _S]),
+    "mlagg_weight_image_bytes": (_SZ, [_I, _I]),
+    "mlagg_weight_image": (_I, [_F, _I, _F, _F, _I, _I, _S]),
+    "mlagg_weight_images": (_I, [_F, _I, _I, _S]),
+    "mlagg_linear_x3_supported": (_I, [_I, _I, _I]),
+    "mlagg_linear_x3": (_I, [_F, _I, _F, _F, _F, _I, _F, _F, _I, _I, _I, _I, _I, _S]),
     "mlagg_flash_attn_fwd": (_I, [_F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _FL, _I, _S]),
     "mlagg_flash_attn_bwd_workspace_floats": (_SZ, [_I, _I, _I, _I, _I]),
     "mlagg_flash_attn_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _FL, _I, _S]),
