@@ -569,7 +569,7 @@ int mlagg_conv_wgrad_taps(const float *A, long a_batch, long a_row, const float 
  * with zeros to a multiple of 32 (mlagg_weight_image_bytes(N, K) bytes) and, if img_t is non-NULL, the same for W^T (K, N)
  * (mlagg_weight_image_bytes(K, N) bytes): the operand of the data gradient dx (M, K) = dy (M, N) . W = mlagg_linear_x3(dy, img_t, ...,
  * N_gemm = K, K_gemm = N).  mlagg_weight_images builds the images of a whole network in one launch from a device table of rows
- * {const float *w; void *img; void *img_t; int32 N, K, w_stride, pad} (32 bytes each); max_tiles >= ceil(N / 32) * ceil(K / 32) of
+ * {const float *w; void *img; void *img_t; int32 N, K, w_stride, pad} (40 bytes each); max_tiles >= ceil(N / 32) * ceil(K / 32) of
  * every row.  K % 8 == 0 (mlagg_linear_x3_supported).
  * epilogue 0: y = x W^T + bias (bias may be NULL); 1: y = x W^T + bias AND y_act = GELU(y) (exact, erf: Mlp fc1 + nn.GELU, T:188-190);
  * 2: y = (x W^T) * GELU'(pre) (the data gradient that flows back through that GELU; bias ignored).

@@ -322,12 +322,13 @@ extern "C" int mlagg_linear_x3(const float *x, int x_stride, const void *w_image
     hipStream_t st = static_cast<hipStream_t>(stream);
     MLAGG_TIMED(K_LINEAR_FWD, st);
     const unsigned short *img = static_cast<const unsigned short *>(w_image);
-    // tile shape: MLAGG_X3_TILE=<NW><TN> forces one (benchmarks); default: 96-column tiles where N is a multiple of 96 and they still
-    // give every CU work, else 64-column tiles; 64-row workgroups for the shortest token counts
+    // tile shape (profiles/round4_d_linear_x3_variants.log): 96-column tiles only where N is a multiple of 96 AND the grid is long
+    // (stage 0 / 1 projections: >= 1024 workgroups); everywhere else 64-column tiles -- a third more workgroups per CU, 10-15 % faster
+    // on the 10 240- and 2 560-token shapes; 64-row workgroups for the pooled branch's few hundred rows.
+    // MLAGG_X3_TILE=<NW><TN> forces one variant (benchmarks)
     static const int forced = [] { const char *e = getenv("MLAGG_X3_TILE"); return e ? atoi(e) : 0; }();
-    int nw = 4, tn = (N % 96 == 0) ? 3 : 2;
-    if ((long)((M + 127) / 128) * ((N + 32 * tn - 1) / (32 * tn)) < 256) tn = 2;
-    if ((long)((M + 127) / 128) * ((N + 63) / 64) < 256) nw = 2;
+    int nw = M <= 1024 ? 2 : 4, tn = 2;
+    if (N % 96 == 0 && (long)((M + 127) / 128) * (N / 96) >= 1024) tn = 3;
     if (forced) { nw = forced / 10; tn = forced % 10; }
     if (nw == 4 && tn == 3) return launch_x3<4, 3>(x, img, bias, y, y_act, pre, g, epilogue, st);
     if (nw == 4 && tn == 2) return launch_x3<4, 2>(x, img, bias, y, y_act, pre, g, epilogue, st);

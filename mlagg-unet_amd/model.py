@@ -234,6 +234,8 @@ class Mlp(nn.Module):
         self.fc2 = Linear(hidden, dim)
 
     def forward(self, x):
+        if ops.mlp_supported(x, self.fc1.weight, self.fc2.weight):
+            return ops.mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)        # GELU in K5's epilogues
         return self.fc2(F.gelu(self.fc1(x)))
 
 
@@ -297,7 +299,9 @@ class _Stack:
             with torch.no_grad():
                 torch._foreach_copy_(views, [t.detach() for t in srcs])
         self.fresh = False                                      # consumed: the next use without a network refresh copies again
-        return _StackFn.apply(self.buf, *srcs)
+        out = _StackFn.apply(self.buf, *srcs)
+        out._mlagg_buffer = self.buf                            # ops.WeightImageSet keeps THIS (no grad_fn), never the graph-bound view
+        return out
 
 
 def refresh_stacks(stacks):
@@ -854,6 +858,7 @@ class MLLA_Uper(nn.Module):  # reference T:1183-1407
         # the reference's "finished reduction" hazard (SURVEY finding 7a) cannot arise and no DDP-private API is needed
         self.dummy_tensor = nn.Parameter(torch.tensor([1.0]), requires_grad=False)
         self._dp_pool = _DropPathPool()
+        self._images = ops.WeightImageSet()
         if deep_supervision:
             self.out_1 = OutBlock(E, out_channels)
             self.out_2 = OutBlock(2 * E, out_channels)
@@ -878,6 +883,10 @@ class MLLA_Uper(nn.Module):  # reference T:1183-1407
 
     def _forward(self, x_in):
         refresh_stacks(self._stacks())                      # every stacked projection weight / bias in one multi-tensor copy
+        with self._images:                                  # ... and the bf16 images of every projection weight in one launch
+            return self._forward_body(x_in)
+
+    def _forward_body(self, x_in):
         hs = self.mlla(x_in)
         hs[1:] = self.mambaskip(hs[1:])
         ds = self.deep_supervision

@@ -751,18 +751,155 @@ def _mfma_rows(t, name):
     return t2, ts
 
 
+# ------------------------------------------------------------------------------------------------
+# K5, round-4 form (csrc/linear_x3.hip): the weight operand is an IMAGE (its three bf16 pieces, laid out for the kernel; the same for
+# W^T for the data gradient), built once per step for every projection of a network in ONE launch (WeightImageSet) or, for a weight
+# nobody registered, on the fly.  MLAGG_K5_V2=0: the round-3 kernels + the library GEMM for short token counts.
+# ------------------------------------------------------------------------------------------------
+K5_V2 = _os.environ.get("MLAGG_K5_V2", "1") == "1"
+X3_MIN_ROWS = int(_os.environ.get("MLAGG_X3_MIN_ROWS", "16384"))     # below: the TUNED library GEMM (gemm_db) is still ahead in the step
+_IMAGE_EPOCH = [0]              # bumped by whatever rewrites parameters behind autograd's back (ClipAdamW's raw-pointer update)
+
+
+def invalidate_weight_images():
+    _IMAGE_EPOCH[0] += 1
+
+
+def _image_pair(w):
+    """(img, imgT) of a contiguous fp32 (N, K) matrix, built now (one launch)."""
+    N, K = w.shape
+    lib = _lib.lib()
+    img = torch.empty(lib.mlagg_weight_image_bytes(N, K), dtype=torch.uint8, device=w.device)
+    imgT = torch.empty(lib.mlagg_weight_image_bytes(K, N), dtype=torch.uint8, device=w.device)
+    _lib.check(lib.mlagg_weight_image(_ptr(w), K, _ptr(img), _ptr(imgT), N, K, _stream()), "mlagg_weight_image")
+    return img, imgT
+
+
+class WeightImageSet:
+    """The weight images of one network.  The first forward pass under ``with images:`` records which persistent matrices (parameters
+    and stacked-weight buffers) the projections ask for; from then on ``begin`` rebuilds all their images with one launch over a
+    device table, and lookups are a dictionary hit checked against the matrix's version counter (an in-place change since the build
+    -- a stack refreshed again, a loaded checkpoint -- falls back to building that one image on the fly)."""
+
+    active = None
+
+    def __init__(self):
+        self.tensors, self.entries, self.table, self.store, self.ptrs, self.max_tiles = [], {}, None, None, None, 0
+
+    def _rebuild_table(self):
+        import numpy as np
+        lib = _lib.lib()
+        dev = self.tensors[0].device
+        sizes = [(lib.mlagg_weight_image_bytes(*t.shape), lib.mlagg_weight_image_bytes(t.shape[1], t.shape[0])) for t in self.tensors]
+        offs, total = [], 0
+        for a, b in sizes:
+            offs.append((total, total + ((a + 255) & ~255)))
+            total += ((a + 255) & ~255) + ((b + 255) & ~255)
+        self.store = torch.empty(total, dtype=torch.uint8, device=dev)
+        base = self.store.data_ptr()
+        jobs = np.zeros(len(self.tensors), dtype=np.dtype([("w", "<u8"), ("img", "<u8"), ("imgT", "<u8"), ("N", "<i4"), ("K", "<i4"),
+                                                           ("ws", "<i4"), ("pad", "<i4")]))
+        self.views, self.max_tiles = [], 0
+        for i, (t, (oa, ob), (sa, sb)) in enumerate(zip(self.tensors, offs, sizes)):
+            N, K = t.shape
+            jobs[i] = (t.data_ptr(), base + oa, base + ob, N, K, K, 0)
+            self.views.append((self.store[oa:oa + sa], self.store[ob:ob + sb]))
+            self.max_tiles = max(self.max_tiles, ((N + 31) // 32) * ((K + 31) // 32))
+        self.table = torch.from_numpy(jobs.view(np.uint8).copy()).to(dev)
+        self.ptrs = tuple(t.data_ptr() for t in self.tensors)
+
+    def begin(self):
+        WeightImageSet.active = self
+        if not self.tensors:
+            return
+        if self.table is None or self.ptrs != tuple(t.data_ptr() for t in self.tensors):
+            self._rebuild_table()
+        _lib.check(_lib.lib().mlagg_weight_images(_ptr(self.table), len(self.tensors), self.max_tiles, _stream()), "mlagg_weight_images")
+        ep = _IMAGE_EPOCH[0]
+        self.entries = {t.data_ptr(): (t._version, ep, v) for t, v in zip(self.tensors, self.views)}
+
+    def end(self):
+        WeightImageSet.active = None
+
+    def __enter__(self):
+        self.begin()
+        return self
+
+    def __exit__(self, *exc):
+        self.end()
+        return False
+
+    def lookup(self, w):
+        e = self.entries.get(w.data_ptr())
+        if e is not None and e[0] == w._version and e[1] == _IMAGE_EPOCH[0]:
+            return e[2]
+        pair = _image_pair(w)
+        # what is worth keeping: a parameter, or the buffer behind a stacked-weight view.  Never the view itself: a tensor with a
+        # grad_fn keeps the AccumulateGrad nodes of an earlier iteration alive, and autograd then runs them on the stream they were
+        # created on -- inside a hipGraph capture that cross-stream hand-off is a segmentation fault (DESIGN section 5)
+        keep = getattr(w, "_mlagg_buffer", w if isinstance(w, torch.nn.Parameter) else None)
+        if keep is not None and keep.grad_fn is None and keep.dim() == 2 and keep.is_contiguous() and \
+                keep.data_ptr() == w.data_ptr() and all(keep.data_ptr() != t.data_ptr() for t in self.tensors):
+            self.tensors.append(keep)               # from the next forward on: part of the one-launch build
+            self.table = None
+        return pair
+
+
+def weight_images(w):
+    """(img, imgT) of the contiguous (N, K) matrix ``w`` that are current NOW."""
+    s = WeightImageSet.active
+    return _image_pair(w) if s is None else s.lookup(w)
+
+
+def _x3_ok(M, N, K):
+    return K5_V2 and M >= X3_MIN_ROWS and bool(_lib.lib().mlagg_linear_x3_supported(M, N, K))
+
+
+def _x3(x2, xs, img, bias, M, N, K, epilogue=0, pre=None, pre_stride=0, out_shape=None):
+    """One launch of mlagg_linear_x3; returns y, or (pre-activation, activation) for the GELU epilogue."""
+    y = torch.empty(out_shape if out_shape is not None else (M, N), device=x2.device, dtype=torch.float32)
+    act = torch.empty_like(y) if epilogue == 1 else None
+    _lib.check(_lib.lib().mlagg_linear_x3(_ptr(x2), xs, _ptr(img), _ptr(bias), _ptr(y), N, _ptr(act), _ptr(pre), pre_stride, M, N, K,
+                                          epilogue, _stream()), "mlagg_linear_x3")
+    return y if epilogue != 1 else (y, act)
+
+
+def _linear_wgrad(dy2, dys, x, O, I, has_bias):
+    """dW (O, I) and db (O) of a token-major Linear: K5w for long token counts, the library GEMM + K8 column sums below."""
+    M = dy2.shape[0]
+    x2, xs = _rows2d(x, "x")
+    lib = _lib.lib()
+    if M >= WGRAD_MIN_ROWS:
+        # dW | db in one allocation (every entry is written by the reduction)
+        buf = torch.empty(O * I + (O if has_bias else 0), device=dy2.device, dtype=torch.float32)
+        dW = buf[:O * I].view(O, I)
+        db = buf[O * I:] if has_bias else None
+        ws = torch.empty(lib.mlagg_linear_wgrad_workspace_floats(M, O, I), device=dy2.device, dtype=torch.float32)
+        wgrad = lib.mlagg_linear_wgrad_x3 if K5_X3 else lib.mlagg_linear_wgrad
+        _lib.check(wgrad(_ptr(dy2), dys, _ptr(x2), xs, _ptr(dW), _ptr(db), _ptr(ws), M, O, I, _stream()), "mlagg_linear_wgrad")
+        return dW, db
+    dW = dy2.t().matmul(x2)
+    db = (column_sum(dy2) if dy2.is_cuda else dy2.sum(0)) if has_bias else None
+    return dW, db
+
+
 class LinearFn(torch.autograd.Function):
-    """y = x W^T + b for token-major activations.  With many tokens (the tall-skinny case of the encoder and
-    the MSMM block) all three GEMMs run on this package's fp32 MFMA kernels: K5 (forward, dx) and K5w (dW, db);
-    small problems go to the library GEMM."""
+    """y = x W^T + b for token-major activations: forward and dx on K5 (round-4 form on weight images at every token count from
+    X3_MIN_ROWS up; MLAGG_K5_V2=0 / 16-bit modes: the round-3 kernels for long token counts, the library GEMM below), dW / db on K5w."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.cdt = cdt = compute_dtype()
+        ctx.imgT = None
         O, I = weight.shape
         M = x.numel() // I
+        if cdt == torch.float32 and x.is_cuda and _x3_ok(M, O, I):
+            x2, xs = _mfma_rows(x, "x")
+            w = _require(weight.contiguous(), "weight")
+            img, ctx.imgT = weight_images(w)
+            return _x3(x2, xs, img, bias, M, O, I, out_shape=x.shape[:-1] + (O,))
         if M >= (K5_MIN_ROWS if cdt == torch.float32 else WGRAD_MIN_ROWS) and I % 4 == 0 and x.is_cuda:
             x2, xs = _mfma_rows(x, "x")
             w = _require(weight.contiguous(), "weight")
@@ -792,7 +929,10 @@ class LinearFn(torch.autograd.Function):
         big = M >= WGRAD_MIN_ROWS
         lib = _lib.lib()
         if ctx.needs_input_grad[0]:
-            if big and (M >= K5_MIN_ROWS or cdt != torch.float32) and O % 4 == 0 and I % 4 == 0:
+            if ctx.imgT is not None and _x3_ok(M, I, O):
+                # dx = dy . W on the image of W^T built with the forward's image (no per-step transpose of the weight)
+                dx = _x3(dy2, dys, ctx.imgT, None, M, I, O, out_shape=x.shape)
+            elif big and (M >= K5_MIN_ROWS or cdt != torch.float32) and O % 4 == 0 and I % 4 == 0:
                 w = _require(weight.contiguous(), "weight")
                 dx = torch.empty(x.shape, device=dy.device, dtype=torch.float32)
                 if cdt == torch.float32 and K5_X3:
@@ -813,24 +953,59 @@ class LinearFn(torch.autograd.Function):
                 dx = dy.matmul(weight)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             # weight / bias gradients stay fp32 in every mode (K5w: the token sum is the long one)
-            x2, xs = _rows2d(x, "x")
-            if big:
-                # dW | db in one allocation: the kernel zero-fills both with a single memset
-                buf = torch.empty(O * I + (O if ctx.has_bias else 0), device=dy.device, dtype=torch.float32)
-                dW = buf[:O * I].view(O, I)
-                db = buf[O * I:] if ctx.has_bias else None
-                ws = torch.empty(lib.mlagg_linear_wgrad_workspace_floats(M, O, I), device=dy.device,
-                                 dtype=torch.float32)
-                wgrad = lib.mlagg_linear_wgrad_x3 if K5_X3 else lib.mlagg_linear_wgrad
-                _lib.check(wgrad(_ptr(dy2), dys, _ptr(x2), xs, _ptr(dW), _ptr(db), _ptr(ws), M, O, I, _stream()), "mlagg_linear_wgrad")
-            else:
-                dW = dy2.t().matmul(x2)
-                db = (column_sum(dy2) if dy2.is_cuda else dy2.sum(0)) if ctx.has_bias else None
+            dW, db = _linear_wgrad(dy2, dys, x, O, I, ctx.has_bias)
         return dx, dW, db
 
 
 def linear(x, weight, bias=None):
     return LinearFn.apply(x, weight, bias)
+
+
+class MlpFn(torch.autograd.Function):
+    """fc2(GELU(fc1(x))) of reference Mlp (T:176-192) as four K5 launches: fc1 writes the pre-activation AND its GELU, and in backward
+    the data gradient of fc2 comes out already multiplied by GELU'(pre) -- the two elementwise GELU passes of the ATen form are gone."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        H, I = w1.shape
+        O = w2.shape[0]
+        M = x.numel() // I
+        x2, xs = _mfma_rows(x, "x")
+        w1c, w2c = _require(w1.contiguous(), "fc1.weight"), _require(w2.contiguous(), "fc2.weight")
+        img1, img1T = weight_images(w1c)
+        img2, img2T = weight_images(w2c)
+        pre, act = _x3(x2, xs, img1, b1, M, H, I, epilogue=1)
+        y = _x3(act, H, img2, b2, M, O, H, out_shape=x.shape[:-1] + (O,))
+        ctx.save_for_backward(x, w1, w2, pre, act)
+        ctx.images = (img1T, img2T)
+        ctx.bias = (b1 is not None, b2 is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, pre, act = ctx.saved_tensors
+        img1T, img2T = ctx.images
+        H, I = w1.shape
+        O = w2.shape[0]
+        dy2, dys = _mfma_rows(dy, "dy")
+        M = dy2.shape[0]
+        dW2, db2 = _linear_wgrad(dy2, dys, act, O, H, ctx.bias[1])
+        dpre = _x3(dy2, dys, img2T, None, M, H, O, epilogue=2, pre=pre, pre_stride=H)          # (dy . W2) * GELU'(pre)
+        dW1, db1 = _linear_wgrad(dpre, H, x, H, I, ctx.bias[0])
+        dx = _x3(dpre, H, img1T, None, M, I, H, out_shape=x.shape) if ctx.needs_input_grad[0] else None
+        return dx, dW1, db1, dW2, db2
+
+
+def mlp_supported(x, w1, w2):
+    H, I = w1.shape
+    O = w2.shape[0]
+    M = x.numel() // I
+    return bool(compute_dtype() == torch.float32 and x.is_cuda and _x3_ok(M, H, I) and _x3_ok(M, O, H) and _x3_ok(M, I, H)
+                and _x3_ok(M, H, O))
+
+
+def mlp(x, w1, b1, w2, b2):
+    return MlpFn.apply(x, w1, b1, w2, b2)
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -1733,13 +1908,14 @@ K19_MIN_PIXELS = int(_os.environ.get("MLAGG_K19_MIN_PIXELS", "1024"))
 
 K19_WGRAD = _os.environ.get("MLAGG_K19_WGRAD", "1") == "1"
 K19_WGRAD_MIN_PIXELS = int(_os.environ.get("MLAGG_K19_WGRAD_MIN_PIXELS", "1024"))
+K19_WGRAD_MIN_CH = int(_os.environ.get("MLAGG_K19_WGRAD_MIN_CH", "96"))
 
 
 def _k19_wgrad(O, I, H, W):
     """3 x 3 weight gradient on K19?  Measured against MIOpen's implicit-GEMM kernels + their NHWC transposes (tools/bench_conv3x3.py):
     706 vs 816, 280 vs 323, 175 vs 205, 190 vs 212 us where a channel extent reaches 96 (32-channel tiles are then well filled);
     48 x 48 channels fill 56 % of a tile pair and lose or tie (492 vs 493, 179 vs 119 us), 16 x 16 maps tie."""
-    return (K19_WGRAD and H * W >= K19_WGRAD_MIN_PIXELS and max(O, I) >= 96 and
+    return (K19_WGRAD and H * W >= K19_WGRAD_MIN_PIXELS and max(O, I) >= K19_WGRAD_MIN_CH and
             bool(_lib.lib().mlagg_conv3x3_wgrad_supported(O, I, H, W)))
 
 

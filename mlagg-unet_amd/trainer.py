@@ -203,6 +203,8 @@ class ClipAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         self._steps += 1
+        from . import ops
+        ops.invalidate_weight_images()                # the kernels below rewrite the parameters through raw pointers: no version bump
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
