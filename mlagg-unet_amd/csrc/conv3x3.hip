@@ -432,12 +432,16 @@ void launch(const float *x, const unsigned short *wimg, const float *bias, float
 
 namespace {
 // y = conv(x, w) for a 3 x 3 (D == 1) or 3 x 3 x 3 kernel, stride 1, zero padding 1
+// the kernel's per-lane byte offsets are 32-bit: 4 * (8 * P + q) with q < P, i.e. up to 36 P bytes -- planes (volumes) of up to
+// 2^32 / 36 - 1 elements (about 492^3); larger ones are refused, not wrapped
+constexpr long K19_MAX_PLANE = (1LL << 32) / 36 - 1;
+
 int conv_fwd(const float *x, long x_batch, const float *w, int transposed, const float *bias, float *y, long y_batch, void *workspace,
              int B, int O, int I, int D, int H, int W, void *stream)
 {
     if (!x || !w || !y || !workspace) return MLAGG_E_NULLPTR;
     const long P = (long)D * H * W;
-    if (B <= 0 || B > 65535 || O <= 0 || I <= 0 || (I % 16) || D <= 0 || H <= 0 || W <= 0 || P < 96 || P >= (1L << 28))
+    if (B <= 0 || B > 65535 || O <= 0 || I <= 0 || (I % 16) || D <= 0 || H <= 0 || W <= 0 || P < 96 || P > K19_MAX_PLANE)
         return MLAGG_E_UNSUPPORTED;
     if (x_batch < (long)I * P || y_batch < (long)O * P || (reinterpret_cast<uintptr_t>(workspace) & 15)) return MLAGG_E_UNSUPPORTED;
     C3Geom g{B, O, I, D, H, W, (int)P, x_batch, y_batch};
@@ -478,7 +482,7 @@ int conv_fwd(const float *x, long x_batch, const float *w, int transposed, const
 
 extern "C" int mlagg_conv3x3_supported(int O, int I, int H, int W)
 {
-    return O > 0 && I > 0 && (I % 16) == 0 && H > 0 && W > 0 && (long)H * W >= 96 && (long)H * W < (1L << 28);
+    return O > 0 && I > 0 && (I % 16) == 0 && H > 0 && W > 0 && (long)H * W >= 96 && (long)H * W <= (1LL << 32) / 36 - 1;
 }
 
 // bytes of the weight image: 3 pieces x 9 taps x O x I bf16
@@ -495,7 +499,7 @@ extern "C" int mlagg_conv3x3_fwd(const float *x, long x_batch, const float *w, i
 // the same for 3 x 3 x 3 kernels on (B, C, D, H, W) volumes (nine kernel rows (kz, ky) of three taps each)
 extern "C" int mlagg_conv3x3x3_supported(int O, int I, int D, int H, int W)
 {
-    return O > 0 && I > 0 && (I % 16) == 0 && D > 0 && H > 0 && W > 0 && (long)D * H * W >= 96 && (long)D * H * W < (1L << 28);
+    return O > 0 && I > 0 && (I % 16) == 0 && D > 0 && H > 0 && W > 0 && (long)D * H * W >= 96 && (long)D * H * W <= (1LL << 32) / 36 - 1;
 }
 
 extern "C" size_t mlagg_conv3x3x3_workspace_bytes(int O, int I) { return O > 0 && I > 0 ? (size_t)3 * 27 * O * I * 2 : 0; }

@@ -37,10 +37,14 @@ def hard_tp_fp_fn(logits, target, ignore_label=None):
     zeroed there and ``get_tp_fp_fn_tn(..., mask=mask)`` multiplies every count by the mask)."""
     C = logits.shape[1]
     pred, tgt = logits.argmax(1).reshape(-1), target.reshape(-1).long()
-    if ignore_label is not None:
+    if ignore_label is None:
+        cm = confusion_matrix(pred, tgt, C)
+    else:
+        # no boolean-mask indexing (a nonzero() and a host synchronisation per validation step): ignored pixels are counted into one
+        # extra bin that is dropped
         keep = tgt != int(ignore_label)
-        pred, tgt = pred[keep], tgt[keep]
-    cm = confusion_matrix(pred, tgt, C)
+        idx = torch.where(keep, tgt * C + pred, torch.full_like(tgt, C * C))
+        cm = torch.bincount(idx, minlength=C * C + 1)[:C * C].view(C, C)
     tp = cm.diagonal()
     return tp[1:], (cm.sum(0) - tp)[1:], (cm.sum(1) - tp)[1:]
 

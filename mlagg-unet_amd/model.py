@@ -268,56 +268,73 @@ class _StackFn(torch.autograd.Function):
         return tuple(out)
 
 
+def _capturing(t):
+    return t.is_cuda and torch.cuda.is_current_stream_capturing()
+
+
 class _Stack:
     """Several parameters (or row slices of parameters) stacked along dim 0 for ONE projection.  ``torch.cat`` per use cost 48
     launches per forward of the 256 x 256 network (24 weight + 24 bias stacks: 0.28 ms of device time and as much host time); here
-    every stack owns a buffer, the network refreshes ALL of them with one multi-tensor copy at the start of a forward
-    (``refresh_stacks``), and a stack used outside that (a block called on its own) refreshes itself.  Not parameters, not
-    buffers: state_dict keys are untouched."""
+    every stack owns a buffer that is rewritten only when a source CHANGED since the last copy (the sources' version counters, plus
+    the epoch ``ops.invalidate_weight_images`` bumps when ClipAdamW rewrites parameters through raw pointers): the network refreshes
+    all stale stacks with one multi-tensor copy at the start of a forward (``refresh_stacks``), a stack used outside that refreshes
+    itself.  Two forward passes between optimizer steps therefore share one, unmodified, buffer -- the graph of the first stays
+    valid for its backward -- and a stack can never serve weights older than its sources.  Inside a hipGraph capture the copy is
+    always recorded (a replay must see the parameters of ITS step).  Not parameters, not buffers: state_dict keys are untouched."""
 
     def __init__(self, sources):
-        self.sources, self.buf, self.fresh = sources, None, False          # sources: bound method -> list of tensors
+        self.sources, self.buf, self.sig = sources, None, None             # sources: bound method -> list of tensors
 
     def _views(self, srcs):
         rows = sum(int(t.shape[0]) for t in srcs)
         shape = (rows,) + tuple(srcs[0].shape[1:])
         if self.buf is None or self.buf.device != srcs[0].device or tuple(self.buf.shape) != shape:
             self.buf = torch.empty(shape, device=srcs[0].device, dtype=srcs[0].dtype)
-            self.fresh = False
+            self.sig = None
         out, off = [], 0
         for t in srcs:
             out.append(self.buf[off:off + t.shape[0]])
             off += int(t.shape[0])
         return out
 
+    @staticmethod
+    def signature(srcs):
+        return (ops.image_epoch(),) + tuple(t._version for t in srcs) + tuple(t.data_ptr() for t in srcs)
+
+    def stale(self, srcs):
+        return self.sig != self.signature(srcs) or _capturing(srcs[0])
+
     def get(self):
         srcs = self.sources()
         if not WEIGHT_STACKS:
             return torch.cat(srcs)
         views = self._views(srcs)
-        if not self.fresh:
+        if self.stale(srcs):
             with torch.no_grad():
                 torch._foreach_copy_(views, [t.detach() for t in srcs])
-        self.fresh = False                                      # consumed: the next use without a network refresh copies again
+            self.sig = self.signature(srcs)
         out = _StackFn.apply(self.buf, *srcs)
         out._mlagg_buffer = self.buf                            # ops.WeightImageSet keeps THIS (no grad_fn), never the graph-bound view
         return out
 
 
 def refresh_stacks(stacks):
-    """One multi-tensor copy for every stack of a network (called at the start of its forward)."""
+    """One multi-tensor copy for every stack of a network whose sources changed (called at the start of its forward)."""
     if not WEIGHT_STACKS:
         return
-    dst, src = [], []
+    dst, src, done = [], [], []
     for st in stacks:
         srcs = st.sources()
-        dst += st._views(srcs)
-        src += [t.detach() for t in srcs]
+        views = st._views(srcs)
+        if st.stale(srcs):
+            dst += views
+            src += [t.detach() for t in srcs]
+            done.append((st, srcs))
     if dst:
         with torch.no_grad():
             torch._foreach_copy_(dst, src)
-    for st in stacks:
-        st.fresh = True
+    for st, srcs in done:
+        st.sig = st.signature(srcs)
 
 
 class AggregatedAttention(nn.Module):

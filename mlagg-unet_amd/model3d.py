@@ -269,8 +269,19 @@ def build_network_architecture_3d(num_input_channels, num_segmentation_heads, co
     """``get_umamba_enc_3d_from_plans`` (S:890-942) on the values it reads from the plans: features min(base * 2^i, max)."""
     n = len(conv_kernel_sizes)
     features = [min(base_num_features * 2 ** i, max_num_features) for i in range(n)]
-    return UMambaEnc(num_input_channels, features, [list(k) for k in conv_kernel_sizes], [list(s) for s in pool_op_kernel_sizes],
-                     n_conv_per_stage_encoder, num_segmentation_heads, n_conv_per_stage_decoder, enable_deep_supervision)
+    net = UMambaEnc(num_input_channels, features, [list(k) for k in conv_kernel_sizes], [list(s) for s in pool_op_kernel_sizes],
+                    n_conv_per_stage_encoder, num_segmentation_heads, n_conv_per_stage_decoder, enable_deep_supervision)
+    net.apply(init_weights_he)                                               # S:941 model.apply(InitWeights_He(1e-2))
+    return net
+
+
+def init_weights_he(module, neg_slope=1e-2):
+    """``InitWeights_He`` (reference utilities/network_initialization.py:4-13): every (transposed) convolution -- the depthwise
+    Conv3d of the SS3D blocks included -- gets kaiming_normal_(a = 1e-2) weights and a zero bias."""
+    if isinstance(module, (nn.Conv3d, nn.Conv2d, nn.ConvTranspose2d, nn.ConvTranspose3d)):
+        nn.init.kaiming_normal_(module.weight, a=neg_slope)
+        if module.bias is not None:
+            nn.init.constant_(module.bias, 0)
 
 
 # the 3d_fullres plan shape behind BASELINE configs[3] (BTCV-shaped 96 x 160 x 160 patches): six stages, 3x3x3 kernels, five

@@ -765,6 +765,10 @@ def invalidate_weight_images():
     _IMAGE_EPOCH[0] += 1
 
 
+def image_epoch():
+    return _IMAGE_EPOCH[0]
+
+
 def _image_pair(w):
     """(img, imgT) of a contiguous fp32 (N, K) matrix, built now (one launch)."""
     N, K = w.shape
@@ -784,7 +788,7 @@ class WeightImageSet:
     active = None
 
     def __init__(self):
-        self.tensors, self.entries, self.table, self.store, self.ptrs, self.max_tiles = [], {}, None, None, None, 0
+        self.tensors, self.entries, self.table, self.store, self.ptrs, self.max_tiles, self.built = [], {}, None, None, None, 0, None
 
     def _rebuild_table(self):
         import numpy as np
@@ -814,8 +818,13 @@ class WeightImageSet:
             return
         if self.table is None or self.ptrs != tuple(t.data_ptr() for t in self.tensors):
             self._rebuild_table()
-        _lib.check(_lib.lib().mlagg_weight_images(_ptr(self.table), len(self.tensors), self.max_tiles, _stream()), "mlagg_weight_images")
+            self.built = None
         ep = _IMAGE_EPOCH[0]
+        sig = (ep,) + tuple(t._version for t in self.tensors)
+        if sig == self.built and not torch.cuda.is_current_stream_capturing():
+            return                                    # nothing changed since the last build (inference loops, a second forward of a step)
+        _lib.check(_lib.lib().mlagg_weight_images(_ptr(self.table), len(self.tensors), self.max_tiles, _stream()), "mlagg_weight_images")
+        self.built = sig
         self.entries = {t.data_ptr(): (t._version, ep, v) for t, v in zip(self.tensors, self.views)}
 
     def end(self):

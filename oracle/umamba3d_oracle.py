@@ -195,8 +195,18 @@ class UMambaEnc(nn.Module):                                      # S:815-888
 def build_reference_3d_model(input_channels, num_classes, features, strides, n_conv_per_stage=2, n_conv_per_stage_decoder=2,
                              deep_supervision=True):
     """``get_umamba_enc_3d_from_plans`` (S:890-942) without the plans objects: 3x3x3 kernels at every stage."""
-    return UMambaEnc(input_channels, list(features), [[3, 3, 3]] * len(features), strides, n_conv_per_stage, num_classes,
-                     n_conv_per_stage_decoder, deep_supervision)
+    net = UMambaEnc(input_channels, list(features), [[3, 3, 3]] * len(features), strides, n_conv_per_stage, num_classes,
+                    n_conv_per_stage_decoder, deep_supervision)
+    net.apply(init_weights_he)                                               # S:941 model.apply(InitWeights_He(1e-2))
+    return net
+
+
+def init_weights_he(module, neg_slope=1e-2):
+    """``InitWeights_He`` (reference utilities/network_initialization.py:4-13)."""
+    if isinstance(module, (nn.Conv3d, nn.Conv2d, nn.ConvTranspose2d, nn.ConvTranspose3d)):
+        nn.init.kaiming_normal_(module.weight, a=neg_slope)
+        if module.bias is not None:
+            nn.init.constant_(module.bias, 0)
 
 
 def features_for(n_stages, base=32, cap=320):

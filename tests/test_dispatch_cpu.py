@@ -29,6 +29,10 @@ def test_convolution_kernels_decline_host_tensors_and_unsupported_geometries():
     assert lib.mlagg_conv3x3_supported(48, 48, 16, 16) and not lib.mlagg_conv3x3_supported(48, 1, 256, 256)            # the one-channel stem
     assert lib.mlagg_conv3x3_wgrad_supported(96, 48, 32, 32) and not lib.mlagg_conv3x3_wgrad_supported(96, 48, 30, 30)  # W % 8
     assert lib.mlagg_conv3x3x3_supported(32, 32, 8, 16, 16) and not lib.mlagg_conv3x3x3_supported(32, 1, 8, 16, 16)
+    # 32-bit lane offsets of up to 36 bytes per plane element: planes beyond 2^32 / 36 - 1 elements are refused, not wrapped
+    pmax = (1 << 32) // 36 - 1
+    assert lib.mlagg_conv3x3_supported(16, 16, 1, pmax) and not lib.mlagg_conv3x3_supported(16, 16, 1, pmax + 1)
+    assert lib.mlagg_conv3x3x3_supported(16, 16, 492, 492, 492) and not lib.mlagg_conv3x3x3_supported(16, 16, 493, 493, 493)
     assert lib.mlagg_conv3x3x3_wgrad_supported(32, 32, 8, 16, 40) and not lib.mlagg_conv3x3x3_wgrad_supported(32, 32, 8, 16, 20)
     assert lib.mlagg_conv3x3_workspace_bytes(48, 96) == 3 * 9 * 48 * 96 * 2 and lib.mlagg_conv3x3x3_workspace_bytes(32, 32) == 3 * 27 * 32 * 32 * 2
     assert lib.mlagg_column_sum_workspace_floats(100, 64) == 0 and lib.mlagg_column_sum_workspace_floats(7840, 384) > 0
@@ -53,8 +57,8 @@ def test_residual_norm_off_the_device_is_residual_then_norm():
 
 def test_stacked_projection_weights_refresh_route_gradients_and_survive_deepcopy():
     """model._Stack: values = torch.cat of the sources (a row slice of kv.weight and the 1 x 1 convolution's weight among them),
-    gradients land in the sources, a refreshed stack is consumed once, a copy of the module stacks ITS parameters, and the
-    state_dict has the reference's keys only."""
+    gradients land in the sources, a refreshed stack is not copied again while its sources are unchanged, a copy of the module stacks
+    ITS parameters, and the state_dict has the reference's keys only."""
     import copy
     att = PM.AggregatedAttention(96, (8, 8), 2, False, 2, "B")
     d = 96
@@ -69,11 +73,36 @@ def test_stacked_projection_weights_refresh_route_gradients_and_survive_deepcopy
         att.q.weight.add_(1.0)                                  # an optimizer step
     assert torch.equal(att._w_stack.get()[:d].detach(), att.q.weight.detach())      # a stack nobody refreshed copies on use
     PM.refresh_stacks([att._w_stack])
-    assert att._w_stack.fresh
+    v = att._w_stack.buf._version
     att._w_stack.get()
-    assert not att._w_stack.fresh                              # consumed: the next forward refreshes again
+    PM.refresh_stacks([att._w_stack])
+    assert att._w_stack.buf._version == v                      # sources unchanged: no second copy
     c = copy.deepcopy(att)
     with torch.no_grad():
         c.q.weight.zero_()
     assert float(c._w_stack.get()[:d].abs().max()) == 0 and float(att._w_stack.get()[:d].abs().max()) > 0
     assert sorted(att.state_dict()) == sorted(k for k in att.state_dict() if "stack" not in k) and len(att.state_dict()) == 15
+
+
+def test_weight_stacks_survive_two_forwards_and_never_serve_stale_rows():
+    """model._Stack rewrites its buffer only when a source changed: two forward passes between optimizer steps share one unmodified
+    buffer (both backward passes run: no 'modified by an inplace operation'), an in-place parameter change or ClipAdamW's epoch bump
+    makes the next use copy again -- also for a stack the network refreshed but did not consume."""
+    from mlagg_unet_amd import model
+    a, b = torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(2, 4))
+    st = model._Stack(lambda: [a, b])
+    x = torch.randn(5, 4)
+    y1 = (x @ st.get().t()).sum()
+    v = st.buf._version
+    y2 = (2 * x @ st.get().t()).sum()                     # second forward before the first backward
+    assert st.buf._version == v                           # ... did not touch the buffer
+    y1.backward()
+    y2.backward()
+    assert torch.allclose(a.grad, 3 * x.sum(0).expand(3, 4)) and torch.allclose(b.grad, 3 * x.sum(0).expand(2, 4))
+    with torch.no_grad():
+        a.mul_(2.0)                                       # an optimizer step of torch's: version counter moves
+    assert torch.equal(st.get()[:3], a.detach())
+    model.refresh_stacks([st])                            # refreshed by "the network", not consumed ...
+    a.data.add_(1.0)                                      # ... then rewritten behind autograd's back (what ClipAdamW's kernels do)
+    ops.invalidate_weight_images()                        # ... which is why ClipAdamW bumps the epoch
+    assert torch.equal(st.get()[:3], a.detach())

@@ -89,3 +89,20 @@ def test_validation_step_on_tiny_network():
     a, b, c = EO.hard_tp_fp_fn(o[0], target[0])
     assert np.array_equal(out["tp_hard"].numpy(), a) and np.array_equal(out["fn_hard"].numpy(), c)
     assert np.array_equal(out["fp_hard"].numpy(), b)
+
+
+def test_hard_counts_with_an_ignore_label_match_explicit_masking():
+    """The sync-free ignore-label form (one extra histogram bin) == dropping the ignored pixels first (reference B:917-929)."""
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(3, 6, 16, 16, generator=g)
+    target = torch.round(torch.rand(3, 1, 16, 16, generator=g) * 6)            # label 6 = ignore
+    tp, fp, fn = EV.hard_tp_fp_fn(logits, target, ignore_label=6)
+    keep = target.reshape(-1) != 6
+    pred = logits.argmax(1).reshape(-1)[keep]
+    tgt = target.reshape(-1).long()[keep]
+    for c in range(1, 6):
+        assert int(tp[c - 1]) == int(((pred == c) & (tgt == c)).sum())
+        assert int(fp[c - 1]) == int(((pred == c) & (tgt != c)).sum())
+        assert int(fn[c - 1]) == int(((pred != c) & (tgt == c)).sum())
+    all_ignored = torch.full_like(target, 6)
+    assert all(int(v.sum()) == 0 for v in EV.hard_tp_fp_fn(logits, all_ignored, ignore_label=6))

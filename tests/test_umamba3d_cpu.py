@@ -70,3 +70,28 @@ def test_product_3d_network_has_the_reference_checkpoint_keys():
     assert net.decoder.deep_supervision is False
     with pytest.raises(RuntimeError):                        # the device ops have no host path
         net(torch.zeros(1, 1, 8, 64, 64))
+
+
+@pytest.mark.parametrize("which", ["product", "oracle"])
+def test_3d_builders_apply_the_references_he_initialisation(which):
+    """get_umamba_enc_3d_from_plans ends with model.apply(InitWeights_He(1e-2)) (UMambaEnc_SS3D.py:941; utilities/
+    network_initialization.py:4-13): every (transposed) convolution -- SS3D's depthwise Conv3d included -- has a zero bias and
+    kaiming_normal_(a = 1e-2) weights, i.e. std = sqrt(2 / (1 + a^2) / fan_in)."""
+    import math
+    import mlagg_unet_amd  # noqa: F401
+    from mlagg_unet_amd import model3d
+    n = len(CFG["strides"])
+    torch.manual_seed(3)
+    if which == "product":
+        net = model3d.build_network_architecture_3d(CFG["in_ch"], CFG["n_cls"], [[3, 3, 3]] * n, CFG["strides"], [2] * n, [2] * (n - 1))
+    else:
+        net = U.build_reference_3d_model(CFG["in_ch"], CFG["n_cls"], U.features_for(n), CFG["strides"])
+    convs = [m for m in net.modules() if isinstance(m, (torch.nn.Conv3d, torch.nn.ConvTranspose3d))]
+    assert len(convs) > 30 and any(m.groups > 1 for m in convs)                       # the depthwise convolutions are among them
+    for m in convs:
+        if m.bias is not None:
+            assert float(m.bias.detach().abs().max()) == 0.0
+        fan_in = m.weight.shape[1] * m.weight[0, 0].numel()
+        want = math.sqrt(2.0 / (1 + 1e-2 ** 2) / fan_in)
+        if m.weight.numel() >= 20000:                                                  # enough samples for a 5 % test of the std
+            assert abs(float(m.weight.detach().std()) - want) < 0.05 * want, (tuple(m.weight.shape), float(m.weight.std()), want)
