@@ -27,6 +27,11 @@ IMG = (256, 256)
 BATCH_PER_GPU = 10
 N_CLASSES = 14
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BF16_MFMA_PEAK_TFS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
+FP32_MFMA_PEAK_TFS = 157.3   # v_mfma_f32_32x32x2_f32: what an fp32 GEMM on the fp32 matrix instruction is bounded by
+# this package's matrix kernels by their profile name; the fp32 products run as SIX bf16 MFMAs each (csrc/bf16x3.h), so the ceiling
+# of real fp32 flop is a sixth of the bf16 peak
+MFMA_FAMILIES = {"K5": "linear forward + data gradient (K5", "K5w": "linear weight gradient (K5w", "K18": "conv1x1 (", "K19": "conv3x3 ("}
 # BASELINE.json configs by their 1-based position; 2 is the headline (the default).  The others print the same JSON line
 # for their own shape / arithmetic type and are never the headline number.
 CONFIGS = {
@@ -326,10 +331,26 @@ def main():
     # into the graph with the kernel, so they time every replay)
     roof = None
     dominant = None
+    mfma = None
     if not args.no_roofline:
+        from mlagg_unet_amd import ops
         profiling.select_all()
+        ops.FLOP_COUNT = {}
         eager_step()
         table = profiling.collect()
+        flop, ops.FLOP_COUNT = ops.FLOP_COUNT, None
+        if cfg["precision"] == "fp32":
+            # the matrix kernels against the MFMA roofline: real flop of the products they ran in this step (counted at the call
+            # sites, 2 M N K each) / their HIP-event time in the same step
+            split_peak = BF16_MFMA_PEAK_TFS / 6.0
+            mfma = {"unit": "TFLOP/s", "peak": round(split_peak, 1), "peak_note": "dense bf16 MFMA peak / 6 (every fp32 product is six "
+                    "bf16 MFMAs)", "fp32_mfma_peak": FP32_MFMA_PEAK_TFS, "kernels": {}}
+            for fam, prefix in MFMA_FAMILIES.items():
+                ms = sum(v["ms"] for k, v in table.items() if k.startswith(prefix))
+                if ms > 0 and flop.get(fam):
+                    tf = flop[fam] / (ms * 1e-3) / 1e12
+                    mfma["kernels"][fam] = {"flop_per_step": flop[fam], "ms_per_step": round(ms, 3), "achieved": round(tf, 1),
+                                            "frac": round(tf / split_peak, 3), "vs_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TFS, 3)}
         # candidates: kernels with ONE shape per step, hence one algorithmic bytes-per-launch figure
         fixed = [k for k in table if profiling.algorithmic_bytes(k, args.batch, IMG) > 0]
         dominant = max(fixed, key=lambda k: table[k]["ms"]) if fixed else None
@@ -387,7 +408,8 @@ def main():
                         "achieved_GBs": round(profiling.algorithmic_bytes(k, args.batch, IMG)
                                               / (table[k]["ms"] / table[k]["count"] * 1e-3) / 1e9, 1)}
                     for k in sorted(fixed)},
-                "all_kernels_ms_per_step": {k: round(v["ms"], 3) for k, v in sorted(table.items())}}
+                "all_kernels_ms_per_step": {k: round(v["ms"], 3) for k, v in sorted(table.items())},
+                "mfma": mfma}
         profiling.select(None)
 
     if rank == 0:

@@ -26,13 +26,13 @@ const char *const kNames[K_COUNT] = {
     "pooled_attn_bwd2_kernel", "dwconv_tiled_kernel<fwd>", "dwconv_tiled_kernel<dgrad>", "dwconv_bwd_weight_kernel", "linear weight gradient (K5w: linear_wgrad_kernel / linear_wgrad_x3_kernel + reduce)", "layernorm_fwd_kernel",
     "layernorm_bwd_kernel", "dwconv_nchw_fwd_kernel", "dwconv_nchw_bwd (data+weight+reduce)",
     "cross_scan_kernel<false>", "cross_scan_kernel<true>", "gate_fwd_kernel", "gate_bwd_kernel",
-    "linear forward (K5: linear_mfma_kernel<true> / linear_lp_kernel<true, MODE>; with x3 also the data gradient on W^T)", "linear data gradient (K5: linear_mfma_kernel<false> / linear_lp_kernel<false, MODE>)", "row_scale_kernel", "dice_ce_stats_kernel", "dice_ce_grad_kernel", "transpose_tile_kernel", "bias gradient (plane_sum / column_sum)", "plane_norm_fwd_kernel", "plane_norm_bwd_kernel", "adamw (sumsq + update)", "flash_fwd_kernel", "flash_bwd (dq + dk/dv)", "channel_epilogue (bias + residual + GELU)",
+    "linear forward + data gradient (K5: linear_x3_kernel on weight images; MLAGG_K5_V2=0: linear_lp_kernel<true, MODE> / linear_mfma_kernel<true>)", "linear data gradient (K5: linear_mfma_kernel<false> / linear_lp_kernel<false, MODE>)", "row_scale_kernel", "dice_ce_stats_kernel", "dice_ce_grad_kernel", "transpose_tile_kernel", "bias gradient (plane_sum / column_sum)", "plane_norm_fwd_kernel", "plane_norm_bwd_kernel", "adamw (sumsq + update)", "flash_fwd_kernel", "flash_bwd (dq + dk/dv)", "channel_epilogue (bias + residual + GELU)",
     "sel1_fwd_kernel<2, false>", "sel1_fwd_kernel<2, true>", "sel1_bwd_local_kernel<2>", "sel1_bwd_kernel<2>",
     "sel1_fwd_kernel<R != 2, false>", "sel1_fwd_kernel<R != 2, true>", "sel1_bwd_local_kernel<R != 2>", "sel1_bwd_kernel<R != 2>",
     "sel1_prefix_kernel", "sel1 reductions (step partials + per-chunk rows)",
     "volume_pad_kernel (+ guard fill)", "conv_wgrad_taps_kernel", "conv_wgrad_reduce_kernel", "conv_taps_kernel (forward / data gradient)",
     "gelu_pool (forward + backward)", "conv1x1 (forward / data gradient / weight gradient)",
-    "conv3x3 (forward / data gradient, incl. weight image)",
+    "conv3x3 (forward / data gradient / weight gradient, incl. weight image and reduce)",
     "tok_fwd_kernel<false>", "tok_fwd_kernel<true>", "tok_bwd_local_kernel", "tok_bwd_group_kernel"};
 }  // namespace
 

@@ -38,9 +38,20 @@ class _DropPathPool:
 
     def __init__(self):
         self.order, self.keep, self.masks, self.pos, self.recording = [], None, None, 0, False
+        self.injected, self.forced = None, False
+
+    def inject(self, factors):
+        """(n_calls, batch) factors -- keep mask / keep probability, in call order -- that the NEXT training forward uses instead of
+        drawing its own (parity tests against a reference run whose DropPath draws were recorded)."""
+        self.injected = factors
 
     def begin(self, batch, device):
-        if not self.order:
+        if self.injected is not None:
+            self.masks = self.injected.to(device=device, dtype=torch.float32).contiguous()
+            if self.masks.dim() != 2 or self.masks.shape[1] != batch:
+                raise RuntimeError("injected DropPath factors must be (n_calls, batch)")
+            self.injected, self.forced, self.pos = None, True, 0
+        elif not self.order:
             self.recording = True
         else:
             if self.keep is None or self.keep.device != device or self.keep.shape[1] != batch:
@@ -50,10 +61,18 @@ class _DropPathPool:
         _DropPathPool.active = self
 
     def end(self):
+        forced, self.forced = self.forced, False
         self.recording = False
         _DropPathPool.active = None
+        if forced and self.pos != self.masks.shape[0]:
+            raise RuntimeError(f"{self.masks.shape[0]} DropPath factors were injected, the forward made {self.pos} calls")
 
     def next(self, keep, batch):
+        if self.forced:
+            if self.pos >= self.masks.shape[0]:
+                raise RuntimeError("more DropPath calls than injected factors")
+            self.pos += 1
+            return self.masks[self.pos - 1]
         if self.recording:
             self.order.append(keep)
             return None
@@ -252,19 +271,29 @@ WEIGHT_STACKS = os.environ.get("MLAGG_WEIGHT_STACKS", "1") == "1"      # 0: torc
 
 class _StackFn(torch.autograd.Function):
     """The stacked matrix as a function of its sources: forward hands out the (already refreshed) buffer, backward cuts the gradient
-    into the sources' row blocks (views: what ``torch.cat``'s backward does)."""
+    into the sources' row blocks -- a view where a source is stacked whole, a zero-filled copy where only rows [lo, hi) of it are.
+    The cutting runs on the leaf-gradient stream (ops._LeafStream): what comes out goes straight to the parameters' AccumulateGrad
+    nodes, so the gradient of a stacked projection never has to be waited for inside backward."""
 
     @staticmethod
-    def forward(ctx, buf, *srcs):
-        ctx.rows = [int(t.shape[0]) for t in srcs]
+    def forward(ctx, buf, ranges, *params):
+        ctx.ranges, ctx.shapes, ctx.sources = ranges, [tuple(p.shape) for p in params], list(params)
+        ops.note_leaf_use(*params)
         return buf.detach()
 
     @staticmethod
     def backward(ctx, g):
-        out, off = [None], 0
-        for r in ctx.rows:
-            out.append(g[off:off + r])
-            off += r
+        out, off = [None, None], 0
+        with ops._LeafStream(g, ok=ops.leaf_single_use(ctx.sources)):
+            for (lo, hi), shape in zip(ctx.ranges, ctx.shapes):
+                piece = g[off:off + hi - lo]
+                if lo == 0 and hi == shape[0]:
+                    out.append(piece)
+                else:
+                    full = torch.zeros(shape, device=g.device, dtype=g.dtype)
+                    full[lo:hi] = piece
+                    out.append(full)
+                off += hi - lo
         return tuple(out)
 
 
@@ -283,38 +312,50 @@ class _Stack:
     always recorded (a replay must see the parameters of ITS step).  Not parameters, not buffers: state_dict keys are untouched."""
 
     def __init__(self, sources):
-        self.sources, self.buf, self.sig = sources, None, None             # sources: bound method -> list of tensors
+        self.sources, self.buf, self.sig = sources, None, None             # sources: bound method -> list of tensors / (tensor, lo, hi)
+
+    @staticmethod
+    def _norm(srcs):
+        """[(parameter (or a view of one), lo, hi)]: a bare tensor is stacked whole, a tuple contributes its rows [lo, hi)."""
+        return [(t[0], int(t[1]), int(t[2])) if isinstance(t, tuple) else (t, 0, int(t.shape[0])) for t in srcs]
 
     def _views(self, srcs):
-        rows = sum(int(t.shape[0]) for t in srcs)
-        shape = (rows,) + tuple(srcs[0].shape[1:])
-        if self.buf is None or self.buf.device != srcs[0].device or tuple(self.buf.shape) != shape:
-            self.buf = torch.empty(shape, device=srcs[0].device, dtype=srcs[0].dtype)
+        rows = sum(hi - lo for _, lo, hi in srcs)
+        shape = (rows,) + tuple(srcs[0][0].shape[1:])
+        dev, dt = srcs[0][0].device, srcs[0][0].dtype
+        if self.buf is None or self.buf.device != dev or tuple(self.buf.shape) != shape:
+            self.buf = torch.empty(shape, device=dev, dtype=dt)
             self.sig = None
         out, off = [], 0
-        for t in srcs:
-            out.append(self.buf[off:off + t.shape[0]])
-            off += int(t.shape[0])
+        for _, lo, hi in srcs:
+            out.append(self.buf[off:off + hi - lo])
+            off += hi - lo
         return out
 
     @staticmethod
+    def _rows(srcs):
+        return [t.detach()[lo:hi] for t, lo, hi in srcs]
+
+    @staticmethod
     def signature(srcs):
-        return (ops.image_epoch(),) + tuple(t._version for t in srcs) + tuple(t.data_ptr() for t in srcs)
+        return (ops.image_epoch(),) + tuple(t._version for t, _, _ in srcs) + tuple(t.data_ptr() for t, _, _ in srcs)
 
     def stale(self, srcs):
-        return self.sig != self.signature(srcs) or _capturing(srcs[0])
+        return self.sig != self.signature(srcs) or _capturing(srcs[0][0])
 
     def get(self):
-        srcs = self.sources()
+        srcs = self._norm(self.sources())
         if not WEIGHT_STACKS:
-            return torch.cat(srcs)
+            return torch.cat([t[lo:hi] for t, lo, hi in srcs])
         views = self._views(srcs)
         if self.stale(srcs):
             with torch.no_grad():
-                torch._foreach_copy_(views, [t.detach() for t in srcs])
+                torch._foreach_copy_(views, self._rows(srcs))
             self.sig = self.signature(srcs)
-        out = _StackFn.apply(self.buf, *srcs)
+        out = _StackFn.apply(self.buf, [(lo, hi) for _, lo, hi in srcs], *[t for t, _, _ in srcs])
         out._mlagg_buffer = self.buf                            # ops.WeightImageSet keeps THIS (no grad_fn), never the graph-bound view
+        out._mlagg_leaf_safe = True                             # its gradient goes to AccumulateGrad nodes only (see _StackFn.backward)
+        out._mlagg_sources = [t for t, _, _ in srcs]            # ... of THESE parameters (ops.leaf_single_use)
         return out
 
 
@@ -324,11 +365,11 @@ def refresh_stacks(stacks):
         return
     dst, src, done = [], [], []
     for st in stacks:
-        srcs = st.sources()
+        srcs = st._norm(st.sources())
         views = st._views(srcs)
         if st.stale(srcs):
             dst += views
-            src += [t.detach() for t in srcs]
+            src += st._rows(srcs)
             done.append((st, srcs))
     if dst:
         with torch.no_grad():
@@ -366,12 +407,13 @@ class AggregatedAttention(nn.Module):
         if self.local:
             return [self.q.weight, self.kv.weight]
         d = self.q.weight.shape[0]
-        return [self.q.weight, self.kv.weight[d:], self.sr.weight.view(d, d)]
+        return [self.q.weight, (self.kv.weight, d, 2 * d), self.sr.weight.view(d, d)]       # the value half of kv only (T:719)
 
     def _stacked_biases(self):
         if self.local:
             return [self.q.bias, self.kv.bias]
-        return [self.q.bias, self.kv.bias[self.q.bias.shape[0]:], self.sr.bias]
+        d = self.q.bias.shape[0]
+        return [self.q.bias, (self.kv.bias, d, 2 * d), self.sr.bias]
 
     def lambda_full(self):
         return ops.diff_lambda(self.lambda_q1, self.lambda_k1, self.lambda_q2, self.lambda_k2, LAMBDA_INIT)

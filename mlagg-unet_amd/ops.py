@@ -77,6 +77,138 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+# ------------------------------------------------------------------------------------------------
+# Leaf gradients on a second stream.  Nothing in backward consumes a weight / bias gradient: only the optimizer (and the data-parallel
+# exchange) read them, after the last backward kernel.  Inside ``with leaf_grad_overlap():`` (trainer.train_step wraps backward in
+# it) the weight-gradient launches of the projection and convolution Functions go to a side stream that forks off the data-gradient
+# chain where their operands are ready; the context's exit joins it back.  The data-gradient chain -- the critical path of backward --
+# gets shorter by the weight-gradient kernels and their reductions, which fill the gaps the small-grid kernels of the chain leave
+# on the 256 CUs.  Operands handed to the side stream stay referenced until the join (see _LeafStream).  Captured into a hipGraph
+# the fork / join become graph edges.
+# Outside the context (a bare ``loss.backward()``) everything stays on the current stream.
+# ------------------------------------------------------------------------------------------------
+# Measured (profiles/round4_e_leaf_stream_ab.log): 37.9 -> 37.7 ms per eager step (0.6 %), but 38.4 -> 39.8 ms under hipGraph replay (the
+# fork / join edges cost more than the overlap returns: the backward chain's kernels already fill the chip).  OFF by default.
+LEAF_STREAM = _os.environ.get("MLAGG_LEAF_STREAM", "0") == "1"
+_LEAF = {"on": False, "side": None, "main": None, "used": False, "epoch": 0, "keep": []}
+
+
+def leaf_grads_ready():
+    """Make the CURRENT stream wait for every leaf gradient enqueued so far (the data-parallel exchange calls it before it gathers a
+    bucket in the middle of backward)."""
+    if _LEAF["on"] and _LEAF["used"]:
+        torch.cuda.current_stream().wait_stream(_LEAF["side"])
+
+
+class leaf_grad_overlap:
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        if self.enabled and LEAF_STREAM and torch.cuda.is_available():
+            _LEAF["main"] = torch.cuda.current_stream()
+            if _LEAF["side"] is None or _LEAF["side"].device != _LEAF["main"].device:
+                _LEAF["side"] = torch.cuda.Stream(device=_LEAF["main"].device)
+            _LEAF["on"], _LEAF["used"] = True, False
+        return self
+
+    def __exit__(self, *exc):
+        _LEAF["epoch"] += 1                                      # the uses counted by note_leaf_use belong to the forward just consumed
+        if _LEAF["on"]:
+            _LEAF["on"] = False
+            if _LEAF["used"]:
+                _LEAF["main"].wait_stream(_LEAF["side"])         # every leaf gradient is complete before anything reads it
+            _LEAF["keep"].clear()                                # (freed behind the join: reuse on the main stream is ordered after it)
+        return False
+
+
+_LEAF_USES = {}
+
+
+def _leaf_base(t):
+    return t._base if t._is_view() and t._base is not None else t
+
+
+def note_leaf_use(*tensors):
+    """Forward-time bookkeeping: how many projections of THIS forward a parameter feeds (see leaf_single_use)."""
+    for t in tensors:
+        if t is None:
+            continue
+        p = _leaf_base(t)
+        if not (p.is_leaf and p.requires_grad):
+            continue
+        u = _LEAF_USES.get(id(p))
+        if u is None or u[0] != _LEAF["epoch"]:
+            _LEAF_USES[id(p)] = [_LEAF["epoch"], 1, p]         # (p itself is kept: an id must not be recycled)
+        else:
+            u[1] += 1
+
+
+def leaf_single_use(tensors):
+    """True when every parameter behind ``tensors`` received ONE use in the forward being differentiated.  A parameter that feeds two
+    projections (kv.weight of the pooled branch: a row slice inside the stacked q | v | sr projection and the whole matrix on the
+    pooled tokens) gets two gradient contributions, and AccumulateGrad adds the second in place on the backward stream: both must
+    then be produced on that stream, so such projections keep their weight gradients off the leaf-gradient stream."""
+    for t in tensors:
+        if t is None:
+            continue
+        u = _LEAF_USES.get(id(_leaf_base(t)))
+        if u is not None and u[0] == _LEAF["epoch"] and u[1] > 1:
+            return False
+    return True
+
+
+def _leaf_sources(*tensors):
+    out = []
+    for t in tensors:
+        if t is not None:
+            out += getattr(t, "_mlagg_sources", [t])
+    return out
+
+
+def _leaf_ok(*tensors):
+    """True when the gradients of these forward arguments go NOWHERE but to AccumulateGrad nodes: parameters themselves, or tensors
+    whose producer promises it (weight stacks, the padded x_proj: ``_mlagg_leaf_safe``).  A gradient that another backward node reads
+    (a sliced or cast weight) must be produced on the backward stream."""
+    return all(t is None or t.is_leaf or getattr(t, "_mlagg_leaf_safe", False) for t in tensors)
+
+
+class _LeafStream:
+    """with _LeafStream(dy, x, ...): launches inside go to the side stream (when the overlap is on), behind everything enqueued so far."""
+
+    def __init__(self, *operands, ok=True):
+        self.operands, self.prev, self.ok = operands, None, ok
+
+    def __enter__(self):
+        if _LEAF["on"] and self.ok:
+            cur = torch.cuda.current_stream()
+            side = _LEAF["side"]
+            if cur.device == side.device:
+                side.wait_stream(cur)
+                # the operands stay REFERENCED until the join: (i) their memory cannot be handed out again while the side stream
+                # reads it, and (ii) autograd cannot add another gradient contribution INTO them in place on the backward stream (it
+                # does that to a gradient nobody else holds: the dy of out_proj is also the gradient of the residual skip)
+                _LEAF["keep"].extend(t for t in self.operands if t is not None)
+                self.prev = cur
+                torch.cuda.set_stream(side)
+                _LEAF["used"] = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_stream(self.prev)
+        return False
+
+
+# flop of the matrix products this package's own kernels run, per family (bench.py's roofline.mfma): None = not counting
+FLOP_COUNT = None
+
+
+def _flop(family, n):
+    if FLOP_COUNT is not None:
+        FLOP_COUNT[family] = FLOP_COUNT.get(family, 0) + int(n)
+
+
 def _stream():
     """Raw handle of torch's current HIP stream on the current device.  Every kernel wrapper asks for it: the two C calls below cost
     0.3 us, `torch.cuda.current_stream().cuda_stream` 9 us (tools/host_profile.py: 2.6 ms of host time per direction and step, and
@@ -233,6 +365,8 @@ class PadXProjFn(torch.autograd.Function):
     def forward(ctx, w):
         K, per, dI = w.shape
         ctx.per = per
+        ctx.leaf, ctx.leaf_params = w.is_leaf, [w]
+        note_leaf_use(w)
         out = w.new_zeros(K, MSMM_XB, dI)
         out[:, :3] = w[:, :3]
         out[:, 4:] = w[:, 3:]
@@ -240,12 +374,17 @@ class PadXProjFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        g = g.view(-1, MSMM_XB, g.shape[-1])
-        return torch.cat([g[:, :3], g[:, 4:]], dim=1)
+        with _LeafStream(g, ok=ctx.leaf and leaf_single_use(ctx.leaf_params)):   # the projection's weight gradient may live on the leaf-gradient stream
+            g3 = g.view(-1, MSMM_XB, g.shape[-1])
+            return torch.cat([g3[:, :3], g3[:, 4:]], dim=1)
 
 
 def pad_x_proj(w):
-    return PadXProjFn.apply(w)
+    out = PadXProjFn.apply(w)
+    if w.is_leaf:
+        out._mlagg_leaf_safe = True                    # its gradient reaches x_proj_weight's AccumulateGrad through PadXProjFn only
+        out._mlagg_sources = [w]
+    return out
 
 
 class MsmmScanFn(torch.autograd.Function):
@@ -868,6 +1007,7 @@ def _x3(x2, xs, img, bias, M, N, K, epilogue=0, pre=None, pre_stride=0, out_shap
     """One launch of mlagg_linear_x3; returns y, or (pre-activation, activation) for the GELU epilogue."""
     y = torch.empty(out_shape if out_shape is not None else (M, N), device=x2.device, dtype=torch.float32)
     act = torch.empty_like(y) if epilogue == 1 else None
+    _flop("K5", 2 * M * N * K)
     _lib.check(_lib.lib().mlagg_linear_x3(_ptr(x2), xs, _ptr(img), _ptr(bias), _ptr(y), N, _ptr(act), _ptr(pre), pre_stride, M, N, K,
                                           epilogue, _stream()), "mlagg_linear_x3")
     return y if epilogue != 1 else (y, act)
@@ -885,6 +1025,7 @@ def _linear_wgrad(dy2, dys, x, O, I, has_bias):
         db = buf[O * I:] if has_bias else None
         ws = torch.empty(lib.mlagg_linear_wgrad_workspace_floats(M, O, I), device=dy2.device, dtype=torch.float32)
         wgrad = lib.mlagg_linear_wgrad_x3 if K5_X3 else lib.mlagg_linear_wgrad
+        _flop("K5w", 2 * M * O * I)
         _lib.check(wgrad(_ptr(dy2), dys, _ptr(x2), xs, _ptr(dW), _ptr(db), _ptr(ws), M, O, I, _stream()), "mlagg_linear_wgrad")
         return dW, db
     dW = dy2.t().matmul(x2)
@@ -902,6 +1043,9 @@ class LinearFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.cdt = cdt = compute_dtype()
         ctx.imgT = None
+        ctx.leaf = _leaf_ok(weight, bias)
+        ctx.leaf_params = _leaf_sources(weight, bias)
+        note_leaf_use(weight, bias)
         O, I = weight.shape
         M = x.numel() // I
         if cdt == torch.float32 and x.is_cuda and _x3_ok(M, O, I):
@@ -913,6 +1057,7 @@ class LinearFn(torch.autograd.Function):
             x2, xs = _mfma_rows(x, "x")
             w = _require(weight.contiguous(), "weight")
             y = torch.empty(x.shape[:-1] + (O,), device=x.device, dtype=torch.float32)
+            _flop("K5", 2 * M * O * I)
             if cdt == torch.float32 and K5_X3:
                 _lib.check(_lib.lib().mlagg_linear_lp_fwd(_ptr(x2), xs, _ptr(w), _ptr(bias), _ptr(y), O, M, O, I, _DTYPE_BF16X3,
                                                           _stream()), "mlagg_linear_lp_fwd")
@@ -944,6 +1089,7 @@ class LinearFn(torch.autograd.Function):
             elif big and (M >= K5_MIN_ROWS or cdt != torch.float32) and O % 4 == 0 and I % 4 == 0:
                 w = _require(weight.contiguous(), "weight")
                 dx = torch.empty(x.shape, device=dy.device, dtype=torch.float32)
+                _flop("K5", 2 * M * O * I)
                 if cdt == torch.float32 and K5_X3:
                     # dx = dy . W as the forward form of the kernel on W^T (I, O): its weight tile is then read along the
                     # contraction, the fast staging path (the transpose is a (O, I) copy of a few hundred KB)
@@ -962,7 +1108,8 @@ class LinearFn(torch.autograd.Function):
                 dx = dy.matmul(weight)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             # weight / bias gradients stay fp32 in every mode (K5w: the token sum is the long one)
-            dW, db = _linear_wgrad(dy2, dys, x, O, I, ctx.has_bias)
+            with _LeafStream(dy2, x, ok=ctx.leaf and leaf_single_use(ctx.leaf_params)):
+                dW, db = _linear_wgrad(dy2, dys, x, O, I, ctx.has_bias)
         return dx, dW, db
 
 
@@ -986,6 +1133,9 @@ class MlpFn(torch.autograd.Function):
         pre, act = _x3(x2, xs, img1, b1, M, H, I, epilogue=1)
         y = _x3(act, H, img2, b2, M, O, H, out_shape=x.shape[:-1] + (O,))
         ctx.save_for_backward(x, w1, w2, pre, act)
+        ctx.leaf = _leaf_ok(w1, b1, w2, b2)
+        ctx.leaf_params = _leaf_sources(w1, b1, w2, b2)
+        note_leaf_use(w1, b1, w2, b2)
         ctx.images = (img1T, img2T)
         ctx.bias = (b1 is not None, b2 is not None)
         return y
@@ -998,9 +1148,12 @@ class MlpFn(torch.autograd.Function):
         O = w2.shape[0]
         dy2, dys = _mfma_rows(dy, "dy")
         M = dy2.shape[0]
-        dW2, db2 = _linear_wgrad(dy2, dys, act, O, H, ctx.bias[1])
+        ok = ctx.leaf and leaf_single_use(ctx.leaf_params)
+        with _LeafStream(dy2, act, ok=ok):
+            dW2, db2 = _linear_wgrad(dy2, dys, act, O, H, ctx.bias[1])
         dpre = _x3(dy2, dys, img2T, None, M, H, O, epilogue=2, pre=pre, pre_stride=H)          # (dy . W2) * GELU'(pre)
-        dW1, db1 = _linear_wgrad(dpre, H, x, H, I, ctx.bias[0])
+        with _LeafStream(dpre, x, ok=ok):
+            dW1, db1 = _linear_wgrad(dpre, H, x, H, I, ctx.bias[0])
         dx = _x3(dpre, H, img1T, None, M, I, H, out_shape=x.shape) if ctx.needs_input_grad[0] else None
         return dx, dW1, db1, dW2, db2
 
@@ -1859,12 +2012,15 @@ class Conv1x1Fn(torch.autograd.Function):
         w = _require(weight.reshape(O, I).contiguous(), "weight")
         if _k18_product(O, I, P):
             y = torch.empty((B, O) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
+            _flop("K18", 2 * B * O * I * P)
             _lib.check(_lib.lib().mlagg_conv1x1_fwd(_ptr(x), xb, _ptr(w), None, _ptr(y), O * P, B, O, I, P, _stream()),
                        "mlagg_conv1x1_fwd")
         else:
             y = torch.nn.functional.conv2d(x, weight)
         ctx.save_for_backward(x, w)
         ctx.wshape = weight.shape
+        ctx.leaf, ctx.leaf_params = _leaf_ok(weight), [weight]
+        note_leaf_use(weight)
         return y
 
     @staticmethod
@@ -1879,16 +2035,19 @@ class Conv1x1Fn(torch.autograd.Function):
             if _k18_product(I, O, P):
                 wt = transpose_2d(w.unsqueeze(0))[0]                                   # (I, O): the contraction runs along its rows
                 dx = torch.empty((B, I) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
+                _flop("K18", 2 * B * O * I * P)
                 _lib.check(lib.mlagg_conv1x1_fwd(_ptr(dy), dyb, _ptr(wt), None, _ptr(dx), I * P, B, I, O, P, _stream()),
                            "mlagg_conv1x1_fwd")
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, w.view(ctx.wshape), None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1,
                                                          (True, False, False))[0]
         if ctx.needs_input_grad[1]:
-            dW = torch.empty(O, I, device=x.device, dtype=torch.float32)
-            ws = torch.empty(lib.mlagg_conv1x1_wgrad_workspace_floats(B, O, I, P), device=x.device, dtype=torch.float32)
-            _lib.check(lib.mlagg_conv1x1_wgrad(_ptr(dy), dyb, _ptr(x), x.stride(0), _ptr(dW), _ptr(ws), B, O, I, P, _stream()),
-                       "mlagg_conv1x1_wgrad")
+            with _LeafStream(dy, x, ok=ctx.leaf and leaf_single_use(ctx.leaf_params)):
+                dW = torch.empty(O, I, device=x.device, dtype=torch.float32)
+                ws = torch.empty(lib.mlagg_conv1x1_wgrad_workspace_floats(B, O, I, P), device=x.device, dtype=torch.float32)
+                _flop("K18", 2 * B * O * I * P)
+                _lib.check(lib.mlagg_conv1x1_wgrad(_ptr(dy), dyb, _ptr(x), x.stride(0), _ptr(dW), _ptr(ws), B, O, I, P, _stream()),
+                           "mlagg_conv1x1_wgrad")
             dW = dW.view(ctx.wshape)
         return dx, dW
 
@@ -1938,6 +2097,7 @@ def _conv3x3_k19(x, xb, w, transposed, O, I, H, W):
     B = x.shape[0]
     y = torch.empty(B, O, H, W, device=x.device, dtype=torch.float32)
     ws = torch.empty(lib.mlagg_conv3x3_workspace_bytes(O, I), device=x.device, dtype=torch.uint8)
+    _flop("K19", 2 * 9 * B * O * I * H * W)
     _lib.check(lib.mlagg_conv3x3_fwd(_ptr(x), xb, _ptr(w), int(transposed), None, _ptr(y), O * H * W, _ptr(ws), B, O, I, H, W, _stream()),
                "mlagg_conv3x3_fwd")
     return y
@@ -1958,6 +2118,8 @@ class Conv3x3Fn(torch.autograd.Function):
         else:
             y = torch.nn.functional.conv2d(x, w, None, 1, 1)
         ctx.save_for_backward(x, w)
+        ctx.leaf, ctx.leaf_params = _leaf_ok(weight), [weight]
+        note_leaf_use(weight)
         return y
 
     @staticmethod
@@ -1976,13 +2138,17 @@ class Conv3x3Fn(torch.autograd.Function):
             lib = _lib.lib()
             if _k19_wgrad(O, I, H, W):
                 dy, dyb, _ = _planes(dy, "dy")
-                dW = torch.empty(O, I, 3, 3, device=x.device, dtype=torch.float32)
-                ws = torch.empty(lib.mlagg_conv3x3_wgrad_workspace_floats(B, O, I, H, W), device=x.device, dtype=torch.float32)
-                _lib.check(lib.mlagg_conv3x3_wgrad(_ptr(dy), dyb, _ptr(x), x.stride(0), _ptr(dW), _ptr(ws), B, O, I, H, W, _stream()),
-                           "mlagg_conv3x3_wgrad")
+                with _LeafStream(dy, x, ok=ctx.leaf and leaf_single_use(ctx.leaf_params)):
+                    dW = torch.empty(O, I, 3, 3, device=x.device, dtype=torch.float32)
+                    ws = torch.empty(lib.mlagg_conv3x3_wgrad_workspace_floats(B, O, I, H, W), device=x.device, dtype=torch.float32)
+                    _flop("K19", 2 * 9 * B * O * I * H * W)
+                    _lib.check(lib.mlagg_conv3x3_wgrad(_ptr(dy), dyb, _ptr(x), x.stride(0), _ptr(dW), _ptr(ws), B, O, I, H, W, _stream()),
+                               "mlagg_conv3x3_wgrad")
             else:
-                dW = torch.ops.aten.convolution_backward(dy.contiguous(), x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
-                                                         (False, True, False))[1]
+                dyc = dy.contiguous()
+                with _LeafStream(dyc, x, w, ok=ctx.leaf and leaf_single_use(ctx.leaf_params)):
+                    dW = torch.ops.aten.convolution_backward(dyc, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                             (False, True, False))[1]
         return dx, dW
 
 

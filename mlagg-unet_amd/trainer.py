@@ -381,6 +381,8 @@ class BucketedGradSync:
         b = self.buckets[self._where[p]]
         b["ready"] += 1
         if b["ready"] == len(b["params"]):
+            from . import ops
+            ops.leaf_grads_ready()                    # weight gradients may still be in flight on the leaf-gradient stream
             torch._foreach_copy_(b["views"], [q.grad for q in b["params"]])
             if self.world > 1:
                 b["flat"].mul_(1.0 / self.world)
@@ -461,8 +463,13 @@ def train_step(network, optimizer, data, target: List[torch.Tensor], batch_dice=
     optimizer.zero_grad(set_to_none=True)
     output = network(data)
     loss = deep_supervision_loss(output, target, batch_dice, ddp) if loss_fn is None else loss_fn(output, target)
+    from . import ops
+    # torch's own DistributedDataParallel copies every gradient into its bucket the moment it is accumulated, on the backward stream:
+    # no side stream under it (BucketedGradSync waits for the leaf-gradient stream before it gathers a bucket)
+    overlap = not isinstance(network, torch.nn.parallel.DistributedDataParallel)
     if grad_scaler is not None:
-        grad_scaler.scale(loss).backward()
+        with ops.leaf_grad_overlap(overlap):
+            grad_scaler.scale(loss).backward()
         finish_grad_sync(network)
         grad_scaler.unscale_(optimizer)
         if isinstance(optimizer, ClipAdamW):
@@ -472,7 +479,8 @@ def train_step(network, optimizer, data, target: List[torch.Tensor], batch_dice=
             grad_scaler.step(optimizer)
         grad_scaler.update()
         return loss.detach()
-    loss.backward()
+    with ops.leaf_grad_overlap(overlap):                   # weight gradients on a second stream, joined before anything reads them
+        loss.backward()
     finish_grad_sync(network)
     if isinstance(optimizer, ClipAdamW):
         optimizer.step(max_norm=clip)                      # norm, clip coefficient and AdamW on the device, two launches

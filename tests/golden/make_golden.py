@@ -237,6 +237,126 @@ def golden_full_model_config(T, tag):
     print("full model", tag, float(loss), [tuple(o.shape) for o in out], out[0].dtype, f"{time.time() - t0:.0f}s", flush=True)
 
 
+GRAD_TENSOR_PARAMS = (
+    # >= 20 parameters spread over the encoder, the downs, the MSMM skip module and the decoder: the
+    # gradient TENSORS, not only their norms -- a wrong direction with the right norm must not pass
+    "mlla.patch_embed.proj1.conv1.weight", "mlla.patch_embed.proj2.conv2.weight", "mlla.patch_embed.proj1.norm1.weight",
+    "mlla.layers.0.blocks.0.in_proj.weight", "mlla.layers.0.blocks.0.dwc.weight", "mlla.layers.0.blocks.1.attn.0.kv.weight",
+    "mlla.layers.0.blocks.1.attn.1.lepe.weight", "mlla.layers.0.blocks.0.mlp.fc1.weight", "mlla.layers.1.blocks.0.attn.1.q.weight",
+    "mlla.layers.1.blocks.1.attn.1.sr.weight", "mlla.layers.1.blocks.1.norm2.weight", "mlla.layers.2.blocks.0.out_proj.weight",
+    "mlla.layers.2.blocks.1.attn.0.lambda_q1", "mlla.layers.2.blocks.1.attn.1.subln.weight", "mlla.layers.3.blocks.0.act_proj.weight",
+    "mlla.layers.3.blocks.1.mlp.fc2.bias", "mlla.layers.3.blocks.1.attn.1.kv.weight", "mlla.downs.0.conv1.weight",
+    "mlla.downs.2.res_conv.weight", "mambaskip.blocks.0.ln_1.weight", "mambaskip.blocks.0.self_attention.in_proj.weight",
+    "mambaskip.blocks.0.self_attention.conv2d.0.weight", "mambaskip.blocks.0.self_attention.x_proj_weight",
+    "mambaskip.blocks.0.self_attention.dt_projs_weight", "mambaskip.blocks.0.self_attention.dt_projs_bias",
+    "mambaskip.blocks.0.self_attention.A_logs", "mambaskip.blocks.0.self_attention.Ds", "mambaskip.blocks.0.self_attention.out_norm.weight",
+    "mambaskip.blocks.0.self_attention.out_proj.weight", "mambaskip.blocks.0.mlps.1.fc1.weight", "mambaskip.blocks.0.mlps.3.dwconv.dwconv.weight",
+    "mambaskip.blocks.0.conv_branches.0.0.weight", "mambaskip.blocks.0.conv_branches.2.1.weight", "up_2.conv1.weight", "up_0.res_conv.weight",
+    "dec_block_2.0.conv2.weight", "dec_block_0.1.conv1.weight", "dec_block_1.0.norm.weight", "encoder0.layer.conv1.conv.weight",
+    "encoder0.layer.conv3.conv.weight", "decoder0.transp_conv.conv.weight", "decoder0.conv_block.conv2.conv.weight",
+    "out_0.conv_out.weight", "out_3.conv_out.bias",
+)
+GRAD_TENSOR_CASES = {
+    # tag: (img, in_ch, n_cls, batch, variant, data_seed) -- the inputs of the forward goldens of the same shapes
+    "256_variantB": ((256, 256), 1, 14, 1, "B", 4321),
+    "224_variantB": ((224, 224), 1, 4, 1, "B", 2240),
+    "512x640_variantA": ((512, 640), 3, 8, 1, "A", 5126),
+}
+
+
+def _subsample(t, budget=2048):
+    flat = t.detach().reshape(-1)
+    stride = max(1, -(-flat.numel() // budget))
+    return flat[::stride].numpy().copy(), stride
+
+
+def golden_gradient_tensors(T, tag):
+    """Gradient TENSORS of GRAD_TENSOR_PARAMS (sub-sampled to <= 2048 entries each, stride stored) of the reference network +
+    DeepSupervisionWrapper(DC_and_CE_loss) at one BASELINE shape, eval mode, same inputs as full_model_<tag>.npz."""
+    img, in_ch, n_cls, batch, variant, seed = GRAD_TENSOR_CASES[tag]
+    FLASH_SCALE["value"] = None if variant == "A" else 1.0
+    m = ref_model(T, img, n_cls, in_ch).eval()
+    data, target = O.synthetic_batch(batch, in_ch, *img, n_cls, seed=seed)
+    from nnunetv2.training.loss.compound_losses import DC_and_CE_loss
+    from nnunetv2.training.loss.deep_supervision import DeepSupervisionWrapper
+    from nnunetv2.training.loss.dice import MemoryEfficientSoftDiceLoss
+    base = DC_and_CE_loss({'batch_dice': True, 'smooth': 1e-5, 'do_bg': False, 'ddp': False}, {}, weight_ce=1,
+                          weight_dice=1, ignore_label=None, dice_class=MemoryEfficientSoftDiceLoss)
+    w = np.array([1 / (2 ** i) for i in range(5)])
+    import time
+    t0 = time.time()
+    loss = DeepSupervisionWrapper(base, w / w.sum())(m(data), target)
+    loss.backward()
+    params = dict(m.named_parameters())
+    store = {}
+    for n in GRAD_TENSOR_PARAMS:
+        g, stride = _subsample(params[n].grad)
+        store["grad/" + n] = g
+        store["stride/" + n] = stride
+        store["absmax/" + n] = float(params[n].grad.abs().max())
+    np.savez_compressed(os.path.join(HERE, f"full_model_{tag}_grads.npz"), img=np.asarray(img), in_ch=in_ch, n_cls=n_cls, batch=batch,
+                        variant=variant, data_seed=seed, loss=float(loss), names=np.asarray(GRAD_TENSOR_PARAMS), **store)
+    print("gradient tensors", tag, float(loss), len(GRAD_TENSOR_PARAMS), "parameters", f"{time.time() - t0:.0f}s", flush=True)
+
+
+TRAIN_MODE_DROPS = ((3, 1), (12, 0), (14, 1), (17, 0))      # (DropPath call, sample): encoder stage 1 and 3 branches, MSMM scan, MSMM MLP of scale 2
+
+
+def golden_train_mode(T):
+    """The reference network in TRAIN mode (DropPath active: T:868, 903, 907; M:688, 741, 745; rates linspace(0, 0.1, 8) and 0.1) on
+    two 64 x 64 samples.  The per-sample keep masks of the 19 DropPath calls (the first block's rate is 0) are PRESET instead of drawn
+    -- with rates <= 0.1 a seeded draw drops one branch in 38; the preset drops four, one of them the MSMM scan branch and one an
+    MSMM gated MLP -- applied exactly as timm applies a drawn mask (x * mask / keep), and stored already divided by the keep
+    probability so that the other side can inject the same factors; logits, loss, every gradient norm and the GRAD_TENSOR_PARAMS
+    gradient tensors."""
+    FLASH_SCALE["value"] = 1.0
+    img = (64, 64)
+    m = ref_model(T, img).train()
+    data, target = O.synthetic_batch(2, 1, *img, 14, seed=777)
+    drawn = []
+    orig = O.DropPath.forward
+
+    def recording_forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_ones((x.shape[0],) + (1,) * (x.ndim - 1))
+        for call, sample in TRAIN_MODE_DROPS:
+            if call == len(drawn):
+                mask[sample] = 0.0
+        drawn.append((keep, (mask.reshape(-1) / keep).clone()))
+        return x * mask / keep
+
+    O.DropPath.forward = recording_forward
+    try:
+        torch.manual_seed(2024)
+        out = m(data)
+    finally:
+        O.DropPath.forward = orig
+    from nnunetv2.training.loss.compound_losses import DC_and_CE_loss
+    from nnunetv2.training.loss.deep_supervision import DeepSupervisionWrapper
+    from nnunetv2.training.loss.dice import MemoryEfficientSoftDiceLoss
+    base = DC_and_CE_loss({'batch_dice': True, 'smooth': 1e-5, 'do_bg': False, 'ddp': False}, {}, weight_ce=1,
+                          weight_dice=1, ignore_label=None, dice_class=MemoryEfficientSoftDiceLoss)
+    w = np.array([1 / (2 ** i) for i in range(5)])
+    loss = DeepSupervisionWrapper(base, w / w.sum())(out, target)
+    loss.backward()
+    names, norms = grad_summary(m)
+    params = dict(m.named_parameters())
+    store = {}
+    for n in GRAD_TENSOR_PARAMS:
+        g, stride = _subsample(params[n].grad)
+        store["grad/" + n] = g
+        store["stride/" + n] = stride
+    masks = torch.stack([v for _, v in drawn]).numpy()
+    assert masks.shape == (19, 2) and int((masks == 0).sum()) == len(TRAIN_MODE_DROPS), (masks.shape, masks)
+    np.savez_compressed(os.path.join(HERE, "full_model_64_train_mode.npz"), img=np.asarray(img), batch=2, n_cls=14, data_seed=777,
+                        keep=np.asarray([k for k, _ in drawn]), masks=masks, loss=float(loss), grad_names=np.asarray(names),
+                        grad_norms=norms, names=np.asarray(GRAD_TENSOR_PARAMS),
+                        **{f"out{i}": o.detach().numpy() for i, o in enumerate(out)}, **store)
+    print("train mode", float(loss), masks.tolist())
+
+
 def golden_mllablock(T, variant):
     FLASH_SCALE["value"] = None if variant == "A" else 1.0
     for tag, dim, res, heads, sr in (("s0", 96, (16, 16), 2, 4), ("s2", 384, (6, 8), 8, 2)):
@@ -544,6 +664,13 @@ if __name__ == "__main__":
     if "--config" in sys.argv:
         for tag in sys.argv[sys.argv.index("--config") + 1:]:
             golden_full_model_config(T, tag)
+        sys.exit(0)
+    if "--grads" in sys.argv:
+        for tag in sys.argv[sys.argv.index("--grads") + 1:]:
+            golden_gradient_tensors(T, tag)
+        sys.exit(0)
+    if "--only-train-mode" in sys.argv:
+        golden_train_mode(T)
         sys.exit(0)
     if "--only-ss3d" in sys.argv:
         golden_ss3d()

@@ -69,6 +69,10 @@ K16_CASES = [
     (2, 16, 6, (3, 5, 8), 1),          # 1x1x1
     (1, 32, 32, (24, 40, 40), 3),      # a stage of BASELINE configs[3] at 1/64 of its voxels
     (1, 9, 33, (2, 3, 4), 3),          # odd channel counts, a volume smaller than one workgroup's 512 voxels
+    # "last workgroup past Q" (the geometry behind commit 3cf46f4): the padded box holds Q = 5 * 13 * 16 = 1040 = 2 * 512 + 16 voxels,
+    # so 496 of the last workgroup's 512 positions lie past it -- their loads must be clamped into the guarded rows (before the fix
+    # they ran up to a plane + a row beyond the LAST sample's guard, i.e. off the end of the buffer)
+    (2, 16, 16, (3, 11, 8), 3),
 ]
 
 
