@@ -20,11 +20,20 @@ What the class overrides, and why the inherited method cannot stay (B = nnUNetTr
                     all-reduce; the ignore label of partially annotated datasets is handled in K9; region datasets keep the
                     reference's own loss classes.
 """
+import os
+
 import torch
 
 from . import evaluation, miopen_tuning, model, trainer
 
 PRECISIONS = ("fp32", "bf16", "fp16")
+# The reference loop reads the loss back every step (B:863), so the host cannot run ahead of the device: an eagerly enqueued step then
+# costs its ~30 ms of Python / launch time ON TOP of a part of its GPU time (41.6 against 37.7 ms per step at 256 x 256, batch 10:
+# profiles/round4_e_bench_with_mfma_roofline.json.log).  After GRAPH_AFTER eager steps on one batch geometry the plugin therefore
+# captures the whole step (zero_grad, forward, loss, backward, clip, AdamW: trainer.GraphedTrainStep) and replays it: 38.4 ms with
+# the read-back.  Single-process fp32 / bf16 training only; MLAGG_PLUGIN_GRAPH=0 keeps every step eager.
+PLUGIN_GRAPH = os.environ.get("MLAGG_PLUGIN_GRAPH", "1") == "1"
+GRAPH_AFTER = 3
 
 
 def make_trainer_class(nnUNetTrainer, variant="B", precision="fp32"):
@@ -48,6 +57,7 @@ def make_trainer_class(nnUNetTrainer, variant="B", precision="fp32"):
             if precision != "fp16":
                 self.grad_scaler = None
             self.mlagg_precision = precision
+            self._graphed, self._graph_key, self._graph_eager, self._graph_failed = None, None, 0, None
             # run_training.py:123-125 sets cudnn.benchmark (MIOpen's exhaustive find); here: the committed find-db, which
             # holds the fp32 convolutions of the 256 x 256 step only.  Any other patch size or precision takes MIOpen's
             # immediate-mode choice (no find, naive fallback solvers left available): a find-db miss in FAST mode with the
@@ -97,8 +107,14 @@ def make_trainer_class(nnUNetTrainer, variant="B", precision="fp32"):
 
             return loss
 
+        def _graph_ok(self):
+            """The step may be replayed as a hipGraph: one process, no GradScaler, the fused device loss, a device network."""
+            return bool(PLUGIN_GRAPH and self._graph_failed is None and not self.is_ddp and self.grad_scaler is None
+                        and self.device.type == "cuda" and not getattr(self.label_manager, "has_regions", False))
+
         def configure_optimizers(self):                                             # reference T:137-147
-            return trainer.configure_optimizers(self.network, self.initial_lr, self.weight_decay)
+            # capturable: learning rate and step counter live on the device, so the same optimizer serves eager and replayed steps
+            return trainer.configure_optimizers(self.network, self.initial_lr, self.weight_decay, capturable=self._graph_ok())
 
         def _to_device(self, batch):                                                # reference B:834-841
             data = batch["data"].to(self.device, non_blocking=True)
@@ -111,8 +127,26 @@ def make_trainer_class(nnUNetTrainer, variant="B", precision="fp32"):
             data, target = self._to_device(batch)
             if not isinstance(target, list):
                 target = [target]
-            loss = trainer.train_step(self.network, self.optimizer, data.float(), [t.float() for t in target],
-                                      clip=12.0, loss_fn=self.loss, grad_scaler=self.grad_scaler)
+            data, target = data.float(), [t.float() for t in target]
+            if self._graph_ok() and isinstance(self.optimizer, trainer.ClipAdamW) and self.optimizer.capturable:
+                key = (tuple(data.shape),) + tuple(tuple(t.shape) for t in target)
+                if self._graphed is not None and key == self._graph_key:
+                    return {"loss": self._graphed(data, target).cpu().numpy()}      # replay + the reference's per-step host copy
+                if self._graphed is None:
+                    self._graph_eager = self._graph_eager + 1 if key == self._graph_key else 1
+                    self._graph_key = key
+                    if self._graph_eager > GRAPH_AFTER:
+                        try:
+                            # warmup=0: the eager steps above were the warm-up; the capture itself executes nothing, so the first
+                            # replay IS this step (no batch is trained on twice)
+                            self._graphed = trainer.GraphedTrainStep(self.network, self.optimizer, data, target, clip=12.0,
+                                                                     warmup=0, loss_fn=self.loss)
+                            return {"loss": self._graphed().cpu().numpy()}
+                        except Exception as e:                                      # noqa: BLE001  (stay eager, say why once)
+                            self._graphed, self._graph_failed = None, repr(e)
+                            self.print_to_log_file(f"MLAgg: hipGraph capture of the train step failed ({e!r}); steps stay eager")
+            loss = trainer.train_step(self.network, self.optimizer, data, target, clip=12.0, loss_fn=self.loss,
+                                      grad_scaler=self.grad_scaler)
             return {"loss": loss.cpu().numpy()}                                     # the reference's per-step host copy
 
         def validation_step(self, batch):                                           # reference B:880-942

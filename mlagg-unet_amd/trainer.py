@@ -329,8 +329,11 @@ class BucketedGradSync:
 
     torch's DDP copies every gradient into its bucket with its own kernel (and scales it there): 456 launches of ~4 us per step for
     the 524 gradients of this network (profiles/round3_j_ddp_single_rank_trace.md: 1.8 ms of a 38 ms step, before a single byte is
-    exchanged).  Here the parameters are cut into buckets in reverse registration order (the order backward produces them; a small
-    first bucket so that the exchange starts early); when the last gradient of a bucket has been accumulated
+    exchanged).  Here the parameters are cut into buckets in reverse registration order for the FIRST step, and from the second step
+    on in the order that step's backward actually delivered the gradients (what DDP's bucket rebuild does: registration order has
+    ``downs.i`` behind all ``layers.j``, backward interleaves them, and the round-4 trace showed five of ten buckets -- half of the
+    108 MB -- becoming complete at 95 % of backward: profiles/round4_f_ddp_bucket_timeline.md); a small first bucket so that the
+    exchange starts early; when the last gradient of a bucket has been accumulated
     (``register_post_accumulate_grad_hook``) the bucket's gradients are gathered into its flat buffer by ONE multi-tensor copy,
     scaled by 1 / world once, and all-reduced asynchronously (RCCL on its own stream, overlapped with the rest of backward).
     ``finish()`` -- called by ``train_step`` after backward -- waits for the exchanges and points every ``p.grad`` at its slice of
@@ -353,21 +356,28 @@ class BucketedGradSync:
             for p in params:
                 p.copy_(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
+        self._caps = (int(first_bucket_mb * (1 << 20)) // 4, int(bucket_cap_mb * (1 << 20)) // 4)
+        self._arrival, self._rebuilt = [], False
+        self._plan(list(reversed(params)))
+        for p in params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def _plan(self, ordered):
+        """Cut ``ordered`` (parameters in the order their gradients arrive) into buckets."""
         self.buckets, cur, n = [], [], 0
-        cap = int(first_bucket_mb * (1 << 20)) // 4
-        for p in reversed(params):
+        cap = self._caps[0]
+        for p in ordered:
             cur.append(p)
             n += p.numel()
             if n >= cap:
                 self._close(cur, n)
-                cur, n, cap = [], 0, int(bucket_cap_mb * (1 << 20)) // 4
+                cur, n, cap = [], 0, self._caps[1]
         if cur:
             self._close(cur, n)
         self._where = {}
         for bi, b in enumerate(self.buckets):
             for p in b["params"]:
                 self._where[p] = bi
-                p.register_post_accumulate_grad_hook(self._on_grad)
 
     def _close(self, params, n):
         flat = torch.zeros(n, device=params[0].device, dtype=torch.float32)
@@ -378,6 +388,8 @@ class BucketedGradSync:
         self.buckets.append({"params": list(params), "flat": flat, "views": views, "ready": 0, "handle": None})
 
     def _on_grad(self, p):
+        if not self._rebuilt:
+            self._arrival.append(p)                   # first backward: remember the order the gradients arrive in
         b = self.buckets[self._where[p]]
         b["ready"] += 1
         if b["ready"] == len(b["params"]):
@@ -400,6 +412,13 @@ class BucketedGradSync:
             b["handle"], b["ready"] = None, 0
             for p, v in zip(b["params"], b["views"]):
                 p.grad = v
+        if not self._rebuilt:
+            # every rank saw the same arrival order (same network, same autograd graph): the new plan is identical everywhere.  The
+            # gradients of THIS step keep living in the old flat buffers (p.grad views above) until the optimizer has used them
+            self._rebuilt = True
+            if len(self._arrival) == len(self._where) and len(set(map(id, self._arrival))) == len(self._arrival):
+                self._plan(self._arrival)
+            self.arrival_order, self._arrival = self._arrival, []
 
 
 GRAD_SYNC = os.environ.get("MLAGG_GRAD_SYNC", "bucketed")     # "ddp": torch's DistributedDataParallel on the device too
@@ -500,13 +519,13 @@ class GraphedTrainStep:
     PyTorch 2.10 / ROCm 7.0 build (AccumulateGrad nodes stashed by DDP on another stream, then a crash in the RCCL work enqueue:
     profiles/round3_ddp_graph_capture_segfault.log), so a DistributedDataParallel network is refused here."""
 
-    def __init__(self, network, optimizer, data, target, batch_dice=True, clip=12.0, warmup=3):
+    def __init__(self, network, optimizer, data, target, batch_dice=True, clip=12.0, warmup=3, loss_fn=None):
         if isinstance(network, torch.nn.parallel.DistributedDataParallel) or getattr(network, "_mlagg_grad_sync", None) is not None:
             raise RuntimeError("GraphedTrainStep: a DistributedDataParallel network cannot be captured on this build "
                                "(segmentation fault inside the capture); run the data-parallel step eagerly")
         self.data = data.clone()
         self.target = [t.clone() for t in target]
-        body = lambda: train_step(network, optimizer, self.data, self.target, batch_dice, False, clip)  # noqa: E731
+        body = lambda: train_step(network, optimizer, self.data, self.target, batch_dice, False, clip, loss_fn=loss_fn)  # noqa: E731
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

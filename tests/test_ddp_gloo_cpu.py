@@ -230,7 +230,13 @@ def _bucketed_case(rank, world):
                               torch.nn.Linear(300, 4))
     frozen = torch.nn.Parameter(torch.ones(3), requires_grad=False)
     net.register_parameter("dummy_tensor", frozen)
+    # registration order and gradient-arrival order disagree (like mlla.downs.* behind all mlla.layers.* in the real network): a
+    # parameter of the container itself comes FIRST in parameters() -- last in the reverse-registration plan -- but is used last in
+    # forward, so its gradient arrives first
+    net.register_parameter("head_gain", torch.nn.Parameter(torch.ones(4)))
+    net[4].register_forward_hook(lambda m, a, out: out * net.head_gain)
     sync = trainer.BucketedGradSync(net, bucket_cap_mb=0.2, first_bucket_mb=0.001)      # 92 k parameters: several buckets
+    first_plan = [id(p) for b in sync.buckets for p in b["params"]]
     start = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
     opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], 0.05)
     g = torch.Generator().manual_seed(10 + rank)
@@ -247,6 +253,11 @@ def _bucketed_case(rank, world):
             errs.append(float((p.grad - want / world).abs().max()))
             assert p.grad.is_contiguous() and p.grad.shape == p.shape
         opt.step()
+    # after the first step the buckets follow the order the gradients ARRIVED in: that parameter moved from the last bucket (reverse
+    # registration order) to the first
+    plan = [id(p) for b in sync.buckets for p in b["params"]]
+    assert plan == [id(p) for p in sync.arrival_order] and plan != first_plan
+    assert first_plan[-1] == id(net.head_gain) and plan[0] == id(net.head_gain)
     # a step in which a parameter gets no gradient is an error, not a silent stale exchange
     opt.zero_grad(set_to_none=True)
     net[0](torch.randn(2, 6)).sum().backward()

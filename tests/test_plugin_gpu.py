@@ -75,6 +75,41 @@ def test_plugin_and_trainer_steps_are_bit_identical_in_deterministic_mode():
         trainer.set_deterministic(False)
 
 
+def test_plugin_replays_the_step_as_a_hipgraph_after_three_eager_steps():
+    """The plugin's train_step behind the reference loop (per-step loss read-back, B:863): three eager steps, then the whole step is
+    captured and replayed (trainer.GraphedTrainStep, warm-up 0: no batch is trained on twice).  Deterministic mode, DropPath off
+    (eval) so that both sides are comparable bit for bit: seven steps on seven different batches end on the losses and parameters of
+    seven eager ``trainer.train_step`` calls on a twin; a batch of another geometry falls back to an eager step."""
+    from mlagg_unet_amd import nnunet_plugin, trainer
+    assert nnunet_plugin.PLUGIN_GRAPH
+    trainer.set_deterministic(True)
+    try:
+        tr = _trainer()
+        tr.network.eval()
+        assert tr.optimizer.capturable
+        twin = copy.deepcopy(tr.network)
+        twin_opt, _ = trainer.configure_optimizers(twin, tr.initial_lr, tr.weight_decay)
+        for it, b in enumerate(_batches(7)):
+            got = tr.train_step(b)
+            want = trainer.train_step(twin, twin_opt, b["data"].cuda(), [t.cuda() for t in b["target"]], batch_dice=True)
+            assert float(got["loss"]) == float(want), it
+            assert (tr._graphed is not None) == (it >= 3), it
+        for (k, a), q in zip(tr.network.state_dict().items(), twin.state_dict().values()):
+            assert torch.equal(a, q), k
+        assert tr.optimizer.steps_done() == 7 and tr._graph_failed is None
+        # another batch geometry: an eager step, the captured graph stays valid for the old one
+        data, target = trainer.synthetic_batch(1, 1, *IMG, NCLS, seed=99)
+        got = tr.train_step({"data": data, "target": target})
+        want = trainer.train_step(twin, twin_opt, data.cuda(), [t.cuda() for t in target], batch_dice=True)
+        assert float(got["loss"]) == float(want)
+        b = _batches(1)[0]
+        got = tr.train_step(b)
+        want = trainer.train_step(twin, twin_opt, b["data"].cuda(), [t.cuda() for t in b["target"]], batch_dice=True)
+        assert float(got["loss"]) == float(want) and tr.optimizer.steps_done() == 9
+    finally:
+        trainer.set_deterministic(False)
+
+
 def test_reference_amp_step_also_runs_on_the_product_network():
     """The inherited body of B:833-863 (autocast('cuda') + GradScaler) is not what the plugin runs, but a maintainer who
     keeps it must not crash: the network leaves autocast for its own precision, gradients come back fp32, and the scaled

@@ -30,9 +30,11 @@ for s in range(max(1, len(upd) - a.steps), len(upd)):
     bwd = seg[first:]
     sumsq = next((r for r in bwd if "adamw_sumsq_kernel" in r["Kernel_Name"]), bwd[-1])
     t_end = (int(sumsq["Start_Timestamp"]) - t0) / 1e6
-    gathers = [(j, r) for j, r in enumerate(bwd) if re.search(r"multi_tensor_apply_kernel", r["Kernel_Name"]) and
-               re.search(r"[Cc]opy", r["Kernel_Name"]) and int(r["Start_Timestamp"]) < int(sumsq["Start_Timestamp"])]
-    print(f"## step {s}: backward {t_end:.2f} ms, {len(bwd)} kernels, {len(gathers)} bucket gathers\n")
+    launches = [(j, r) for j, r in enumerate(bwd) if re.search(r"multi_tensor_apply_kernel", r["Kernel_Name"]) and
+                re.search(r"[Cc]opy", r["Kernel_Name"]) and int(r["Start_Timestamp"]) < int(sumsq["Start_Timestamp"])]
+    # a bucket of many tensors is gathered by several back-to-back launches of the multi-tensor copy: one line per bucket
+    gathers = [(j, r) for n, (j, r) in enumerate(launches) if n == 0 or launches[n - 1][0] != j - 1]
+    print(f"## step {s}: backward {t_end:.2f} ms, {len(bwd)} kernels, {len(gathers)} buckets ({len(launches)} gather launches)\n")
     print("| bucket | gather starts at (ms) | % of backward elapsed | kernel in front of it | kernels of backward still to run |\n|---|---|---|---|---|")
     for b, (j, r) in enumerate(gathers):
         t = (int(r["Start_Timestamp"]) - t0) / 1e6
