@@ -332,7 +332,7 @@ class BucketedGradSync:
     exchanged).  Here the parameters are cut into buckets in reverse registration order for the FIRST step, and from the second step
     on in the order that step's backward actually delivered the gradients (what DDP's bucket rebuild does: registration order has
     ``downs.i`` behind all ``layers.j``, backward interleaves them, and the round-4 trace showed five of ten buckets -- half of the
-    108 MB -- becoming complete at 95 % of backward: profiles/round4_f_ddp_bucket_timeline.md); a small first bucket so that the
+    108 MB -- becoming complete at 95 % of backward: profiles/round4_f_ddp_bucket_timeline_registration_order.md); a small first bucket so that the
     exchange starts early; when the last gradient of a bucket has been accumulated
     (``register_post_accumulate_grad_hook``) the bucket's gradients are gathered into its flat buffer by ONE multi-tensor copy,
     scaled by 1 / world once, and all-reduced asynchronously (RCCL on its own stream, overlapped with the rest of backward).
