@@ -149,6 +149,14 @@ int mlagg_pooled_attn_bwd(const float *q, int q_stride, const float *kp, int kp_
 int mlagg_dwconv3x3_fwd(const float *x, int x_stride, const float *w, const float *bias, const float *res, float *y,
                         int y_stride, float *pre, int batch, int H, int W, int C, int silu, void *stream);
 size_t mlagg_dwconv3x3_bwd_workspace_floats(int batch, int H, int W, int C);
+/* Gated form: y = SiLU(conv(x) + bias) * gate -- `self.fc2(self.act(self.dwconv(x, H, W)) * v)` of ConvolutionalGLU (MambaSkip.py:559-577)
+ * with the product in the convolution's epilogue; gate (batch, H*W, C) with row stride gate_stride (the v half of fc1's output).  Backward
+ * also writes dgate = dy * SiLU(pre) (row stride dgate_stride).  Workspace as for mlagg_dwconv3x3_bwd. */
+int mlagg_dwconv3x3_gated_fwd(const float *x, int x_stride, const float *w, const float *bias, const float *gate, int gate_stride, float *y,
+                              int y_stride, float *pre, int batch, int H, int W, int C, void *stream);
+int mlagg_dwconv3x3_gated_bwd(const float *x, int x_stride, const float *w, const float *dy, int dy_stride, const float *pre,
+                              const float *gate, int gate_stride, float *dx, int dx_stride, float *dgate, int dgate_stride, float *dw,
+                              float *dbias, float *workspace, int batch, int H, int W, int C, void *stream);
 int mlagg_dwconv3x3_bwd(const float *x, int x_stride, const float *w, const float *dy, int dy_stride,
                         const float *pre, float *dx, int dx_stride, float *dw, float *dbias, float *workspace,
                         int batch, int H, int W, int C, int silu, void *stream);

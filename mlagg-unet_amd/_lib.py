@@ -52,6 +52,8 @@ SIGNATURES = {
     "mlagg_dwconv3x3_fwd": (_I, [_F, _I, _F, _F, _F, _F, _I, _F, _I, _I, _I, _I, _I, _S]),
     "mlagg_dwconv3x3_bwd_workspace_floats": (_SZ, [_I, _I, _I, _I]),
     "mlagg_dwconv3x3_bwd": (_I, [_F, _I, _F, _F, _I, _F, _F, _I, _F, _F, _F, _I, _I, _I, _I, _I, _S]),
+    "mlagg_dwconv3x3_gated_fwd": (_I, [_F, _I, _F, _F, _F, _I, _F, _I, _F, _I, _I, _I, _I, _S]),
+    "mlagg_dwconv3x3_gated_bwd": (_I, [_F, _I, _F, _F, _I, _F, _F, _I, _F, _I, _F, _I, _F, _F, _F, _I, _I, _I, _I, _S]),
     "mlagg_dwconv3d_fwd": (_I, [_F, _I, _F, _F, _F, _I, _F, _I, _I, _I, _I, _I, _I, _S]),
     "mlagg_dwconv3d_bwd_workspace_floats": (_SZ, [_I, _I, _I, _I, _I]),
     "mlagg_dwconv3d_bwd": (_I, [_F, _I, _F, _F, _I, _F, _F, _I, _F, _F, _F, _I, _I, _I, _I, _I, _I, _S]),

@@ -38,7 +38,8 @@ constexpr int HY = TY + 2, HX = TX + 2;
 template <bool SILU, bool FLIP>
 __global__ void __launch_bounds__(256)
 dwconv_tiled_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-                    const float *__restrict__ res, float *__restrict__ y, float *__restrict__ pre, Geom g)
+                    const float *__restrict__ res, float *__restrict__ y, float *__restrict__ pre, Geom g,
+                    const float *__restrict__ gate = nullptr, int gate_stride = 0)
 {
     __shared__ float4 tile[HY * HX * (CCH / 4)];
     const int tiles_x = (g.W + TX - 1) / TX;
@@ -95,6 +96,10 @@ dwconv_tiled_kernel(const float *__restrict__ x, const float *__restrict__ w, co
         if (SILU) {
             if (pre) *reinterpret_cast<float4 *>(pre + t * g.C + c) = acc;
             acc = make_float4(silu_f(acc.x), silu_f(acc.y), silu_f(acc.z), silu_f(acc.w));
+            if (gate) {                        // y = SiLU(conv(x)) * gate: the product of ConvolutionalGLU (MambaSkip.py:575) in the same pass
+                const float4 q = *reinterpret_cast<const float4 *>(gate + t * gate_stride + c);
+                acc.x *= q.x; acc.y *= q.y; acc.z *= q.z; acc.w *= q.w;
+            }
         }
         *reinterpret_cast<float4 *>(y + t * g.y_stride + c) = acc;
     }
@@ -109,7 +114,8 @@ template <bool SILU>
 __global__ void __launch_bounds__(256)
 dwconv_bwd_weight_kernel(const float *__restrict__ x, int x_stride, const float *__restrict__ dy, int dy_stride,
                          const float *__restrict__ pre, float *__restrict__ part, float *__restrict__ gbuf, int batch,
-                         int H, int W, int C)
+                         int H, int W, int C, const float *__restrict__ gate = nullptr, int gate_stride = 0,
+                         float *__restrict__ dgate = nullptr, int dgate_stride = 0)
 {
     __shared__ float red[4][10][64];
     const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
@@ -138,19 +144,22 @@ dwconv_bwd_weight_kernel(const float *__restrict__ x, int x_stride, const float 
         constexpr int UN = 4;
         int xx = x_begin;
         for (; xx + UN <= x_end; xx += UN) {
-            float rr[UN][3], gv[UN], pv[UN];
+            float rr[UN][3], gv[UN], pv[UN], qv[UN];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 col(xx + 1 + u, rr[u]);
                 const size_t t = (size_t)b * N + (size_t)y * W + xx + u;
                 gv[u] = dy[t * dy_stride + c];
                 pv[u] = SILU ? pre[t * C + c] : 0.f;
+                qv[u] = (SILU && gate) ? gate[t * gate_stride + c] : 1.f;
             }
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 float g1 = gv[u];
                 if (SILU) {
-                    g1 *= dsilu_f(pv[u]);
+                    // gated form: y = SiLU(pre) * gate, so d(gate) = dy * SiLU(pre) and the gradient entering the SiLU is dy * gate
+                    if (dgate) dgate[((size_t)b * N + (size_t)y * W + xx + u) * dgate_stride + c] = g1 * silu_f(pv[u]);
+                    g1 *= qv[u] * dsilu_f(pv[u]);
                     if (gbuf) gbuf[((size_t)b * N + (size_t)y * W + xx + u) * C + c] = g1;
                 }
                 gb += g1;
@@ -169,8 +178,10 @@ dwconv_bwd_weight_kernel(const float *__restrict__ x, int x_stride, const float 
             const size_t t = (size_t)b * N + (size_t)y * W + xx;
             float gv = dy[t * dy_stride + c];
             if (SILU) {
-                gv *= dsilu_f(pre[t * C + c]);
-                if (gbuf) gbuf[t * C + c] = gv;      // g = dy * silu'(pre), reused by the data-gradient kernel
+                const float pv1 = pre[t * C + c];
+                if (dgate) dgate[t * dgate_stride + c] = gv * silu_f(pv1);
+                gv *= (gate ? gate[t * gate_stride + c] : 1.f) * dsilu_f(pv1);
+                if (gbuf) gbuf[t * C + c] = gv;      // g = dy * (gate) * silu'(pre), reused by the data-gradient kernel
             }
             gb += gv;
 #pragma unroll
@@ -246,7 +257,7 @@ size_t dwconv_wgrad_workspace_floats(int batch, int H, int W, int C)
 
 void dwconv_wgrad_launch(const float *x, int x_stride, const float *dy, int dy_stride, const float *pre, float *dw,
                          float *dbias, float *part, int batch, int H, int W, int C, int silu, hipStream_t st,
-                         float *gbuf, bool accumulate)
+                         float *gbuf, bool accumulate, const float *gate, int gate_stride, float *dgate, int dgate_stride)
 {
     const int chunks = H;
     const dim3 grid(chunks, (C + 63) / 64, batch);
@@ -254,10 +265,10 @@ void dwconv_wgrad_launch(const float *x, int x_stride, const float *dy, int dy_s
         MLAGG_TIMED(K_DWCONV_BWD_WEIGHT, st);
         if (silu)
             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<true>, grid, dim3(256), 0, st, x, x_stride, dy, dy_stride, pre,
-                               part, gbuf, batch, H, W, C);
+                               part, gbuf, batch, H, W, C, gate, gate_stride, dgate, dgate_stride);
         else
             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<false>, grid, dim3(256), 0, st, x, x_stride, dy, dy_stride, pre,
-                               part, gbuf, batch, H, W, C);
+                               part, gbuf, batch, H, W, C, (const float *)nullptr, 0, (float *)nullptr, 0);
         if (accumulate)
             hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel<true>, dim3((C * 10 + 63) / 64), dim3(1024), 0, st, part,
                                batch * chunks, C, dw, dbias);
@@ -274,9 +285,44 @@ extern "C" size_t mlagg_dwconv3x3_bwd_workspace_floats(int batch, int H, int W, 
     return mlagg_internal::dwconv_wgrad_workspace_floats(batch, H, W, C) + (size_t)batch * H * W * C;
 }
 
+namespace {
+int dwconv_fwd(const float *x, int x_stride, const float *w, const float *bias, const float *res, float *y, int y_stride, float *pre,
+               int batch, int H, int W, int C, int silu, const float *gate, int gate_stride, void *stream);
+int dwconv_bwd(const float *x, int x_stride, const float *w, const float *dy, int dy_stride, const float *pre, float *dx, int dx_stride,
+               float *dw, float *dbias, float *workspace, int batch, int H, int W, int C, int silu, const float *gate, int gate_stride,
+               float *dgate, int dgate_stride, void *stream);
+}  // namespace
+
 extern "C" int mlagg_dwconv3x3_fwd(const float *x, int x_stride, const float *w, const float *bias, const float *res, float *y,
                                    int y_stride, float *pre, int batch, int H, int W, int C, int silu,
                                    void *stream)
+{
+    return dwconv_fwd(x, x_stride, w, bias, res, y, y_stride, pre, batch, H, W, C, silu, nullptr, 0, stream);
+}
+
+// y = SiLU(conv(x) + bias) * gate: the depthwise conv of ConvolutionalGLU with the GLU product in its epilogue (MambaSkip.py:559-577)
+extern "C" int mlagg_dwconv3x3_gated_fwd(const float *x, int x_stride, const float *w, const float *bias, const float *gate,
+                                         int gate_stride, float *y, int y_stride, float *pre, int batch, int H, int W, int C,
+                                         void *stream)
+{
+    if (!gate || !pre) return MLAGG_E_NULLPTR;
+    if (gate_stride < C || (gate_stride & 3)) return MLAGG_E_UNSUPPORTED;
+    return dwconv_fwd(x, x_stride, w, bias, nullptr, y, y_stride, pre, batch, H, W, C, 1, gate, gate_stride, stream);
+}
+
+extern "C" int mlagg_dwconv3x3_gated_bwd(const float *x, int x_stride, const float *w, const float *dy, int dy_stride, const float *pre,
+                                         const float *gate, int gate_stride, float *dx, int dx_stride, float *dgate, int dgate_stride,
+                                         float *dw, float *dbias, float *workspace, int batch, int H, int W, int C, void *stream)
+{
+    if (!gate || !dgate || !pre) return MLAGG_E_NULLPTR;
+    if (gate_stride < C || (gate_stride & 3) || dgate_stride < C) return MLAGG_E_UNSUPPORTED;
+    return dwconv_bwd(x, x_stride, w, dy, dy_stride, pre, dx, dx_stride, dw, dbias, workspace, batch, H, W, C, 1, gate, gate_stride,
+                      dgate, dgate_stride, stream);
+}
+
+namespace {
+int dwconv_fwd(const float *x, int x_stride, const float *w, const float *bias, const float *res, float *y, int y_stride, float *pre,
+               int batch, int H, int W, int C, int silu, const float *gate, int gate_stride, void *stream)
 {
     if (!x || !w || !y) return MLAGG_E_NULLPTR;
     Geom g;
@@ -287,16 +333,27 @@ extern "C" int mlagg_dwconv3x3_fwd(const float *x, int x_stride, const float *w,
     {
         MLAGG_TIMED(K_DWCONV_FWD, st);
         if (silu)
-            hipLaunchKernelGGL((dwconv_tiled_kernel<true, false>), grid, block, 0, st, x, w, bias, nullptr, y, pre, g);
+            hipLaunchKernelGGL((dwconv_tiled_kernel<true, false>), grid, block, 0, st, x, w, bias, (const float *)nullptr, y, pre, g, gate,
+                               gate_stride);
         else
-            hipLaunchKernelGGL((dwconv_tiled_kernel<false, false>), grid, block, 0, st, x, w, bias, res, y, pre, g);
+            hipLaunchKernelGGL((dwconv_tiled_kernel<false, false>), grid, block, 0, st, x, w, bias, res, y, pre, g, (const float *)nullptr, 0);
     }
     return (int)hipGetLastError();
 }
+}  // namespace
 
 extern "C" int mlagg_dwconv3x3_bwd(const float *x, int x_stride, const float *w, const float *dy, int dy_stride,
                                    const float *pre, float *dx, int dx_stride, float *dw, float *dbias,
                                    float *workspace, int batch, int H, int W, int C, int silu, void *stream)
+{
+    return dwconv_bwd(x, x_stride, w, dy, dy_stride, pre, dx, dx_stride, dw, dbias, workspace, batch, H, W, C, silu, nullptr, 0, nullptr, 0,
+                      stream);
+}
+
+namespace {
+int dwconv_bwd(const float *x, int x_stride, const float *w, const float *dy, int dy_stride, const float *pre, float *dx, int dx_stride,
+               float *dw, float *dbias, float *workspace, int batch, int H, int W, int C, int silu, const float *gate, int gate_stride,
+               float *dgate, int dgate_stride, void *stream)
 {
     if (!x || !w || !dy || !dx || !dw || !workspace || (silu && !pre)) return MLAGG_E_NULLPTR;
     Geom g;
@@ -308,14 +365,15 @@ extern "C" int mlagg_dwconv3x3_bwd(const float *x, int x_stride, const float *w,
     // gradient below is a plain 9-tap gather of g instead of 9 x (load dy, load pre, evaluate silu')
     float *gbuf = silu ? workspace + mlagg_internal::dwconv_wgrad_workspace_floats(batch, H, W, C) : nullptr;
     mlagg_internal::dwconv_wgrad_launch(x, x_stride, dy, dy_stride, pre, dw, dbias, workspace, batch, H, W, C, silu, st,
-                                        gbuf);
+                                        gbuf, false, gate, gate_stride, dgate, dgate_stride);
     {
         MLAGG_TIMED(K_DWCONV_BWD_DATA, st);
         Geom gd = g;                       // source = g (or dy when no SiLU), destination = dx
         gd.x_stride = silu ? C : dy_stride;
         gd.y_stride = dx_stride;
-        hipLaunchKernelGGL((dwconv_tiled_kernel<false, true>), grid, block, 0, st, silu ? gbuf : dy, w, nullptr, nullptr, dx,
-                           nullptr, gd);
+        hipLaunchKernelGGL((dwconv_tiled_kernel<false, true>), grid, block, 0, st, silu ? gbuf : dy, w, (const float *)nullptr,
+                           (const float *)nullptr, dx, (float *)nullptr, gd, (const float *)nullptr, 0);
     }
     return (int)hipGetLastError();
 }
+}  // namespace

@@ -90,5 +90,6 @@ size_t dwconv_wgrad_workspace_floats(int batch, int H, int W, int C);
 // dw (C, 9) and dbias (C, may be NULL) are written (accumulate: added to); part = workspace of the size above
 void dwconv_wgrad_launch(const float *x, int x_stride, const float *dy, int dy_stride, const float *pre, float *dw,
                          float *dbias, float *part, int batch, int H, int W, int C, int silu, hipStream_t st,
-                         float *gbuf = nullptr, bool accumulate = false);
+                         float *gbuf = nullptr, bool accumulate = false, const float *gate = nullptr, int gate_stride = 0,
+                         float *dgate = nullptr, int dgate_stride = 0);
 }  // namespace mlagg_internal

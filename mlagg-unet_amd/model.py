@@ -267,6 +267,8 @@ class RMSNormWeight(nn.Module):
 
 
 WEIGHT_STACKS = os.environ.get("MLAGG_WEIGHT_STACKS", "1") == "1"      # 0: torch.cat per use (the round-2 form)
+GLU_FUSED = os.environ.get("MLAGG_GLU_FUSED", "1") == "1"               # 0: the gated MLP's product as a torch multiplication
+DWC_MERGED = os.environ.get("MLAGG_DWC_MERGED", "1") == "1"             # 0: one depthwise conv per channel half of the MLLA block
 
 
 class _StackFn(torch.autograd.Function):
@@ -485,13 +487,22 @@ class MLLABlock(nn.Module):
         # act_proj and in_proj in ONE GEMM over stacked weights: (B, N, 2C) = [act | in]
         ai = ops.linear(xn, self._w_stack.get(), self._b_stack.get())
         h = C // 2
-        act_pre, xa_in, za_in = ops.split_cols(ai, (C, h, h))
-        # depthwise conv per channel half: the halves come out contiguous for the branch projections
-        # (a channel slice of a (B, N, C) row would be copied by every Linear that consumes it)
-        wa, wz = self.dwc.weight.split([h, h], dim=0)
-        ba, bz = self.dwc.bias.split([h, h], dim=0)
-        xa = ops.dwconv3x3_nlc(xa_in, wa, ba, H, W, silu=True)
-        za = ops.dwconv3x3_nlc(za_in, wz, bz, H, W, silu=True)
+        if not DWC_MERGED:                                     # round-3 form: one depthwise conv per channel half
+            act_pre, xa_in, za_in = ops.split_cols(ai, (C, h, h))
+            wa, wz = self.dwc.weight.split([h, h], dim=0)
+            ba, bz = self.dwc.bias.split([h, h], dim=0)
+            xa = ops.dwconv3x3_nlc(xa_in, wa, ba, H, W, silu=True)
+            za = ops.dwconv3x3_nlc(za_in, wz, bz, H, W, silu=True)
+            return self._after_dwc(x, xa, za, act_pre, next_norm)
+        act_pre, xz_in = ops.split_cols(ai, (C, C))
+        # ONE depthwise conv over both channel halves (round 4: one launch instead of two in forward and in each of the three backward
+        # kernels, and no split of dwc.weight / dwc.bias); the branches read their halves as column blocks of the result -- the
+        # projection kernels take a row stride -- and write their input gradients into one buffer (split_cols)
+        xz = ops.dwconv3x3_nlc(xz_in, self.dwc.weight, self.dwc.bias, H, W, silu=True)
+        xa, za = ops.split_cols(xz, (h, h))
+        return self._after_dwc(x, xa, za, act_pre, next_norm)
+
+    def _after_dwc(self, x, xa, za, act_pre, next_norm):
         gated = ops.gate(self.attn[0](xa), self.attn[1](za), act_pre)       # K7: cat(.) * SiLU(act_proj(.))
         dp = self.drop_path if isinstance(self.drop_path, DropPath) else _NO_DROP
         x, n2 = dp.residual_norm(x, self.out_proj(gated), self.norm2)
@@ -834,7 +845,10 @@ class ConvolutionalGLU(nn.Module):  # reference M:559-577
         self.fc2 = Linear(hidden, dim)
 
     def forward(self, x, H, W):
-        xg, vg = ops.split_cols(self.fc1(x), (self.hidden, self.hidden))      # the depthwise convolution's backward writes its half in place
+        xg, vg = ops.split_cols(self.fc1(x), (self.hidden, self.hidden))      # the depthwise convolution's backward writes both halves in place
+        if x.is_cuda and GLU_FUSED:
+            # SiLU(dwconv(x)) * v in the convolution's epilogue (round 4: the product and its two backward products were ATen kernels)
+            return self.fc2(ops.dwconv3x3_gated(xg, vg, self.dwconv.dwconv.weight, self.dwconv.dwconv.bias, H, W))
         g = ops.dwconv3x3_nlc(xg, self.dwconv.dwconv.weight, self.dwconv.dwconv.bias, H, W, silu=True)
         return self.fc2(g * vg)
 

@@ -575,6 +575,51 @@ class DWConv3x3Fn(torch.autograd.Function):
         return dx, dw.reshape(wshape), db, None, None, None, None, (dy if ctx.has_res else None)
 
 
+class DWConvGatedFn(torch.autograd.Function):
+    """K2, gated form: y = SiLU(dwconv3x3(x) + bias) * gate -- ConvolutionalGLU's ``self.act(self.dwconv(x, H, W)) * v`` (MambaSkip.py:
+    559-577) with the product in the convolution's epilogue; backward writes d(gate) from the weight-gradient pass (three ATen
+    multiplications per scale and step gone)."""
+
+    @staticmethod
+    def forward(ctx, x, gate, weight, bias, H, W, slot=None, gate_slot=None):
+        ctx.slots = (slot, gate_slot)
+        x, xs = _rows(x, "x")
+        gate, gs = _rows(gate, "gate")
+        B, N, C = x.shape
+        if N != H * W or tuple(gate.shape) != (B, N, C):
+            raise RuntimeError(f"dwconv3x3_gated: bad shapes x {tuple(x.shape)} gate {tuple(gate.shape)} map {H}x{W}")
+        w = _require(weight.reshape(C, 9).contiguous(), "weight")
+        y = torch.empty(B, N, C, device=x.device, dtype=torch.float32)
+        pre = torch.empty_like(y)
+        _lib.check(_lib.lib().mlagg_dwconv3x3_gated_fwd(_ptr(x), xs, _ptr(w), _ptr(bias), _ptr(gate), gs, _ptr(y), C, _ptr(pre), B, H, W, C,
+                                                        _stream()), "mlagg_dwconv3x3_gated_fwd")
+        ctx.save_for_backward(x, gate, w, pre)
+        ctx.geom = (H, W, bias is not None, weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gate, w, pre = ctx.saved_tensors
+        H, W, has_bias, wshape = ctx.geom
+        B, N, C = x.shape
+        dy, dys = _rows(dy, "dy")
+        dx, dxs = _grad_out(ctx.slots[0], (B, N, C), x.device)
+        dgate, dgs = _grad_out(ctx.slots[1], (B, N, C), x.device)
+        dw = torch.empty(C, 9, device=x.device, dtype=torch.float32)
+        db = torch.empty(C, device=x.device, dtype=torch.float32) if has_bias else None
+        lib = _lib.lib()
+        ws = torch.empty(lib.mlagg_dwconv3x3_bwd_workspace_floats(B, H, W, C), device=x.device, dtype=torch.float32)
+        _lib.check(lib.mlagg_dwconv3x3_gated_bwd(_ptr(x), x.stride(1), _ptr(w), _ptr(dy), dys, _ptr(pre), _ptr(gate), gate.stride(1),
+                                                 _ptr(dx), dxs, _ptr(dgate), dgs, _ptr(dw), _ptr(db), _ptr(ws), B, H, W, C, _stream()),
+                   "mlagg_dwconv3x3_gated_bwd")
+        return dx, dgate, dw.reshape(wshape), db, None, None, None, None
+
+
+def dwconv3x3_gated(x, gate, weight, bias, H, W):
+    """SiLU(depthwise 3x3(x) + bias) * gate on token-major maps (x, gate: column blocks of one projection output are fine)."""
+    return DWConvGatedFn.apply(x, gate, weight, bias, H, W, _claim(x), _claim(gate))
+
+
 def dwconv3x3_nlc(x, weight, bias, H, W, silu=False, res=None):
     """Depthwise 3x3 on a token-major map; `res` (same shape as the output) is added in the same pass."""
     return DWConv3x3Fn.apply(x, weight, bias, H, W, silu, _claim(x), res)
@@ -1003,12 +1048,14 @@ def _x3_ok(M, N, K):
     return K5_V2 and M >= X3_MIN_ROWS and bool(_lib.lib().mlagg_linear_x3_supported(M, N, K))
 
 
-def _x3(x2, xs, img, bias, M, N, K, epilogue=0, pre=None, pre_stride=0, out_shape=None):
-    """One launch of mlagg_linear_x3; returns y, or (pre-activation, activation) for the GELU epilogue."""
-    y = torch.empty(out_shape if out_shape is not None else (M, N), device=x2.device, dtype=torch.float32)
+def _x3(x2, xs, img, bias, M, N, K, epilogue=0, pre=None, pre_stride=0, out_shape=None, out=None, out_stride=None):
+    """One launch of mlagg_linear_x3; returns y, or (pre-activation, activation) for the GELU epilogue.  ``out`` / ``out_stride``: a
+    destination the caller owns (rows of out_stride floats: a column block of a wider buffer)."""
+    y = out if out is not None else torch.empty(out_shape if out_shape is not None else (M, N), device=x2.device, dtype=torch.float32)
+    ys = N if out_stride is None else out_stride
     act = torch.empty_like(y) if epilogue == 1 else None
     _flop("K5", 2 * M * N * K)
-    _lib.check(_lib.lib().mlagg_linear_x3(_ptr(x2), xs, _ptr(img), _ptr(bias), _ptr(y), N, _ptr(act), _ptr(pre), pre_stride, M, N, K,
+    _lib.check(_lib.lib().mlagg_linear_x3(_ptr(x2), xs, _ptr(img), _ptr(bias), _ptr(y), ys, _ptr(act), _ptr(pre), pre_stride, M, N, K,
                                           epilogue, _stream()), "mlagg_linear_x3")
     return y if epilogue != 1 else (y, act)
 
@@ -1038,8 +1085,9 @@ class LinearFn(torch.autograd.Function):
     X3_MIN_ROWS up; MLAGG_K5_V2=0 / 16-bit modes: the round-3 kernels for long token counts, the library GEMM below), dW / db on K5w."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, slot=None):
         ctx.save_for_backward(x, weight)
+        ctx.slot = slot
         ctx.has_bias = bias is not None
         ctx.cdt = cdt = compute_dtype()
         ctx.imgT = None
@@ -1084,8 +1132,13 @@ class LinearFn(torch.autograd.Function):
         lib = _lib.lib()
         if ctx.needs_input_grad[0]:
             if ctx.imgT is not None and _x3_ok(M, I, O):
-                # dx = dy . W on the image of W^T built with the forward's image (no per-step transpose of the weight)
-                dx = _x3(dy2, dys, ctx.imgT, None, M, I, O, out_shape=x.shape)
+                # dx = dy . W on the image of W^T built with the forward's image (no per-step transpose of the weight); a claimed
+                # split_cols slot: written straight into the shared gradient buffer of the pieces
+                if ctx.slot is not None:
+                    dx, dxs = _grad_out(ctx.slot, x.shape, dy.device)
+                    _x3(dy2, dys, ctx.imgT, None, M, I, O, out=dx, out_stride=dxs)
+                else:
+                    dx = _x3(dy2, dys, ctx.imgT, None, M, I, O, out_shape=x.shape)
             elif big and (M >= K5_MIN_ROWS or cdt != torch.float32) and O % 4 == 0 and I % 4 == 0:
                 w = _require(weight.contiguous(), "weight")
                 dx = torch.empty(x.shape, device=dy.device, dtype=torch.float32)
@@ -1110,11 +1163,18 @@ class LinearFn(torch.autograd.Function):
             # weight / bias gradients stay fp32 in every mode (K5w: the token sum is the long one)
             with _LeafStream(dy2, x, ok=ctx.leaf and leaf_single_use(ctx.leaf_params)):
                 dW, db = _linear_wgrad(dy2, dys, x, O, I, ctx.has_bias)
-        return dx, dW, db
+        return dx, dW, db, None
 
 
 def linear(x, weight, bias=None):
-    return LinearFn.apply(x, weight, bias)
+    # a split_cols piece as input: its gradient is written in place when both products of this layer run on K5
+    slot = None
+    if getattr(x, "_mlagg_slot", None) is not None and x.is_cuda and compute_dtype() == torch.float32:
+        O, I = weight.shape
+        M = x.numel() // I
+        if _x3_ok(M, O, I) and _x3_ok(M, I, O):
+            slot = _claim(x)
+    return LinearFn.apply(x, weight, bias, slot)
 
 
 class MlpFn(torch.autograd.Function):

@@ -52,6 +52,36 @@ def test_dwconv3x3_matches_conv2d(C, H, W, silu):
 
 
 @gpu
+@pytest.mark.parametrize("C,H,W,packed", [(256, 16, 12, True), (128, 7, 9, False), (512, 32, 32, True), (4, 1, 1, False)])
+def test_gated_dwconv3x3_matches_conv2d_times_gate(C, H, W, packed):
+    """ops.dwconv3x3_gated = SiLU(dwconv(x) + b) * v (ConvolutionalGLU, MambaSkip.py:559-577) against torch float64 on the host: output,
+    dx, d(gate), dw, db; `packed`: x and the gate are the two column halves of one projection output, gradients written into its arena."""
+    from mlagg_unet_amd import ops
+    g = torch.Generator().manual_seed(C + H)
+    B = 2
+    xv = torch.randn(B, H * W, 2 * C, generator=g)
+    w = torch.randn(C, 1, 3, 3, generator=g) * 0.3
+    b = torch.randn(C, generator=g) * 0.1
+    gy = torch.randn(B, H * W, C, generator=g)
+    xr, wr, br = xv.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    img = xr[..., :C].reshape(B, H, W, C).permute(0, 3, 1, 2)
+    ref = F.silu(F.conv2d(img, wr, br, padding=1, groups=C)).permute(0, 2, 3, 1).reshape(B, H * W, C) * xr[..., C:]
+    ref.backward(gy.double())
+    xg, wg, bg = [t.clone().to(DEV).requires_grad_(True) for t in (xv, w, b)]
+    if packed:
+        a, v = ops.split_cols(xg * 1.0, (C, C))
+    else:
+        a, v = (xg * 1.0)[..., :C].contiguous(), (xg * 1.0)[..., C:].contiguous()
+    out = ops.dwconv3x3_gated(a, v, wg, bg, H, W)
+    out.backward(gy.to(DEV))
+    _close(out, ref.float(), 1e-5, 1e-5, "y")
+    _close(xg.grad[..., :C], xr.grad[..., :C].float(), 1e-5, 1e-4, "dx")
+    _close(xg.grad[..., C:], xr.grad[..., C:].float(), 1e-5, 1e-4, "dgate")
+    _close(wg.grad, wr.grad.float(), 2e-5, 1e-4, "dw")
+    _close(bg.grad, br.grad.float(), 2e-5, 1e-4, "db")
+
+
+@gpu
 def test_dwconv3x3_adds_the_residual_in_the_same_pass():
     """res of ops.dwconv3x3_nlc (x + lepe(v), T:782): output and all four gradients equal conv + add."""
     from mlagg_unet_amd import ops
