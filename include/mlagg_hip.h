@@ -290,6 +290,13 @@ int mlagg_conv1x1_fwd(const float *x, long x_batch, const float *w, const float 
 size_t mlagg_conv1x1_wgrad_workspace_floats(int B, int O, int I, long P);
 int mlagg_conv1x1_wgrad(const float *dy, long dy_batch, const float *x, long x_batch, float *dW, float *workspace, int B, int O,
                         int I, long P, void *stream);
+/* The same two products in the operand form `dtype`: MLAGG_DTYPE_BF16X3 = the calls above; MLAGG_DTYPE_BF16 / MLAGG_DTYPE_F16 = the
+ * reference's autocast train step (nnUNetTrainer.py:848; BASELINE configs[2] / [4]), where the convolution's operands are rounded to
+ * 16 bits and the sums are fp32: operands rounded ONCE in registers (nearest even), one product; x, w, y / dW stay fp32 in memory. */
+int mlagg_conv1x1_fwd_lp(const float *x, long x_batch, const float *w, const float *bias, float *y, long y_batch, int B, int O, int I,
+                         long P, int dtype, void *stream);
+int mlagg_conv1x1_wgrad_lp(const float *dy, long dy_batch, const float *x, long x_batch, float *dW, float *workspace, int B, int O,
+                           int I, long P, int dtype, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K19: dense 3 x 3 convolutions (stride 1, zero padding 1, groups 1) on channel-major maps as nine shifted GEMMs on the 16-bit matrix
@@ -326,6 +333,11 @@ int mlagg_conv3x3x3_wgrad(const float *dy, long dy_batch, const float *x, long x
 size_t mlagg_conv3x3_wgrad_workspace_floats(int B, int O, int I, int H, int W);
 int mlagg_conv3x3_wgrad(const float *dy, long dy_batch, const float *x, long x_batch, float *dW, float *workspace, int B, int O,
                         int I, int H, int W, void *stream);
+/* The 3 x 3 products in the operand form `dtype` (see mlagg_conv1x1_fwd_lp; workspaces as above). */
+int mlagg_conv3x3_fwd_lp(const float *x, long x_batch, const float *w, int transposed, const float *bias, float *y, long y_batch,
+                         void *workspace, int B, int O, int I, int H, int W, int dtype, void *stream);
+int mlagg_conv3x3_wgrad_lp(const float *dy, long dy_batch, const float *x, long x_batch, float *dW, float *workspace, int B, int O,
+                           int I, int H, int W, int dtype, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K17: key / value reduction of the pooled attention branch, pooled (B, (H/r)(W/r), d) = r x r window mean of GELU(s), s (B, H W, d)

@@ -102,6 +102,10 @@ SIGNATURES = {
     "mlagg_conv3x3_wgrad_supported": (_I, [_I, _I, _I, _I]),
     "mlagg_conv3x3_wgrad_workspace_floats": (_SZ, [_I, _I, _I, _I, _I]),
     "mlagg_conv3x3_wgrad": (_I, [_F, ctypes.c_long, _F, ctypes.c_long, _F, _F, _I, _I, _I, _I, _I, _S]),
+    "mlagg_conv3x3_fwd_lp": (_I, [_F, ctypes.c_long, _F, _I, _F, _F, ctypes.c_long, _F, _I, _I, _I, _I, _I, _I, _S]),
+    "mlagg_conv3x3_wgrad_lp": (_I, [_F, ctypes.c_long, _F, ctypes.c_long, _F, _F, _I, _I, _I, _I, _I, _I, _S]),
+    "mlagg_conv1x1_fwd_lp": (_I, [_F, ctypes.c_long, _F, _F, _F, ctypes.c_long, _I, _I, _I, ctypes.c_long, _I, _S]),
+    "mlagg_conv1x1_wgrad_lp": (_I, [_F, ctypes.c_long, _F, ctypes.c_long, _F, _F, _I, _I, _I, ctypes.c_long, _I, _S]),
     "mlagg_conv1x1_supported": (_I, [_I, _I, ctypes.c_long]),
     "mlagg_conv1x1_fwd": (_I, [_F, ctypes.c_long, _F, _F, _F, ctypes.c_long, _I, _I, _I, ctypes.c_long, _S]),
     "mlagg_conv1x1_wgrad_workspace_floats": (_SZ, [_I, _I, _I, ctypes.c_long]),

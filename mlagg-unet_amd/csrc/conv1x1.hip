@@ -21,6 +21,7 @@
 #include "mlagg_hip.h"
 #include "prof.h"
 #include "bf16x3.h"
+#include "opmode.h"
 #include "internal.h"
 
 namespace {
@@ -37,16 +38,10 @@ struct C1Geom {
     long x_batch, y_batch;          // floats between consecutive samples
 };
 
-__device__ __forceinline__ void split8(const float (&f)[8], uint4 (&q)[3])
-{
-    bf16x3::split3(f[0], f[1], q[0].x, q[1].x, q[2].x);
-    bf16x3::split3(f[2], f[3], q[0].y, q[1].y, q[2].y);
-    bf16x3::split3(f[4], f[5], q[0].z, q[1].z, q[2].z);
-    bf16x3::split3(f[6], f[7], q[0].w, q[1].w, q[2].w);
-}
+using opmode::split8;
 
-// y[b][o][p] (+ bias[o]); grid (pixel groups of 32 TP, channel groups of 32 TO, batch); I % 16 == 0
-template <int TO, int TP>
+// y[b][o][p] (+ bias[o]); grid (pixel groups of 32 TP, channel groups of 32 TO, batch); I % 16 == 0.  DT: operand form (opmode.h)
+template <int TO, int TP, int DT>
 __global__ void __launch_bounds__(64)
 conv1x1_fwd_kernel(const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
                    C1Geom g)
@@ -83,15 +78,15 @@ conv1x1_fwd_kernel(const float *__restrict__ X, const float *__restrict__ W, con
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             const float f[8] = {Xv[0].v[j], Xv[1].v[j], Xv[2].v[j], Xv[3].v[j], Xv[4].v[j], Xv[5].v[j], Xv[6].v[j], Xv[7].v[j]};
-            split8(f, bq[j]);
+            split8<DT>(f, bq[j]);
         }
         uint4 aq[TO][3];
 #pragma unroll
         for (int a = 0; a < TO; ++a) {
             const float f[8] = {A[a][0].x, A[a][0].y, A[a][0].z, A[a][0].w, A[a][1].x, A[a][1].y, A[a][1].z, A[a][1].w};
-            split8(f, aq[a]);
+            split8<DT>(f, aq[a]);
         }
-        bf16x3::mfma_tiles<TO, TP>(aq, bq, acc);
+        opmode::mfma_tiles<DT, TO, TP>(aq, bq, acc);
     };
     fetch(wa[0], xv[0], 0);
     int blk = 0;
@@ -133,7 +128,7 @@ struct W1Geom {
 };
 
 // part[(b * nslabs + s)][O * I] = sum over the slab's pixels of dy[b][o][p] x[b][i][p]; grid (B * nslabs, o groups, i groups)
-template <int TO, int TI>
+template <int TO, int TI, int DT>
 __global__ void __launch_bounds__(64)
 conv1x1_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ part, W1Geom g)
 {
@@ -173,15 +168,15 @@ conv1x1_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ X, 
 #pragma unroll
         for (int j = 0; j < TI; ++j) {
             const float f[8] = {Bv[j][0].x, Bv[j][0].y, Bv[j][0].z, Bv[j][0].w, Bv[j][1].x, Bv[j][1].y, Bv[j][1].z, Bv[j][1].w};
-            split8(f, bq[j]);
+            split8<DT>(f, bq[j]);
         }
         uint4 aq[TO][3];
 #pragma unroll
         for (int a = 0; a < TO; ++a) {
             const float f[8] = {A[a][0].x, A[a][0].y, A[a][0].z, A[a][0].w, A[a][1].x, A[a][1].y, A[a][1].z, A[a][1].w};
-            split8(f, aq[a]);
+            split8<DT>(f, aq[a]);
         }
-        bf16x3::mfma_tiles<TO, TI>(aq, bq, acc);
+        opmode::mfma_tiles<DT, TO, TI>(aq, bq, acc);
     };
     if (nblk > 0) {
         fetch(av[0], bv[0], 0);
@@ -240,17 +235,27 @@ void pick_fwd_tile(int B, int O, int I, int P, int &to, int &tp)
 }
 
 template <int TO, int TP>
-void launch_fwd(const float *x, const float *w, const float *bias, float *y, const C1Geom &g, hipStream_t st)
+void launch_fwd(const float *x, const float *w, const float *bias, float *y, const C1Geom &g, int dt, hipStream_t st)
 {
     const dim3 grid((g.P + 32 * TP - 1) / (32 * TP), (g.O + 32 * TO - 1) / (32 * TO), g.B);
-    hipLaunchKernelGGL((conv1x1_fwd_kernel<TO, TP>), grid, dim3(64), 0, st, x, w, bias, y, g);
+    if (dt == MLAGG_DTYPE_BF16)
+        hipLaunchKernelGGL((conv1x1_fwd_kernel<TO, TP, MLAGG_DTYPE_BF16>), grid, dim3(64), 0, st, x, w, bias, y, g);
+    else if (dt == MLAGG_DTYPE_F16)
+        hipLaunchKernelGGL((conv1x1_fwd_kernel<TO, TP, MLAGG_DTYPE_F16>), grid, dim3(64), 0, st, x, w, bias, y, g);
+    else
+        hipLaunchKernelGGL((conv1x1_fwd_kernel<TO, TP, MLAGG_DTYPE_BF16X3>), grid, dim3(64), 0, st, x, w, bias, y, g);
 }
 
 template <int TO, int TI>
-void launch_wgrad(const float *dy, const float *x, float *part, const W1Geom &g, hipStream_t st)
+void launch_wgrad(const float *dy, const float *x, float *part, const W1Geom &g, int dt, hipStream_t st)
 {
     const dim3 grid(g.B * g.nslabs, (g.O + 32 * TO - 1) / (32 * TO), (g.I + 32 * TI - 1) / (32 * TI));
-    hipLaunchKernelGGL((conv1x1_wgrad_kernel<TO, TI>), grid, dim3(64), 0, st, dy, x, part, g);
+    if (dt == MLAGG_DTYPE_BF16)
+        hipLaunchKernelGGL((conv1x1_wgrad_kernel<TO, TI, MLAGG_DTYPE_BF16>), grid, dim3(64), 0, st, dy, x, part, g);
+    else if (dt == MLAGG_DTYPE_F16)
+        hipLaunchKernelGGL((conv1x1_wgrad_kernel<TO, TI, MLAGG_DTYPE_F16>), grid, dim3(64), 0, st, dy, x, part, g);
+    else
+        hipLaunchKernelGGL((conv1x1_wgrad_kernel<TO, TI, MLAGG_DTYPE_BF16X3>), grid, dim3(64), 0, st, dy, x, part, g);
 }
 
 }  // namespace
@@ -260,10 +265,13 @@ extern "C" int mlagg_conv1x1_supported(int O, int I, long P)
     return O > 0 && I > 0 && (I % 16) == 0 && P >= 96 && (P % 16) == 0 && P < (1L << 30);
 }
 
-extern "C" int mlagg_conv1x1_fwd(const float *x, long x_batch, const float *w, const float *bias, float *y, long y_batch, int B,
-                                 int O, int I, long P, void *stream)
+// y = w . x in the operand form `dtype` (MLAGG_DTYPE_BF16X3: the fp32 layers; MLAGG_DTYPE_BF16 / _F16: the 16-bit modes -- operands rounded
+// once, one product, fp32 sums; x, w, y stay fp32 in memory)
+extern "C" int mlagg_conv1x1_fwd_lp(const float *x, long x_batch, const float *w, const float *bias, float *y, long y_batch, int B,
+                                    int O, int I, long P, int dtype, void *stream)
 {
     if (!x || !w || !y) return MLAGG_E_NULLPTR;
+    if (!opmode::valid(dtype)) return MLAGG_E_UNSUPPORTED;
     if (B <= 0 || B > 65535 || !mlagg_conv1x1_supported(O, I, P)) return MLAGG_E_UNSUPPORTED;
     if (x_batch < (long)I * P || y_batch < (long)O * P || (reinterpret_cast<uintptr_t>(w) & 15)) return MLAGG_E_UNSUPPORTED;
     C1Geom g{B, O, I, (int)P, x_batch, y_batch};
@@ -275,17 +283,23 @@ extern "C" int mlagg_conv1x1_fwd(const float *x, long x_batch, const float *w, c
     int to = O <= 32 ? 1 : (O <= 64 ? 2 : 3), tp = O <= 64 ? 3 : 2;
     pick_fwd_tile(B, O, I, (int)P, to, tp);
     switch (to * 4 + tp) {
-    case 1 * 4 + 1: launch_fwd<1, 1>(x, w, bias, y, g, st); break;
-    case 1 * 4 + 2: launch_fwd<1, 2>(x, w, bias, y, g, st); break;
-    case 1 * 4 + 3: launch_fwd<1, 3>(x, w, bias, y, g, st); break;
-    case 2 * 4 + 1: launch_fwd<2, 1>(x, w, bias, y, g, st); break;
-    case 2 * 4 + 2: launch_fwd<2, 2>(x, w, bias, y, g, st); break;
-    case 2 * 4 + 3: launch_fwd<2, 3>(x, w, bias, y, g, st); break;
-    case 3 * 4 + 1: launch_fwd<3, 1>(x, w, bias, y, g, st); break;
-    case 3 * 4 + 2: launch_fwd<3, 2>(x, w, bias, y, g, st); break;
-    default: launch_fwd<3, 3>(x, w, bias, y, g, st); break;
+    case 1 * 4 + 1: launch_fwd<1, 1>(x, w, bias, y, g, dtype, st); break;
+    case 1 * 4 + 2: launch_fwd<1, 2>(x, w, bias, y, g, dtype, st); break;
+    case 1 * 4 + 3: launch_fwd<1, 3>(x, w, bias, y, g, dtype, st); break;
+    case 2 * 4 + 1: launch_fwd<2, 1>(x, w, bias, y, g, dtype, st); break;
+    case 2 * 4 + 2: launch_fwd<2, 2>(x, w, bias, y, g, dtype, st); break;
+    case 2 * 4 + 3: launch_fwd<2, 3>(x, w, bias, y, g, dtype, st); break;
+    case 3 * 4 + 1: launch_fwd<3, 1>(x, w, bias, y, g, dtype, st); break;
+    case 3 * 4 + 2: launch_fwd<3, 2>(x, w, bias, y, g, dtype, st); break;
+    default: launch_fwd<3, 3>(x, w, bias, y, g, dtype, st); break;
     }
     return (int)hipGetLastError();
+}
+
+extern "C" int mlagg_conv1x1_fwd(const float *x, long x_batch, const float *w, const float *bias, float *y, long y_batch, int B,
+                                 int O, int I, long P, void *stream)
+{
+    return mlagg_conv1x1_fwd_lp(x, x_batch, w, bias, y, y_batch, B, O, I, P, MLAGG_DTYPE_BF16X3, stream);
 }
 
 extern "C" size_t mlagg_conv1x1_wgrad_workspace_floats(int B, int O, int I, long P)
@@ -295,10 +309,11 @@ extern "C" size_t mlagg_conv1x1_wgrad_workspace_floats(int B, int O, int I, long
     return (size_t)B * g.nslabs * O * I;
 }
 
-extern "C" int mlagg_conv1x1_wgrad(const float *dy, long dy_batch, const float *x, long x_batch, float *dW, float *workspace, int B,
-                                   int O, int I, long P, void *stream)
+extern "C" int mlagg_conv1x1_wgrad_lp(const float *dy, long dy_batch, const float *x, long x_batch, float *dW, float *workspace, int B,
+                                      int O, int I, long P, int dtype, void *stream)
 {
     if (!dy || !x || !dW || !workspace) return MLAGG_E_NULLPTR;
+    if (!opmode::valid(dtype)) return MLAGG_E_UNSUPPORTED;
     if (P >= (1L << 30)) return MLAGG_E_UNSUPPORTED;
     W1Geom g;
     if (int rc = make_wgeom(g, B, O, I, (int)P, dy_batch, x_batch)) return rc;
@@ -307,18 +322,24 @@ extern "C" int mlagg_conv1x1_wgrad(const float *dy, long dy_batch, const float *
     MLAGG_TIMED(K_CONV1X1, st);
     const int to = O > 64 ? 3 : (O + 31) / 32, ti = I > 64 ? 3 : (I + 31) / 32;
     switch (to * 4 + ti) {
-    case 1 * 4 + 1: launch_wgrad<1, 1>(dy, x, workspace, g, st); break;
-    case 1 * 4 + 2: launch_wgrad<1, 2>(dy, x, workspace, g, st); break;
-    case 1 * 4 + 3: launch_wgrad<1, 3>(dy, x, workspace, g, st); break;
-    case 2 * 4 + 1: launch_wgrad<2, 1>(dy, x, workspace, g, st); break;
-    case 2 * 4 + 2: launch_wgrad<2, 2>(dy, x, workspace, g, st); break;
-    case 2 * 4 + 3: launch_wgrad<2, 3>(dy, x, workspace, g, st); break;
-    case 3 * 4 + 1: launch_wgrad<3, 1>(dy, x, workspace, g, st); break;
-    case 3 * 4 + 2: launch_wgrad<3, 2>(dy, x, workspace, g, st); break;
-    default: launch_wgrad<3, 3>(dy, x, workspace, g, st); break;
+    case 1 * 4 + 1: launch_wgrad<1, 1>(dy, x, workspace, g, dtype, st); break;
+    case 1 * 4 + 2: launch_wgrad<1, 2>(dy, x, workspace, g, dtype, st); break;
+    case 1 * 4 + 3: launch_wgrad<1, 3>(dy, x, workspace, g, dtype, st); break;
+    case 2 * 4 + 1: launch_wgrad<2, 1>(dy, x, workspace, g, dtype, st); break;
+    case 2 * 4 + 2: launch_wgrad<2, 2>(dy, x, workspace, g, dtype, st); break;
+    case 2 * 4 + 3: launch_wgrad<2, 3>(dy, x, workspace, g, dtype, st); break;
+    case 3 * 4 + 1: launch_wgrad<3, 1>(dy, x, workspace, g, dtype, st); break;
+    case 3 * 4 + 2: launch_wgrad<3, 2>(dy, x, workspace, g, dtype, st); break;
+    default: launch_wgrad<3, 3>(dy, x, workspace, g, dtype, st); break;
     }
     const int n = O * I;
     hipLaunchKernelGGL(mlagg_internal::column_sum_kernel<false>, dim3((n + 63) / 64), dim3(1024), 0, st, workspace, B * g.nslabs, n, n,
                        dW);
     return (int)hipGetLastError();
+}
+
+extern "C" int mlagg_conv1x1_wgrad(const float *dy, long dy_batch, const float *x, long x_batch, float *dW, float *workspace, int B,
+                                   int O, int I, long P, void *stream)
+{
+    return mlagg_conv1x1_wgrad_lp(dy, dy_batch, x, x_batch, dW, workspace, B, O, I, P, MLAGG_DTYPE_BF16X3, stream);
 }

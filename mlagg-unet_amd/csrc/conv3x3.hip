@@ -25,6 +25,7 @@
 #include "mlagg_hip.h"
 #include "prof.h"
 #include "bf16x3.h"
+#include "opmode.h"
 
 namespace {
 
@@ -43,6 +44,8 @@ struct C3Geom {
 
 // wimg[q][t][o][i] (bf16 piece q of the weight of tap t); flip: the data gradient's weight, w'[i][o][t] = w[o][i][8 - t] with the
 // roles of o and i exchanged (O, I are the OUTPUT / CONTRACTION extents of the product the image serves)
+// (DT: operand form, opmode.h -- one image per piece: three for the fp32 layers, one rounded image in the 16-bit modes)
+template <int DT>
 __global__ void __launch_bounds__(256)
 conv3x3_weight_image_kernel(const float *__restrict__ w, unsigned short *__restrict__ img, int O, int I, int ntaps, int flip)
 {
@@ -51,11 +54,10 @@ conv3x3_weight_image_kernel(const float *__restrict__ w, unsigned short *__restr
     if (idx >= n) return;
     const int i = idx % I, o = (idx / I) % O, t = idx / (I * O);
     const float v = flip ? w[((size_t)i * O + o) * ntaps + (ntaps - 1 - t)] : w[((size_t)o * I + i) * ntaps + t];
-    unsigned hi, mid, lo;
-    bf16x3::split3(v, 0.f, hi, mid, lo);
-    img[idx] = (unsigned short)(hi & 0xffff);
-    img[n + idx] = (unsigned short)(mid & 0xffff);
-    img[2 * n + idx] = (unsigned short)(lo & 0xffff);
+    unsigned short p[3];
+    opmode::pieces<DT>(v, p);
+#pragma unroll
+    for (int q = 0; q < opmode::Form<DT>::NQ; ++q) img[(size_t)q * n + idx] = p[q];
 }
 
 #ifndef K19_INTERLEAVE
@@ -63,7 +65,7 @@ conv3x3_weight_image_kernel(const float *__restrict__ w, unsigned short *__restr
 #endif
 constexpr int WAVES = 4;            // pixel groups per workgroup: they share the weight stage in LDS
 
-template <int TO, int TP, int NR>
+template <int TO, int TP, int NR, int DT>
 __global__ void __launch_bounds__(64 * WAVES, 2)
 conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Wimg, const float *__restrict__ bias,
                float *__restrict__ Y, C3Geom g)
@@ -74,7 +76,8 @@ conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ W
     // 9 KB per tap, more than the x rows, and the first form of this kernel was bound by L1 bandwidth (its rate followed bytes per
     // MFMA across tile shapes: tools/bench_conv3x3.py with MLAGG_K19_TILE).
     constexpr int ROWS = 32 * TO;
-    constexpr int STAGE = 3 * 3 * ROWS * 2;                 // uint4 per stage
+    constexpr int NQ = opmode::Form<DT>::NQ, NT = opmode::Form<DT>::NT;       // pieces per operand, partial products (opmode.h)
+    constexpr int STAGE = 3 * NQ * ROWS * 2;                // uint4 per stage
     constexpr int WL = (STAGE + 64 * WAVES - 1) / (64 * WAVES);
     __shared__ u32x4 sW[2][STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, kh = lane >> 5;
@@ -113,15 +116,15 @@ conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ W
         offl[r] = 4u * (unsigned)(8 * kh * g.P + min(max(q - 1, 0), g.P - 1));
         offr[r] = 4u * (unsigned)(8 * kh * g.P + min(max(q + TP, 0), g.P - 1));
     }
-    const size_t img = (size_t)(3 * NR) * g.O * g.I;                                  // elements per weight image
+    const size_t img = (size_t)(3 * NR) * g.O * g.I;                                  // elements per weight image (piece)
     const size_t tstride = (size_t)g.O * g.I;
     const int nblk = g.I / 16, nstage = NR * nblk;
-    // weight stage loader: element e = ((tt * 3 + q) * ROWS + row) * 2 + h  <-  Wimg[q][3 srow + tt][o0 + row][16 blk + 8 h ..]
+    // weight stage loader: element e = ((tt * NQ + q) * ROWS + row) * 2 + h  <-  Wimg[q][3 srow + tt][o0 + row][16 blk + 8 h ..]
     unsigned wsrc[WL];                                                               // bytes within a (blk, kernel row) slice
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
         const int e = min(tid + 64 * WAVES * i, STAGE - 1);
-        const int h = e & 1, row = (e >> 1) % ROWS, q = ((e >> 1) / ROWS) % 3, tt = (e >> 1) / (3 * ROWS);
+        const int h = e & 1, row = (e >> 1) % ROWS, q = ((e >> 1) / ROWS) % NQ, tt = (e >> 1) / (NQ * ROWS);
         wsrc[i] = 2u * (unsigned)(q * img + tt * tstride + (size_t)min(o0 + row, g.O - 1) * g.I + 8 * h);
     }
     u32x4 wreg[WL];
@@ -165,16 +168,13 @@ conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ W
                 const float v = m == 0 ? L[r] : (m == TP + 1 ? R[r] : C[r].v[(m >= 1 && m <= TP) ? m - 1 : 0]);
                 f[r] = ok ? v : 0.f;
             }
-            bf16x3::split3(f[0], f[1], src[m][0].x, src[m][1].x, src[m][2].x);
-            bf16x3::split3(f[2], f[3], src[m][0].y, src[m][1].y, src[m][2].y);
-            bf16x3::split3(f[4], f[5], src[m][0].z, src[m][1].z, src[m][2].z);
-            bf16x3::split3(f[6], f[7], src[m][0].w, src[m][1].w, src[m][2].w);
+            opmode::split8<DT>(f, src[m]);
         }
 #if K19_INTERLEAVE
         // ask the scheduler for MFMA / VALU alternation over the stage: the split of the later source elements and the LDS reads of
         // the next tap's weights then issue in the matrix instructions' shadows instead of in a phase of their own
 #pragma unroll
-        for (int i = 0; i < 18 * TO * TP; ++i) {
+        for (int i = 0; i < 3 * NT * TO * TP; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
             __builtin_amdgcn_sched_group_barrier(0x002, K19_INTERLEAVE, 0);   // VALU
         }
@@ -185,17 +185,17 @@ conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ W
 #pragma unroll
             for (int a = 0; a < TO; ++a)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const u32x4 v = wst[(tt * 3 + q) * ROWS * 2 + (32 * a + col) * 2 + kh];
+                for (int q = 0; q < NQ; ++q) {
+                    const u32x4 v = wst[(tt * NQ + q) * ROWS * 2 + (32 * a + col) * 2 + kh];
                     aq[a][q] = make_uint4(v.x, v.y, v.z, v.w);
                 }
 #pragma unroll
-            for (int term = 0; term < 6; ++term)
+            for (int term = 0; term < NT; ++term)
 #pragma unroll
                 for (int a = 0; a < TO; ++a)
 #pragma unroll
                     for (int j = 0; j < TP; ++j)
-                        acc[a][j] = bf16x3::mfma(aq[a][bf16x3::kTermA[term]], src[j + tt][bf16x3::kTermB[term]], acc[a][j]);
+                        acc[a][j] = opmode::mfma<DT>(aq[a][opmode::Form<DT>::termA(term)], src[j + tt][opmode::Form<DT>::termB(term)], acc[a][j]);
         }
     };
     // one stage: the three taps of a kernel row on weight buffer s & 1 while the next stage's weights travel global -> registers
@@ -266,6 +266,7 @@ struct W3Geom {
     long x_last;                    // last float offset from x at which an 8-float load stays inside the operand
 };
 
+template <int DT>
 __global__ void __launch_bounds__(64)
 conv3x3_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ part, W3Geom g)
 {
@@ -309,10 +310,7 @@ conv3x3_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ X, 
     auto consume = [&](const float4 (&A)[2], const float4 (&Bv)[2], const float (&E)[2], int blk, int ky) __attribute__((always_inline)) {
         if (ky == 0) {
             const float f[8] = {A[0].x, A[0].y, A[0].z, A[0].w, A[1].x, A[1].y, A[1].z, A[1].w};
-            bf16x3::split3(f[0], f[1], aq[0][0].x, aq[0][1].x, aq[0][2].x);
-            bf16x3::split3(f[2], f[3], aq[0][0].y, aq[0][1].y, aq[0][2].y);
-            bf16x3::split3(f[4], f[5], aq[0][0].z, aq[0][1].z, aq[0][2].z);
-            bf16x3::split3(f[6], f[7], aq[0][0].w, aq[0][1].w, aq[0][2].w);
+            opmode::split8<DT>(f, aq[0]);
         }
         // the lane's 8-pixel run lies in one image row (W % 8 == 0); its two halves of a block may lie in different rows
         const int p = pb + 16 * blk + 8 * kh;
@@ -324,24 +322,25 @@ conv3x3_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ X, 
         float4 c0 = Bv[0], c1 = Bv[1];
         if (!rok) c0 = c1 = make_float4(0.f, 0.f, 0.f, 0.f);
         unsigned d[3][5];                                        // [piece][pair]: (p-1, p), (p+1, p+2), (p+3, p+4), (p+5, p+6), (p+7, p+8)
-        bf16x3::split3(left, c0.x, d[0][0], d[1][0], d[2][0]);
-        bf16x3::split3(c0.y, c0.z, d[0][1], d[1][1], d[2][1]);
-        bf16x3::split3(c0.w, c1.x, d[0][2], d[1][2], d[2][2]);
-        bf16x3::split3(c1.y, c1.z, d[0][3], d[1][3], d[2][3]);
-        bf16x3::split3(c1.w, right, d[0][4], d[1][4], d[2][4]);
+        opmode::split<DT>(left, c0.x, d[0][0], d[1][0], d[2][0]);
+        opmode::split<DT>(c0.y, c0.z, d[0][1], d[1][1], d[2][1]);
+        opmode::split<DT>(c0.w, c1.x, d[0][2], d[1][2], d[2][2]);
+        opmode::split<DT>(c1.y, c1.z, d[0][3], d[1][3], d[2][3]);
+        opmode::split<DT>(c1.w, right, d[0][4], d[1][4], d[2][4]);
         uint4 bq[3][3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < opmode::Form<DT>::NQ; ++q) {
             bq[0][q] = make_uint4(d[q][0], d[q][1], d[q][2], d[q][3]);                                          // dx = -1
             bq[2][q] = make_uint4(d[q][1], d[q][2], d[q][3], d[q][4]);                                          // dx = +1
             bq[1][q] = make_uint4(__builtin_amdgcn_alignbit(d[q][1], d[q][0], 16), __builtin_amdgcn_alignbit(d[q][2], d[q][1], 16),
                                   __builtin_amdgcn_alignbit(d[q][3], d[q][2], 16), __builtin_amdgcn_alignbit(d[q][4], d[q][3], 16));
         }
 #pragma unroll
-        for (int term = 0; term < 6; ++term)
+        for (int term = 0; term < opmode::Form<DT>::NT; ++term)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx)
-                acc[0][3 * ky + kx] = bf16x3::mfma(aq[0][bf16x3::kTermA[term]], bq[kx][bf16x3::kTermB[term]], acc[0][3 * ky + kx]);
+                acc[0][3 * ky + kx] = opmode::mfma<DT>(aq[0][opmode::Form<DT>::termA(term)], bq[kx][opmode::Form<DT>::termB(term)],
+                                                       acc[0][3 * ky + kx]);
     };
     if (nblk > 0) {
         fetch(av[0], bv[0], be[0], 0, 0);
@@ -376,22 +375,213 @@ conv3x3_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ X, 
         }
 }
 
-// dW[(o, i, t)] = sum over partial blocks of part[s][t][o][i], fixed order
-__global__ void __launch_bounds__(256)
+// dW[(o, i, t)] = sum over partial blocks of part[s][t][o][i], fixed order.  Workgroup = 64 elements x 16 groups of partial blocks
+// (coalesced 256-byte reads, 16 partial blocks in flight per element, LDS combine): one thread per element walked its hundreds of
+// partial blocks serially and cost 40-130 us per layer (profiles/round4_h_*).
+__global__ void __launch_bounds__(1024)
 conv3x3_wgrad_reduce_kernel(const float *__restrict__ part, int nparts, int O, int I, int ntaps, float *__restrict__ dW)
 {
+    __shared__ float red[16][65];
     const int n = ntaps * O * I;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;        // (t, o, i): the partial layout, coalesced reads
-    if (idx >= n) return;
+    const int cx = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + cx;                         // (t, o, i): the partial layout
     float s0 = 0.f, s1 = 0.f;
-    int sidx = 0;
-    for (; sidx + 1 < nparts; sidx += 2) {
-        s0 += part[(size_t)sidx * n + idx];
-        s1 += part[(size_t)(sidx + 1) * n + idx];
+    if (idx < n) {
+        int r = rg;
+        for (; r + 16 < nparts; r += 32) {
+            s0 += part[(size_t)r * n + idx];
+            s1 += part[(size_t)(r + 16) * n + idx];
+        }
+        if (r < nparts) s0 += part[(size_t)r * n + idx];
     }
-    if (sidx < nparts) s0 += part[(size_t)sidx * n + idx];
-    const int i = idx % I, o = (idx / I) % O, t = idx / (I * O);
-    dW[((size_t)o * I + i) * ntaps + t] = s0 + s1;
+    red[rg][cx] = s0 + s1;
+    __syncthreads();
+    if (rg == 0 && idx < n) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][cx];
+        const int i = idx % I, o = (idx / I) % O, t = idx / (I * O);
+        dW[((size_t)o * I + i) * ntaps + t] = v;
+    }
+}
+
+// ---- weight gradient, second form (round 4): 16 x 16 x 32 matrix instructions, a wave owns 16 TO output x 16 TI input channels x the
+// THREE taps of one kernel row ky (TO = TI = 3: 48 x 48 channels -- every dense 3 x 3 layer of the network has 48 k channels -- in 108
+// accumulator registers, two waves per SIMD) and a slab of pixels of one sample; the three kernel rows of a slab are three
+// single-wave workgroups that the grid mapping puts on ONE XCD next to each other in its dispatch order (they read the same dy rows
+// and neighbouring x rows: one L2).  Per 32-pixel block a lane reads 8 consecutive pixels of its dy rows and of its x rows in image
+// row y + ky - 1 plus their two neighbours, splits them once, and the dx = -1 / 0 / +1 operands are dword windows of the same five
+// pairs (see the first form).  The first form (32 x 32 tiles, nine taps per wave: 144 accumulators + 167 registers = one wave per
+// SIMD with a one-step prefetch) ran at 24 % of the matrix rate on the step's shapes, bound by memory latency, and filled 56 % of its
+// tiles on 48 x 48 channels.
+struct W16Geom {
+    int B, O, I, H, W, P;
+    long dy_batch, x_batch;
+    int slab, nslabs, nbs;          // pixels per slab (multiple of 32), slabs per sample, B * nslabs
+    long x_last;                    // last float offset from x at which an 8-float load stays inside the operand
+    int q32, r32;                   // 32 = q32 * W + r32
+};
+
+template <int TO, int TI, int DT>
+__global__ void __launch_bounds__(64)
+conv3x3_wgrad16_kernel(const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ part, W16Geom g)
+{
+    using opmode::f32x4;
+    constexpr int NQ = opmode::Form<DT>::NQ, NT = opmode::Form<DT>::NT;
+    const int lane = threadIdx.x, r16 = lane & 15, kg = lane >> 4;
+    // workgroup id -> (XCD, its dispatch slot): slots 3 n .. 3 n + 2 of an XCD are the kernel rows of slab 8 n + xcd
+    const int id = blockIdx.x, slot = id >> 3;
+    const int ky = slot % 3, bs = (slot / 3) * 8 + (id & 7);
+    if (bs >= g.nbs) return;
+    const int b = bs / g.nslabs, s = bs % g.nslabs;
+    const int o0 = blockIdx.y * (16 * TO), i0 = blockIdx.z * (16 * TI);
+    f32x4 acc[TO][TI][3];
+#pragma unroll
+    for (int a = 0; a < TO; ++a)
+#pragma unroll
+        for (int j = 0; j < TI; ++j)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc[a][j][kx] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int pb = s * g.slab, pe = min(pb + g.slab, g.P);
+    const int nblk = (pe - pb + 31) / 32;
+    const float *ap[TO];
+    long xrow[TI];
+#pragma unroll
+    for (int a = 0; a < TO; ++a) ap[a] = dY + (size_t)b * g.dy_batch + (size_t)min(o0 + 16 * a + r16, g.O - 1) * g.P;
+#pragma unroll
+    for (int j = 0; j < TI; ++j) xrow[j] = (long)b * g.x_batch + (long)min(i0 + 16 * j + r16, g.I - 1) * g.P + (long)(ky - 1) * g.W;
+    struct Raw {
+        float4 a[TO][2], b[TI][2];
+        float e[TI][2];
+    };
+    // every load is unconditional: clamped into the operand; a displaced address only occurs where the value is masked (tail pixels
+    // of the slab, a source row outside the image, the neighbours across an image edge)
+    auto fetch = [&](Raw &R, int blk) __attribute__((always_inline)) {
+        const int p = min(pb + 32 * min(blk, nblk - 1) + 8 * kg, g.P - 8);
+#pragma unroll
+        for (int a = 0; a < TO; ++a) {
+            R.a[a][0] = *reinterpret_cast<const float4 *>(ap[a] + p);
+            R.a[a][1] = *reinterpret_cast<const float4 *>(ap[a] + p + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < TI; ++j) {
+            const long want = xrow[j] + p;
+            const long at = min(max(want, 0L), g.x_last);
+            R.b[j][0] = *reinterpret_cast<const float4 *>(X + at);
+            R.b[j][1] = *reinterpret_cast<const float4 *>(X + at + 4);
+            R.e[j][0] = X[min(max(want - 1, 0L), g.x_last + 7)];
+            R.e[j][1] = X[min(max(want + 8, 0L), g.x_last + 7)];
+        }
+    };
+    // position of the lane's run in block 0; advanced by 32 pixels per block without divisions
+    int x0 = (pb + 8 * kg) % g.W, y = (pb + 8 * kg) / g.W, pl = pb + 8 * kg;
+    auto consume = [&](const Raw &R) __attribute__((always_inline)) {
+        const bool live = pl < pe;                               // tail of the slab: the dy values are dropped
+        const bool rok = (unsigned)(y + ky - 1) < (unsigned)g.H;
+        if (__any(live && rok)) {
+            uint4 aq[TO][3];
+#pragma unroll
+            for (int a = 0; a < TO; ++a) {
+                float f[8] = {R.a[a][0].x, R.a[a][0].y, R.a[a][0].z, R.a[a][0].w, R.a[a][1].x, R.a[a][1].y, R.a[a][1].z, R.a[a][1].w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) f[k] = live ? f[k] : 0.f;
+                opmode::split8<DT>(f, aq[a]);
+            }
+#pragma unroll
+            for (int j = 0; j < TI; ++j) {
+                float4 c0 = R.b[j][0], c1 = R.b[j][1];
+                if (!rok) c0 = c1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float left = (!rok || x0 == 0) ? 0.f : R.e[j][0];
+                const float right = (!rok || x0 + 8 == g.W) ? 0.f : R.e[j][1];
+                unsigned d[3][5];                                // [piece][pair]: (p-1, p), (p+1, p+2), (p+3, p+4), (p+5, p+6), (p+7, p+8)
+                opmode::split<DT>(left, c0.x, d[0][0], d[1][0], d[2][0]);
+                opmode::split<DT>(c0.y, c0.z, d[0][1], d[1][1], d[2][1]);
+                opmode::split<DT>(c0.w, c1.x, d[0][2], d[1][2], d[2][2]);
+                opmode::split<DT>(c1.y, c1.z, d[0][3], d[1][3], d[2][3]);
+                opmode::split<DT>(c1.w, right, d[0][4], d[1][4], d[2][4]);
+                uint4 bq[3][3];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    bq[0][q] = make_uint4(d[q][0], d[q][1], d[q][2], d[q][3]);                                          // dx = -1
+                    bq[2][q] = make_uint4(d[q][1], d[q][2], d[q][3], d[q][4]);                                          // dx = +1
+                    bq[1][q] = make_uint4(__builtin_amdgcn_alignbit(d[q][1], d[q][0], 16), __builtin_amdgcn_alignbit(d[q][2], d[q][1], 16),
+                                          __builtin_amdgcn_alignbit(d[q][3], d[q][2], 16), __builtin_amdgcn_alignbit(d[q][4], d[q][3], 16));
+                }
+#pragma unroll
+                for (int term = 0; term < NT; ++term)
+#pragma unroll
+                    for (int a = 0; a < TO; ++a)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+                            acc[a][j][kx] = opmode::mfma16<DT>(aq[a][opmode::Form<DT>::termA(term)], bq[kx][opmode::Form<DT>::termB(term)],
+                                                               acc[a][j][kx]);
+            }
+        }
+        pl += 32;
+        x0 += g.r32;
+        y += g.q32;
+        if (x0 >= g.W) {
+            x0 -= g.W;
+            ++y;
+        }
+    };
+    Raw r0, r1;
+    fetch(r0, 0);
+#pragma unroll 1
+    for (int blk = 0; blk < nblk; blk += 2) {
+        fetch(r1, blk + 1);
+        consume(r0);
+        fetch(r0, blk + 2);
+        if (blk + 1 < nblk) consume(r1);
+    }
+    // partial [bs][tap][O][I]: D row 4 kg + r -> output channel, column r16 -> input channel (64-byte runs)
+    float *prow = part + (size_t)bs * ((size_t)9 * g.O * g.I) + (size_t)(3 * ky) * g.O * g.I;
+#pragma unroll
+    for (int a = 0; a < TO; ++a)
+#pragma unroll
+        for (int j = 0; j < TI; ++j) {
+            const int i = i0 + 16 * j + r16;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = o0 + 16 * a + 4 * kg + r;
+                    if (o < g.O && i < g.I) prow[((size_t)kx * g.O + o) * g.I + i] = acc[a][j][kx][r];
+                }
+        }
+}
+
+int make_w16geom(W16Geom &g, int B, int O, int I, int H, int W, long dy_batch, long x_batch, int to, int ti)
+{
+    if (B <= 0 || O <= 0 || I <= 0 || H <= 0 || W <= 0 || (W & 7)) return MLAGG_E_UNSUPPORTED;
+    const long P = (long)H * W;
+    if (P >= (1L << 28) || dy_batch < (long)O * P || x_batch < (long)I * P || ((dy_batch | x_batch) & 3)) return MLAGG_E_UNSUPPORTED;
+    g = W16Geom{B, O, I, H, W, (int)P, dy_batch, x_batch, 0, 0, 0, (long)(B - 1) * x_batch + (long)I * P - 8, 32 / W, 32 % W};
+    const int og = (O + 16 * to - 1) / (16 * to), ig = (I + 16 * ti - 1) / (16 * ti);
+    // two waves per SIMD over (sample, slab, kernel row, channel blocks); at least eight 32-pixel blocks per slab
+    static const int target = [] { const char *e = getenv("MLAGG_K19W16_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2048; }();
+    int per_sample = (target + B * og * ig * 3 - 1) / (B * og * ig * 3);
+    const long cap = (256L << 20) / (4L * 9 * O * I) / B;   // partial blocks: under 256 MB in total
+    if (per_sample > cap) per_sample = (int)cap;
+    if (per_sample < 1) per_sample = 1;
+    int slab = (int)((P + per_sample - 1) / per_sample);
+    slab = ((slab + 31) / 32) * 32;
+    if (slab < 256) slab = 256;
+    g.slab = slab;
+    g.nslabs = (int)((P + slab - 1) / slab);
+    if ((long)B * g.nslabs > (1L << 26) || og > 65535 || ig > 65535) return MLAGG_E_UNSUPPORTED;
+    g.nbs = B * g.nslabs;
+    return 0;
+}
+
+// which form serves a 2-D layer: the 16-wide tiles unless a channel extent is small enough that the 32 x 32 x nine-tap form wastes less
+int w16_tiles(int O, int I, int &to, int &ti)
+{
+    static const int mode = [] { const char *e = getenv("MLAGG_K19W16"); return e ? atoi(e) : 1; }();
+    if (!mode) return 0;
+    to = 3;
+    ti = I <= 16 ? 1 : 3;
+    return 1;
 }
 
 int make_w3geom(W3Geom &g, int B, int O, int I, int D, int H, int W, long dy_batch, long x_batch)
@@ -418,14 +608,18 @@ int make_w3geom(W3Geom &g, int B, int O, int I, int D, int H, int W, long dy_bat
 
 
 template <int TO, int TP>
-void launch(const float *x, const unsigned short *wimg, const float *bias, float *y, const C3Geom &g, hipStream_t st)
+void launch(const float *x, const unsigned short *wimg, const float *bias, float *y, const C3Geom &g, int dt, hipStream_t st)
 {
     const int groups = (g.P + 32 * TP - 1) / (32 * TP);
     const dim3 grid((groups + WAVES - 1) / WAVES, (g.O + 32 * TO - 1) / (32 * TO), g.B);
-    if (g.D > 1)
-        hipLaunchKernelGGL((conv3x3_kernel<TO, TP, 9>), grid, dim3(64 * WAVES), 0, st, x, wimg, bias, y, g);
+    if (g.D > 1)                                            // volumes: the fp32 form only (conv_fwd checks)
+        hipLaunchKernelGGL((conv3x3_kernel<TO, TP, 9, MLAGG_DTYPE_BF16X3>), grid, dim3(64 * WAVES), 0, st, x, wimg, bias, y, g);
+    else if (dt == MLAGG_DTYPE_BF16)
+        hipLaunchKernelGGL((conv3x3_kernel<TO, TP, 3, MLAGG_DTYPE_BF16>), grid, dim3(64 * WAVES), 0, st, x, wimg, bias, y, g);
+    else if (dt == MLAGG_DTYPE_F16)
+        hipLaunchKernelGGL((conv3x3_kernel<TO, TP, 3, MLAGG_DTYPE_F16>), grid, dim3(64 * WAVES), 0, st, x, wimg, bias, y, g);
     else
-        hipLaunchKernelGGL((conv3x3_kernel<TO, TP, 3>), grid, dim3(64 * WAVES), 0, st, x, wimg, bias, y, g);
+        hipLaunchKernelGGL((conv3x3_kernel<TO, TP, 3, MLAGG_DTYPE_BF16X3>), grid, dim3(64 * WAVES), 0, st, x, wimg, bias, y, g);
 }
 
 }  // namespace
@@ -437,9 +631,10 @@ namespace {
 constexpr long K19_MAX_PLANE = (1LL << 32) / 36 - 1;
 
 int conv_fwd(const float *x, long x_batch, const float *w, int transposed, const float *bias, float *y, long y_batch, void *workspace,
-             int B, int O, int I, int D, int H, int W, void *stream)
+             int B, int O, int I, int D, int H, int W, int dt, void *stream)
 {
     if (!x || !w || !y || !workspace) return MLAGG_E_NULLPTR;
+    if (!opmode::valid(dt) || (D > 1 && dt != MLAGG_DTYPE_BF16X3)) return MLAGG_E_UNSUPPORTED;
     const long P = (long)D * H * W;
     if (B <= 0 || B > 65535 || O <= 0 || I <= 0 || (I % 16) || D <= 0 || H <= 0 || W <= 0 || P < 96 || P > K19_MAX_PLANE)
         return MLAGG_E_UNSUPPORTED;
@@ -450,7 +645,13 @@ int conv_fwd(const float *x, long x_batch, const float *w, int transposed, const
     unsigned short *img = static_cast<unsigned short *>(workspace);
     const int ntaps = D > 1 ? 27 : 9;
     const int n = ntaps * O * I;
-    hipLaunchKernelGGL(conv3x3_weight_image_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, img, O, I, ntaps, transposed ? 1 : 0);
+    const dim3 igrid((n + 255) / 256);
+    if (dt == MLAGG_DTYPE_BF16)
+        hipLaunchKernelGGL(conv3x3_weight_image_kernel<MLAGG_DTYPE_BF16>, igrid, dim3(256), 0, st, w, img, O, I, ntaps, transposed ? 1 : 0);
+    else if (dt == MLAGG_DTYPE_F16)
+        hipLaunchKernelGGL(conv3x3_weight_image_kernel<MLAGG_DTYPE_F16>, igrid, dim3(256), 0, st, w, img, O, I, ntaps, transposed ? 1 : 0);
+    else
+        hipLaunchKernelGGL(conv3x3_weight_image_kernel<MLAGG_DTYPE_BF16X3>, igrid, dim3(256), 0, st, w, img, O, I, ntaps, transposed ? 1 : 0);
     // tile per wave = (32 TO output channels) x (32 TP pixels); measured on the step's shapes (tools/bench_conv3x3.py with
     // MLAGG_K19_TILE, profiles/round3_h_conv3x3_k19_vs_miopen_tiles.log): 2 x 2 (two workgroups per CU, most waves) everywhere
     // except outputs that fill 96-channel groups exactly on large maps
@@ -469,12 +670,12 @@ int conv_fwd(const float *x, long x_batch, const float *w, int transposed, const
     }
     if (tp == 3) tp = 2 - (W & 1);                          // three-pixel runs are not instantiated
     switch (to * 4 + tp) {
-    case 1 * 4 + 1: launch<1, 1>(x, img, bias, y, g, st); break;
-    case 1 * 4 + 2: launch<1, 2>(x, img, bias, y, g, st); break;
-    case 2 * 4 + 1: launch<2, 1>(x, img, bias, y, g, st); break;
-    case 2 * 4 + 2: launch<2, 2>(x, img, bias, y, g, st); break;
-    case 3 * 4 + 1: launch<3, 1>(x, img, bias, y, g, st); break;
-    default: launch<3, 2>(x, img, bias, y, g, st); break;
+    case 1 * 4 + 1: launch<1, 1>(x, img, bias, y, g, dt, st); break;
+    case 1 * 4 + 2: launch<1, 2>(x, img, bias, y, g, dt, st); break;
+    case 2 * 4 + 1: launch<2, 1>(x, img, bias, y, g, dt, st); break;
+    case 2 * 4 + 2: launch<2, 2>(x, img, bias, y, g, dt, st); break;
+    case 3 * 4 + 1: launch<3, 1>(x, img, bias, y, g, dt, st); break;
+    default: launch<3, 2>(x, img, bias, y, g, dt, st); break;
     }
     return (int)hipGetLastError();
 }
@@ -493,7 +694,15 @@ extern "C" size_t mlagg_conv3x3_workspace_bytes(int O, int I) { return O > 0 && 
 extern "C" int mlagg_conv3x3_fwd(const float *x, long x_batch, const float *w, int transposed, const float *bias, float *y,
                                  long y_batch, void *workspace, int B, int O, int I, int H, int W, void *stream)
 {
-    return conv_fwd(x, x_batch, w, transposed, bias, y, y_batch, workspace, B, O, I, 1, H, W, stream);
+    return conv_fwd(x, x_batch, w, transposed, bias, y, y_batch, workspace, B, O, I, 1, H, W, MLAGG_DTYPE_BF16X3, stream);
+}
+
+// the same product in the operand form `dtype` (MLAGG_DTYPE_BF16X3: the call above; MLAGG_DTYPE_BF16 / _F16: the 16-bit modes -- operands
+// rounded once, one product, fp32 sums; x, w, y stay fp32 in memory)
+extern "C" int mlagg_conv3x3_fwd_lp(const float *x, long x_batch, const float *w, int transposed, const float *bias, float *y,
+                                    long y_batch, void *workspace, int B, int O, int I, int H, int W, int dtype, void *stream)
+{
+    return conv_fwd(x, x_batch, w, transposed, bias, y, y_batch, workspace, B, O, I, 1, H, W, dtype, stream);
 }
 
 // the same for 3 x 3 x 3 kernels on (B, C, D, H, W) volumes (nine kernel rows (kz, ky) of three taps each)
@@ -508,7 +717,7 @@ extern "C" int mlagg_conv3x3x3_fwd(const float *x, long x_batch, const float *w,
                                    long y_batch, void *workspace, int B, int O, int I, int D, int H, int W, void *stream)
 {
     if (D <= 1) return MLAGG_E_UNSUPPORTED;
-    return conv_fwd(x, x_batch, w, transposed, bias, y, y_batch, workspace, B, O, I, D, H, W, stream);
+    return conv_fwd(x, x_batch, w, transposed, bias, y, y_batch, workspace, B, O, I, D, H, W, MLAGG_DTYPE_BF16X3, stream);
 }
 
 extern "C" int mlagg_conv3x3_wgrad_supported(int O, int I, int H, int W)
@@ -524,24 +733,57 @@ extern "C" int mlagg_conv3x3x3_wgrad_supported(int O, int I, int D, int H, int W
 namespace {
 size_t wgrad_ws(int B, int O, int I, int D, int H, int W)
 {
+    int to = 0, ti = 0;
+    if (D == 1 && w16_tiles(O, I, to, ti)) {
+        W16Geom g16;
+        if (make_w16geom(g16, B, O, I, H, W, (long)O * H * W, (long)I * H * W, to, ti)) return 0;
+        return (size_t)g16.nbs * 9 * O * I;
+    }
     W3Geom g;
     if (make_w3geom(g, B, O, I, D, H, W, (long)O * D * H * W, (long)I * D * H * W)) return 0;
     return (size_t)B * g.nslabs * 9 * g.nz * O * I;
 }
 
 int wgrad3(const float *dy, long dy_batch, const float *x, long x_batch, float *dW, float *workspace, int B, int O, int I, int D, int H,
-           int W, void *stream)
+           int W, int dt, void *stream)
 {
     if (!dy || !x || !dW || !workspace) return MLAGG_E_NULLPTR;
-    W3Geom g;
-    if (int rc = make_w3geom(g, B, O, I, D, H, W, dy_batch, x_batch)) return rc;
+    if (!opmode::valid(dt)) return MLAGG_E_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(dy) & 15) || (reinterpret_cast<uintptr_t>(x) & 3)) return MLAGG_E_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    int to = 0, ti = 0;
+    if (D == 1 && w16_tiles(O, I, to, ti)) {
+        W16Geom g;
+        if (int rc = make_w16geom(g, B, O, I, H, W, dy_batch, x_batch, to, ti)) return rc;
+        MLAGG_TIMED(K_CONV3X3, st);
+        const dim3 grid(24 * ((g.nbs + 7) / 8), (O + 16 * to - 1) / (16 * to), (I + 16 * ti - 1) / (16 * ti));
+#define K19W16_LAUNCH(TI_, DT_) hipLaunchKernelGGL((conv3x3_wgrad16_kernel<3, TI_, DT_>), grid, dim3(64), 0, st, dy, x, workspace, g)
+        if (ti == 1) {
+            if (dt == MLAGG_DTYPE_BF16) K19W16_LAUNCH(1, MLAGG_DTYPE_BF16);
+            else if (dt == MLAGG_DTYPE_F16) K19W16_LAUNCH(1, MLAGG_DTYPE_F16);
+            else K19W16_LAUNCH(1, MLAGG_DTYPE_BF16X3);
+        } else {
+            if (dt == MLAGG_DTYPE_BF16) K19W16_LAUNCH(3, MLAGG_DTYPE_BF16);
+            else if (dt == MLAGG_DTYPE_F16) K19W16_LAUNCH(3, MLAGG_DTYPE_F16);
+            else K19W16_LAUNCH(3, MLAGG_DTYPE_BF16X3);
+        }
+#undef K19W16_LAUNCH
+        const int n = 9 * O * I;
+        hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, workspace, g.nbs, O, I, 9, dW);
+        return (int)hipGetLastError();
+    }
+    W3Geom g;
+    if (int rc = make_w3geom(g, B, O, I, D, H, W, dy_batch, x_batch)) return rc;
     MLAGG_TIMED(K_CONV3X3, st);
     const dim3 grid(B * g.nslabs * g.nz, (O + 31) / 32, (I + 31) / 32);
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(64), 0, st, dy, x, workspace, g);
+    if (dt == MLAGG_DTYPE_BF16)
+        hipLaunchKernelGGL(conv3x3_wgrad_kernel<MLAGG_DTYPE_BF16>, grid, dim3(64), 0, st, dy, x, workspace, g);
+    else if (dt == MLAGG_DTYPE_F16)
+        hipLaunchKernelGGL(conv3x3_wgrad_kernel<MLAGG_DTYPE_F16>, grid, dim3(64), 0, st, dy, x, workspace, g);
+    else
+        hipLaunchKernelGGL(conv3x3_wgrad_kernel<MLAGG_DTYPE_BF16X3>, grid, dim3(64), 0, st, dy, x, workspace, g);
     const int ntaps = 9 * g.nz, n = ntaps * O * I;
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, workspace, B * g.nslabs, O, I, ntaps, dW);
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, workspace, B * g.nslabs, O, I, ntaps, dW);
     return (int)hipGetLastError();
 }
 }  // namespace
@@ -553,7 +795,14 @@ extern "C" size_t mlagg_conv3x3x3_wgrad_workspace_floats(int B, int O, int I, in
 extern "C" int mlagg_conv3x3_wgrad(const float *dy, long dy_batch, const float *x, long x_batch, float *dW, float *workspace, int B,
                                    int O, int I, int H, int W, void *stream)
 {
-    return wgrad3(dy, dy_batch, x, x_batch, dW, workspace, B, O, I, 1, H, W, stream);
+    return wgrad3(dy, dy_batch, x, x_batch, dW, workspace, B, O, I, 1, H, W, MLAGG_DTYPE_BF16X3, stream);
+}
+
+// ... in the operand form `dtype` (see mlagg_conv3x3_fwd_lp)
+extern "C" int mlagg_conv3x3_wgrad_lp(const float *dy, long dy_batch, const float *x, long x_batch, float *dW, float *workspace, int B,
+                                      int O, int I, int H, int W, int dtype, void *stream)
+{
+    return wgrad3(dy, dy_batch, x, x_batch, dW, workspace, B, O, I, 1, H, W, dtype, stream);
 }
 
 // dW (O, I, 3, 3, 3) of the 3 x 3 x 3 convolution on (B, C, D, H, W) volumes
@@ -561,5 +810,5 @@ extern "C" int mlagg_conv3x3x3_wgrad(const float *dy, long dy_batch, const float
                                      int O, int I, int D, int H, int W, void *stream)
 {
     if (D <= 1) return MLAGG_E_UNSUPPORTED;
-    return wgrad3(dy, dy_batch, x, x_batch, dW, workspace, B, O, I, D, H, W, stream);
+    return wgrad3(dy, dy_batch, x, x_batch, dW, workspace, B, O, I, D, H, W, MLAGG_DTYPE_BF16X3, stream);
 }

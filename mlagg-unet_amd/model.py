@@ -141,10 +141,17 @@ class _ConvMixin:
     def _fp32_conv(self, x):
         return self._lib_conv(x, self.weight)
 
+    def _lp_conv(self, x, form):
+        return None
+
     def raw(self, x):
         cdt = ops.conv_dtype()
         if cdt == torch.float32:
             return self._fp32_conv(x)
+        if ops.LP_K and x.dtype == torch.float32:
+            y = self._lp_conv(x, ops.conv_form())                    # K18 / K19, one rounded product, fp32 map out (round 4)
+            if y is not None:
+                return y
         return self._lib_conv(x if x.dtype == cdt else x.to(cdt), self.weight.to(cdt))
 
     def fused(self, x, res=None, act=ops.EPI_NONE, dtype=None):
@@ -154,7 +161,7 @@ class _ConvMixin:
             return F.gelu(y) if act == ops.EPI_GELU else y
         y = self.raw(x)
         if y.dtype == torch.float32:
-            return ops.channel_epilogue(y, self.bias, res, act)
+            return ops.channel_epilogue(y, self.bias, res if res is None or res.dtype == torch.float32 else res.float(), act)
         if y.numel() // (y.shape[0] * y.shape[1]) % 4 or not ops.LP_IO:
             return ops.channel_epilogue(y.float(), self.bias, None if res is None else res.float(), act)
         return ops.channel_epilogue_lp(y, self.bias, res, act, dtype or torch.float32)
@@ -183,6 +190,13 @@ class Conv2d(_ConvMixin, nn.Conv2d):
         if self.groups == 1 and ops.K15_2D and tuple(self.dilation) == (1, 1):
             return ops.conv_nd(x, self.weight, self.stride, self.padding)
         return self._lib_conv(x, self.weight)
+
+    def _lp_conv(self, x, form):
+        if ops.conv1x1_supported(x, self.weight, self.stride, self.padding, self.dilation, self.groups, form):
+            return ops.conv1x1(x, self.weight, form)
+        if ops.conv3x3_supported(x, self.weight, self.stride, self.padding, self.dilation, self.groups, form):
+            return ops.conv3x3(x, self.weight, form)
+        return None
 
     def _eager(self, x):
         return nn.Conv2d.forward(self, x)
@@ -219,7 +233,10 @@ def _chain_dtype(x):
     """Element type of a map that only 16-bit library convolutions read, in the current mode: bf16 / fp16 in the 16-bit modes when
     the kernels' vector path applies (plane size a multiple of 4), else None (= keep fp32)."""
     cdt = ops.conv_dtype()
-    if cdt == torch.float32 or not ops.LP_IO or (x.numel() // (x.shape[0] * x.shape[1])) % 4:
+    pixels = x.numel() // (x.shape[0] * x.shape[1])
+    if cdt == torch.float32 or not ops.LP_IO or pixels % 4:
+        return None
+    if ops.LP_K and pixels >= ops.LP_K_MIN_PIXELS:       # the map's stride-1 convolutions are K18 / K19 here: they read fp32
         return None
     return cdt
 

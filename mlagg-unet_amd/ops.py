@@ -73,6 +73,38 @@ def conv_dtype():
     return compute_dtype() if LP_CONV else torch.float32
 
 
+# 16-bit modes, round 4: the 1 x 1 / 3 x 3 stride-1 convolutions run on K18 / K19 in the ONE-product operand form (csrc/opmode.h: operands
+# rounded once to bf16 / fp16 in registers, fp32 sums) straight on the fp32 maps -- the kernels of the fp32 step at a sixth of its matrix
+# work, no cast kernels, no NHWC transposes.  Maps below LP_K_MIN_PIXELS pixels, strided and transposed convolutions stay 16-bit library
+# calls.  MLAGG_LP_K=0: every convolution of the 16-bit modes on the library (the round-3 form).
+LP_K = _os.environ.get("MLAGG_LP_K", "1") == "1"
+LP_K_MIN_PIXELS = int(_os.environ.get("MLAGG_LP_K_MIN_PIXELS", "1024"))
+_DTYPE_BF16X3 = 3
+_FORM_TORCH = {1: torch.bfloat16, 2: torch.float16, 3: torch.float32}
+
+
+def conv_form():
+    """Operand form (MLAGG_DTYPE_* code) of the K18 / K19 products in the current mode: three bf16 pieces (fp32), or one rounded operand."""
+    cdt = conv_dtype()
+    return _DTYPE_BF16X3 if cdt == torch.float32 else _LP_CODE[cdt]
+
+
+def _lib_conv_fwd(x, w, padding, form):
+    """Library forward of a stride-1 convolution inside a K18 / K19 Function, in the arithmetic of `form` (fp32 maps in and out)."""
+    if form == _DTYPE_BF16X3:
+        return torch.nn.functional.conv2d(x, w, None, 1, padding)
+    t = _FORM_TORCH[form]
+    return torch.nn.functional.conv2d(x.to(t), w.to(t), None, 1, padding).float()
+
+
+def _lib_conv_bwd(dy, x, w, padding, mask, form):
+    if form != _DTYPE_BF16X3:
+        t = _FORM_TORCH[form]
+        dy, x, w = dy.to(t), x.to(t), w.to(t)
+    out = torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1), (padding, padding), (1, 1), False, (0, 0), 1, mask)
+    return [None if o is None else o.float() for o in out]
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -911,7 +943,6 @@ def pooled_diff_attn(q, k_pool, v_pool, lam, subln_w, nh, scale):
 # products, fp32 accumulation -- as accurate against float64 as the fp32 instruction, tools/bench_linear.py).  MLAGG_K5_X3=0: K5 on
 # v_mfma_f32_32x32x2_f32.
 K5_X3 = _os.environ.get("MLAGG_K5_X3", "1") == "1"
-_DTYPE_BF16X3 = 3
 WGRAD_MIN_ROWS = int(_os.environ.get("MLAGG_WGRAD_MIN_ROWS", "8192"))      # below this many tokens the library GEMM is no longer the split-K corner case
 K5_MIN_ROWS = int(_os.environ.get("MLAGG_K5_MIN_ROWS", "16384"))     # fp32 forward / dx: K5 from this many tokens on (at 10240 tokens the
 #                            library's split-K kernels win: 80-320 K5 workgroups do not fill 256 CUs evenly; A/B on the step: +0.9 %)
@@ -2054,8 +2085,10 @@ K18 = _os.environ.get("MLAGG_K18", "1") == "1"
 K18_FWD_MIN_PIXELS, K18_FWD_MIN_K, K18_WGRAD_MIN_PIXELS = 16384, 96, 4096
 
 
-def _k18_product(O, I, P):
+def _k18_product(O, I, P, form=_DTYPE_BF16X3):
     """forward-form product y (O) = w (O, I) . x (I) on K18?  (the data gradient asks with O and I exchanged)"""
+    if form != _DTYPE_BF16X3:                # one product per block: a stream of the maps, ahead of cast + library + cast wherever it runs
+        return P >= LP_K_MIN_PIXELS and bool(_lib.lib().mlagg_conv1x1_supported(O, I, P))
     return P >= K18_FWD_MIN_PIXELS and I >= K18_FWD_MIN_K and bool(_lib.lib().mlagg_conv1x1_supported(O, I, P))
 
 
@@ -2065,20 +2098,20 @@ class Conv1x1Fn(torch.autograd.Function):
     library, whichever is faster at the shape (see K18_* above)."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, form=_DTYPE_BF16X3):
         x, xb, P = _planes(x, "x")
         B, I = x.shape[:2]
         O = weight.shape[0]
         w = _require(weight.reshape(O, I).contiguous(), "weight")
-        if _k18_product(O, I, P):
+        if _k18_product(O, I, P, form):
             y = torch.empty((B, O) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
             _flop("K18", 2 * B * O * I * P)
-            _lib.check(_lib.lib().mlagg_conv1x1_fwd(_ptr(x), xb, _ptr(w), None, _ptr(y), O * P, B, O, I, P, _stream()),
-                       "mlagg_conv1x1_fwd")
+            _lib.check(_lib.lib().mlagg_conv1x1_fwd_lp(_ptr(x), xb, _ptr(w), None, _ptr(y), O * P, B, O, I, P, form, _stream()),
+                       "mlagg_conv1x1_fwd_lp")
         else:
-            y = torch.nn.functional.conv2d(x, weight)
+            y = _lib_conv_fwd(x, weight, 0, form)
         ctx.save_for_backward(x, w)
-        ctx.wshape = weight.shape
+        ctx.wshape, ctx.form = weight.shape, form
         ctx.leaf, ctx.leaf_params = _leaf_ok(weight), [weight]
         note_leaf_use(weight)
         return y
@@ -2090,41 +2123,41 @@ class Conv1x1Fn(torch.autograd.Function):
         O = w.shape[0]
         dy, dyb, P = _planes(dy, "dy")
         lib = _lib.lib()
+        form = ctx.form
         dx = dW = None
         if ctx.needs_input_grad[0]:
-            if _k18_product(I, O, P):
+            if _k18_product(I, O, P, form):
                 wt = transpose_2d(w.unsqueeze(0))[0]                                   # (I, O): the contraction runs along its rows
                 dx = torch.empty((B, I) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
                 _flop("K18", 2 * B * O * I * P)
-                _lib.check(lib.mlagg_conv1x1_fwd(_ptr(dy), dyb, _ptr(wt), None, _ptr(dx), I * P, B, I, O, P, _stream()),
-                           "mlagg_conv1x1_fwd")
+                _lib.check(lib.mlagg_conv1x1_fwd_lp(_ptr(dy), dyb, _ptr(wt), None, _ptr(dx), I * P, B, I, O, P, form, _stream()),
+                           "mlagg_conv1x1_fwd_lp")
             else:
-                dx = torch.ops.aten.convolution_backward(dy, x, w.view(ctx.wshape), None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1,
-                                                         (True, False, False))[0]
+                dx = _lib_conv_bwd(dy, x, w.view(ctx.wshape), 0, (True, False, False), form)[0]
         if ctx.needs_input_grad[1]:
             with _LeafStream(dy, x, ok=ctx.leaf and leaf_single_use(ctx.leaf_params)):
                 dW = torch.empty(O, I, device=x.device, dtype=torch.float32)
                 ws = torch.empty(lib.mlagg_conv1x1_wgrad_workspace_floats(B, O, I, P), device=x.device, dtype=torch.float32)
                 _flop("K18", 2 * B * O * I * P)
-                _lib.check(lib.mlagg_conv1x1_wgrad(_ptr(dy), dyb, _ptr(x), x.stride(0), _ptr(dW), _ptr(ws), B, O, I, P, _stream()),
-                           "mlagg_conv1x1_wgrad")
+                _lib.check(lib.mlagg_conv1x1_wgrad_lp(_ptr(dy), dyb, _ptr(x), x.stride(0), _ptr(dW), _ptr(ws), B, O, I, P, form,
+                                                      _stream()), "mlagg_conv1x1_wgrad_lp")
             dW = dW.view(ctx.wshape)
-        return dx, dW
+        return dx, dW, None
 
 
-def conv1x1_supported(x, weight, stride, padding, dilation, groups):
-    """A 1 x 1, stride-1, dense fp32 convolution on the device whose weight gradient (at least) runs on K18."""
+def conv1x1_supported(x, weight, stride, padding, dilation, groups, form=_DTYPE_BF16X3):
+    """A 1 x 1, stride-1, dense convolution on an fp32 device map whose weight gradient (at least) runs on K18 in operand form `form`."""
     if not (K18 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and groups == 1):
         return False
     if tuple(weight.shape[2:]) != (1, 1) or any(int(v) != 1 for v in stride) or any(int(v) != 0 for v in padding) or \
             any(int(v) != 1 for v in dilation):
         return False
     P = int(x.shape[2] * x.shape[3])
-    return P >= K18_WGRAD_MIN_PIXELS and P % 16 == 0
+    return P >= (K18_WGRAD_MIN_PIXELS if form == _DTYPE_BF16X3 else LP_K_MIN_PIXELS) and P % 16 == 0
 
 
-def conv1x1(x, weight):
-    return Conv1x1Fn.apply(x, weight)
+def conv1x1(x, weight, form=_DTYPE_BF16X3):
+    return Conv1x1Fn.apply(x, weight, form)
 
 
 K19 = _os.environ.get("MLAGG_K19", "1") == "1"
@@ -2136,30 +2169,33 @@ K19_MIN_PIXELS = int(_os.environ.get("MLAGG_K19_MIN_PIXELS", "1024"))
 
 K19_WGRAD = _os.environ.get("MLAGG_K19_WGRAD", "1") == "1"
 K19_WGRAD_MIN_PIXELS = int(_os.environ.get("MLAGG_K19_WGRAD_MIN_PIXELS", "1024"))
-K19_WGRAD_MIN_CH = int(_os.environ.get("MLAGG_K19_WGRAD_MIN_CH", "96"))
+K19_WGRAD_MIN_CH = int(_os.environ.get("MLAGG_K19_WGRAD_MIN_CH", "48"))      # round 4: the 16-wide tiles fill 48-channel layers (was 96)
 
 
-def _k19_wgrad(O, I, H, W):
-    """3 x 3 weight gradient on K19?  Measured against MIOpen's implicit-GEMM kernels + their NHWC transposes (tools/bench_conv3x3.py):
+def _k19_wgrad(O, I, H, W, form=_DTYPE_BF16X3):
+    """3 x 3 weight gradient on K19?  (16-bit operand forms: wherever the kernel runs -- one product per tap and block.)  Measured against MIOpen's implicit-GEMM kernels + their NHWC transposes (tools/bench_conv3x3.py):
     706 vs 816, 280 vs 323, 175 vs 205, 190 vs 212 us where a channel extent reaches 96 (32-channel tiles are then well filled);
     48 x 48 channels fill 56 % of a tile pair and lose or tie (492 vs 493, 179 vs 119 us), 16 x 16 maps tie."""
+    if form != _DTYPE_BF16X3:
+        return K19_WGRAD and H * W >= LP_K_MIN_PIXELS and bool(_lib.lib().mlagg_conv3x3_wgrad_supported(O, I, H, W))
     return (K19_WGRAD and H * W >= K19_WGRAD_MIN_PIXELS and max(O, I) >= K19_WGRAD_MIN_CH and
             bool(_lib.lib().mlagg_conv3x3_wgrad_supported(O, I, H, W)))
 
 
-def _k19_product(O, I, H, W):
+def _k19_product(O, I, H, W, form=_DTYPE_BF16X3):
     """forward-form 3 x 3 product (O output channels, contraction I) on K19?  (the data gradient asks with O and I exchanged)"""
-    return K19 and H * W >= K19_MIN_PIXELS and bool(_lib.lib().mlagg_conv3x3_supported(O, I, H, W))
+    floor = K19_MIN_PIXELS if form == _DTYPE_BF16X3 else LP_K_MIN_PIXELS
+    return K19 and H * W >= floor and bool(_lib.lib().mlagg_conv3x3_supported(O, I, H, W))
 
 
-def _conv3x3_k19(x, xb, w, transposed, O, I, H, W):
+def _conv3x3_k19(x, xb, w, transposed, O, I, H, W, form=_DTYPE_BF16X3):
     lib = _lib.lib()
     B = x.shape[0]
     y = torch.empty(B, O, H, W, device=x.device, dtype=torch.float32)
     ws = torch.empty(lib.mlagg_conv3x3_workspace_bytes(O, I), device=x.device, dtype=torch.uint8)
     _flop("K19", 2 * 9 * B * O * I * H * W)
-    _lib.check(lib.mlagg_conv3x3_fwd(_ptr(x), xb, _ptr(w), int(transposed), None, _ptr(y), O * H * W, _ptr(ws), B, O, I, H, W, _stream()),
-               "mlagg_conv3x3_fwd")
+    _lib.check(lib.mlagg_conv3x3_fwd_lp(_ptr(x), xb, _ptr(w), int(transposed), None, _ptr(y), O * H * W, _ptr(ws), B, O, I, H, W, form,
+                                        _stream()), "mlagg_conv3x3_fwd_lp")
     return y
 
 
@@ -2168,16 +2204,17 @@ class Conv3x3Fn(torch.autograd.Function):
     split-bf16 GEMMs straight on the NCHW maps) where it beats the library's Winograd kernels, the weight gradient on the library."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, form=_DTYPE_BF16X3):
         x, xb, P = _planes(x, "x")
         B, I, H, W = x.shape
         O = weight.shape[0]
         w = _require(weight.contiguous(), "weight")
-        if _k19_product(O, I, H, W):
-            y = _conv3x3_k19(x, xb, w, False, O, I, H, W)
+        if _k19_product(O, I, H, W, form):
+            y = _conv3x3_k19(x, xb, w, False, O, I, H, W, form)
         else:
-            y = torch.nn.functional.conv2d(x, w, None, 1, 1)
+            y = _lib_conv_fwd(x, w, 1, form)
         ctx.save_for_backward(x, w)
+        ctx.form = form
         ctx.leaf, ctx.leaf_params = _leaf_ok(weight), [weight]
         note_leaf_use(weight)
         return y
@@ -2187,33 +2224,34 @@ class Conv3x3Fn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         B, I, H, W = x.shape
         O = w.shape[0]
+        form = ctx.form
         dx = dW = None
         if ctx.needs_input_grad[0]:
-            if _k19_product(I, O, H, W):
+            if _k19_product(I, O, H, W, form):
                 dy, dyb, _ = _planes(dy, "dy")
-                dx = _conv3x3_k19(dy, dyb, w, True, I, O, H, W)
+                dx = _conv3x3_k19(dy, dyb, w, True, I, O, H, W, form)
             else:
-                dx = torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (True, False, False))[0]
+                dx = _lib_conv_bwd(dy, x, w, 1, (True, False, False), form)[0]
         if ctx.needs_input_grad[1]:
             lib = _lib.lib()
-            if _k19_wgrad(O, I, H, W):
+            if _k19_wgrad(O, I, H, W, form):
                 dy, dyb, _ = _planes(dy, "dy")
                 with _LeafStream(dy, x, ok=ctx.leaf and leaf_single_use(ctx.leaf_params)):
                     dW = torch.empty(O, I, 3, 3, device=x.device, dtype=torch.float32)
                     ws = torch.empty(lib.mlagg_conv3x3_wgrad_workspace_floats(B, O, I, H, W), device=x.device, dtype=torch.float32)
                     _flop("K19", 2 * 9 * B * O * I * H * W)
-                    _lib.check(lib.mlagg_conv3x3_wgrad(_ptr(dy), dyb, _ptr(x), x.stride(0), _ptr(dW), _ptr(ws), B, O, I, H, W, _stream()),
-                               "mlagg_conv3x3_wgrad")
+                    _lib.check(lib.mlagg_conv3x3_wgrad_lp(_ptr(dy), dyb, _ptr(x), x.stride(0), _ptr(dW), _ptr(ws), B, O, I, H, W, form,
+                                                          _stream()), "mlagg_conv3x3_wgrad_lp")
             else:
                 dyc = dy.contiguous()
                 with _LeafStream(dyc, x, w, ok=ctx.leaf and leaf_single_use(ctx.leaf_params)):
-                    dW = torch.ops.aten.convolution_backward(dyc, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
-                                                             (False, True, False))[1]
-        return dx, dW
+                    dW = _lib_conv_bwd(dyc, x, w, 1, (False, True, False), form)[1]
+        return dx, dW, None
 
 
-def conv3x3_supported(x, weight, stride, padding, dilation, groups):
-    """A dense 3 x 3, stride-1, padding-1 fp32 convolution on the device whose forward or data gradient runs on K19."""
+def conv3x3_supported(x, weight, stride, padding, dilation, groups, form=_DTYPE_BF16X3):
+    """A dense 3 x 3, stride-1, padding-1 convolution on an fp32 device map whose forward or data gradient runs on K19 (16-bit operand
+    forms: or its weight gradient -- the one-channel stem)."""
     if not (K19 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and groups == 1):
         return False
     if tuple(weight.shape[2:]) != (3, 3) or any(int(v) != 1 for v in stride) or any(int(v) != 1 for v in padding) or \
@@ -2221,11 +2259,11 @@ def conv3x3_supported(x, weight, stride, padding, dilation, groups):
         return False
     O, I = int(weight.shape[0]), int(weight.shape[1])
     H, W = int(x.shape[2]), int(x.shape[3])
-    return _k19_product(O, I, H, W) or _k19_product(I, O, H, W)
+    return _k19_product(O, I, H, W, form) or _k19_product(I, O, H, W, form) or (form != _DTYPE_BF16X3 and _k19_wgrad(O, I, H, W, form))
 
 
-def conv3x3(x, weight):
-    return Conv3x3Fn.apply(x, weight)
+def conv3x3(x, weight, form=_DTYPE_BF16X3):
+    return Conv3x3Fn.apply(x, weight, form)
 
 
 K19_3D = _os.environ.get("MLAGG_K19_3D", "1") == "1"

@@ -161,7 +161,7 @@ def test_conv3x3_matches_float64(monkeypatch, B, I, O, H, W, sliced):
     output widths off the 32-channel tiles, and one full-size map."""
     from mlagg_unet_amd import ops
     monkeypatch.setattr(ops, "K19_MIN_PIXELS", 0)
-    monkeypatch.setattr(ops, "_k19_wgrad", lambda O, I, H, W: W % 16 == 0)      # the weight gradient too where the kernel supports it
+    monkeypatch.setattr(ops, "_k19_wgrad", lambda O, I, H, W, form=3: W % 16 == 0)      # the weight gradient too where the kernel supports it
     g = torch.Generator().manual_seed(B * I + O + H)
     wide = torch.randn(B, I + 16, H, W, generator=g).to(DEV)
     x = (wide[:, 8:8 + I] if sliced else wide[:, :I].contiguous()).detach()
@@ -177,6 +177,53 @@ def test_conv3x3_matches_float64(monkeypatch, B, I, O, H, W, sliced):
     for name, got, want, tol in (("y", yp, yr, 2e-6), ("dx", xp.grad, xr.grad, 2e-6), ("dW", wp.grad, wr.grad, 4e-6)):
         err = float((got.detach().double() - want.detach()).abs().max() / want.detach().abs().max())
         assert err < tol, (name, err)
+
+
+def _rounded_products(x, w, gy, pad, t):
+    """The three products of a stride-1 convolution as the reference's autocast step computes them (nnUNetTrainer.py:848): operands
+    rounded to the 16-bit type `t`, exact sums (float64 here; the kernels sum in fp32)."""
+    r = lambda v: v.to(t).double()                                                          # noqa: E731
+    xr, wr, gr = r(x), r(w), r(gy)
+    y = F.conv2d(xr, wr, None, 1, pad)
+    dx = torch.nn.grad.conv2d_input(xr.shape, wr, gr, 1, pad)
+    dW = torch.nn.grad.conv2d_weight(xr, wr.shape, gr, 1, pad)
+    return y, dx, dW
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form,t", [(1, torch.bfloat16), (2, torch.float16)])
+@pytest.mark.parametrize("k,B,I,O,H,W,sliced", [(3, 2, 48, 48, 32, 32, False), (3, 2, 96, 48, 12, 32, True), (3, 1, 48, 1, 16, 64, False),
+                                                (3, 2, 1, 48, 32, 32, False), (3, 1, 144, 33, 10, 16, False),
+                                                (1, 2, 96, 192, 32, 32, False), (1, 3, 192, 96, 16, 24, True), (1, 2, 48, 14, 16, 16, False)])
+def test_convolutions_in_the_16bit_operand_forms(monkeypatch, form, t, k, B, I, O, H, W, sliced):
+    """K18 / K19 with ONE rounded product (csrc/opmode.h; the 16-bit modes of the step, BASELINE configs[2] / [4]): forward, data gradient
+    and weight gradient equal the exact products of the operands rounded to bf16 / fp16, up to fp32 summation.  Cases include the
+    one-channel stem (forward on the library in that type, weight gradient on K19), a one-channel output (data gradient of the stem
+    shape), a 14-channel head (library data gradient) and a channel-slice input."""
+    from mlagg_unet_amd import ops
+    monkeypatch.setattr(ops, "LP_K_MIN_PIXELS", 0)
+    g = torch.Generator().manual_seed(B * I + O + H + k)
+    wide = torch.randn(B, I + 16, H, W, generator=g).to(DEV)
+    x = (wide[:, 8:8 + I] if sliced else wide[:, :I].contiguous()).detach()
+    w = (torch.randn(O, I, k, k, generator=g) * (k * k * I) ** -0.5).to(DEV)
+    gy = torch.randn(B, O, H, W, generator=g).to(DEV)
+    sup = ops.conv3x3_supported if k == 3 else ops.conv1x1_supported
+    assert sup(x, w, (1, 1), (k // 2,) * 2, (1, 1), 1, form)
+    yr, dxr, dWr = _rounded_products(x, w, gy, k // 2, t)
+    xp, wp = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yp = (ops.conv3x3 if k == 3 else ops.conv1x1)(xp, wp, form)
+    assert yp.dtype == torch.float32
+    yp.backward(gy)
+    # products that fall to the library in this form return ITS 16-bit result: a 16-bit rounding of the output (and of whatever the
+    # library's solver keeps in that type on the way) on top
+    lib_tol = 2.0 ** -7 if t == torch.bfloat16 else 2.0 ** -8
+    on_k = {"y": (ops._k19_product(O, I, H, W, form) if k == 3 else ops._k18_product(O, I, H * W, form)),
+            "dx": (ops._k19_product(I, O, H, W, form) if k == 3 else ops._k18_product(I, O, H * W, form)),
+            "dW": (ops._k19_wgrad(O, I, H, W, form) if k == 3 else True)}
+    for name, got, want in (("y", yp, yr), ("dx", xp.grad, dxr), ("dW", wp.grad, dWr)):
+        err = float((got.detach().double() - want).abs().max() / want.abs().max())
+        assert err < (4e-6 if on_k[name] else lib_tol), (name, err, on_k[name])
+    assert on_k["dW"] and (on_k["y"] or I == 1)
 
 
 @pytest.mark.gpu

@@ -40,7 +40,10 @@ def test_convolution_kernels_decline_host_tensors_and_unsupported_geometries():
 
 def test_weight_gradient_policy_reads_only_shapes():
     assert ops._k19_wgrad(96, 48, 256, 256) and ops._k19_wgrad(48, 96, 128, 128)
-    assert not ops._k19_wgrad(48, 48, 256, 256)          # 48 x 48 channels: 56 % tile fill, MIOpen ties or wins
+    assert ops._k19_wgrad(48, 48, 256, 256)              # round 4: 16-wide tiles fill 48 x 48 channels (236 vs MIOpen's 486 us)
+    assert ops._k19_wgrad(48, 1, 256, 256)               # ... the one-channel stem included (a 48 x 16 tile)
+    assert not ops._k19_wgrad(32, 32, 256, 256)          # below 48 channels: the library in fp32 ...
+    assert ops._k19_wgrad(32, 32, 256, 256, 1)           # ... K19's one-product form in the 16-bit modes
     assert not ops._k19_wgrad(720, 720, 16, 16)          # 256 pixels
     assert ops._k18_product(192, 96, 128 * 128) and not ops._k18_product(192, 96, 64 * 64) and not ops._k18_product(96, 48, 256 * 256)
 
