@@ -527,14 +527,171 @@ conv3x3_wgrad16_kernel(const float *__restrict__ dY, const float *__restrict__ X
     };
     Raw r0, r1;
     fetch(r0, 0);
+    int blk = 0;
 #pragma unroll 1
-    for (int blk = 0; blk < nblk; blk += 2) {
-        fetch(r1, blk + 1);
+    for (; blk + 1 < nblk; blk += 2) {                            // pairs; the odd last block is peeled: a conditional consume inside the
+        fetch(r1, blk + 1);                                      // loop made the compiler shuffle all 108 accumulators per iteration
         consume(r0);
         fetch(r0, blk + 2);
-        if (blk + 1 < nblk) consume(r1);
+        consume(r1);
     }
+    if (blk < nblk) consume(r0);
     // partial [bs][tap][O][I]: D row 4 kg + r -> output channel, column r16 -> input channel (64-byte runs)
+    float *prow = part + (size_t)bs * ((size_t)9 * g.O * g.I) + (size_t)(3 * ky) * g.O * g.I;
+#pragma unroll
+    for (int a = 0; a < TO; ++a)
+#pragma unroll
+        for (int j = 0; j < TI; ++j) {
+            const int i = i0 + 16 * j + r16;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = o0 + 16 * a + 4 * kg + r;
+                    if (o < g.O && i < g.I) prow[((size_t)kx * g.O + o) * g.I + i] = acc[a][j][kx][r];
+                }
+        }
+}
+
+// ---- the same tile with the operands staged through LDS in FULL LINES (round 4, second step).  The fragment-shaped loads of the
+// kernel above -- 16 bytes per lane, neighbouring lanes in different channel rows -- cost the texture addresser one access per LANE
+// (65 L1 accesses per load instruction measured, 1150 addresser cycles per block and wave against 2600 matrix cycles, four waves per
+// CU: addresser-bound at 47 % matrix utilisation).  Here a load instruction covers 8 channel rows x 128 bytes (dy) or 6.4 rows x
+// 160 bytes (x: the 32 pixels of the block and 4 on either side, so the two neighbours of every run come with the same lines), 8
+// lanes per row and line; the tile goes registers -> LDS (row pitches 36 / 44 floats: the 16 rows of a fragment read hit 64 distinct
+// banks) and the matrix operands are read back as ds_read_b128 fragments.  One wave per workgroup: no barrier, the wave's LDS
+// operations complete in order.  Stage s + 1 is in flight (registers) while stage s is consumed from LDS.
+template <int TO, int TI, int DT>
+__global__ void __launch_bounds__(64)
+conv3x3_wgrad16_lds_kernel(const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ part, W16Geom g, long dy_last)
+{
+    using opmode::f32x4;
+    constexpr int NQ = opmode::Form<DT>::NQ, NT = opmode::Form<DT>::NT;
+    constexpr int AP = 36, BP = 44;                              // LDS row pitches, floats
+    constexpr int AROWS = 16 * TO, BROWS = 16 * TI;
+    constexpr int NLA = AROWS / 8;                               // dy: 8 rows x 8 chunks of 16 bytes per load instruction
+    constexpr int NLB = (BROWS * 10 + 63) / 64;                  // x: 10 chunks per row
+    __shared__ float sA[2][AROWS * AP];
+    __shared__ float sB[2][BROWS * BP];
+    const int lane = threadIdx.x, r16 = lane & 15, kg = lane >> 4;
+    const int id = blockIdx.x, slot = id >> 3;
+    const int ky = slot % 3, bs = (slot / 3) * 8 + (id & 7);
+    if (bs >= g.nbs) return;
+    const int b = bs / g.nslabs, s = bs % g.nslabs;
+    const int o0 = blockIdx.y * (16 * TO), i0 = blockIdx.z * (16 * TI);
+    f32x4 acc[TO][TI][3];
+#pragma unroll
+    for (int a = 0; a < TO; ++a)
+#pragma unroll
+        for (int j = 0; j < TI; ++j)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc[a][j][kx] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int pb = s * g.slab, pe = min(pb + g.slab, g.P);
+    const int nblk = (pe - pb + 31) / 32;
+    // load lanes: float offsets relative to the block's uniform base (row * P + 4 * chunk), LDS float offsets of the chunk
+    int offA[NLA], offB[NLB];
+    int ldsA[NLA], ldsB[NLB];
+#pragma unroll
+    for (int m = 0; m < NLA; ++m) {
+        const int row = 8 * m + (lane >> 3), c = lane & 7;
+        offA[m] = min(o0 + row, g.O - 1) * g.P + 4 * c;
+        ldsA[m] = row * AP + 4 * c;
+    }
+#pragma unroll
+    for (int m = 0; m < NLB; ++m) {
+        const int idx = 64 * m + lane, row = min(idx / 10, BROWS - 1), c = idx % 10;      // past the tile: the last row again (same bytes)
+        offB[m] = min(i0 + row, g.I - 1) * g.P + 4 * c;
+        ldsB[m] = row * BP + 4 * c;
+    }
+    const long baseA = (long)b * g.dy_batch + pb;                                          // float index of (row 0, pixel pb)
+    const long baseB = (long)b * g.x_batch + pb + (long)(ky - 1) * g.W - 4;                // ... of the x window's first float
+    opmode::f32x4 ga[NLA], gb[NLB];                              // native vectors: arrays of HIP's float4 struct went to scratch
+    // every load is unconditional; a lane's offset is clamped into the operand (uniform bounds per block, 32-bit per-lane arithmetic):
+    // a displaced chunk only holds values that are masked (tail pixels, a source row outside the image, neighbours across an edge)
+    auto fetch = [&](int blk) __attribute__((always_inline)) {
+        const long ua = baseA + 32L * min(blk, nblk - 1), ub = baseB + 32L * min(blk, nblk - 1);
+        const int hiA = (int)min(dy_last - ua, 0x7fffffffL);
+        const int loB = (int)min(max(-ub, 0L), 0x7fffffffL), hiB = (int)min(g.x_last + 4 - ub, 0x7fffffffL);
+        const float *pa = dY + ua, *pbx = X + ub;
+#pragma unroll
+        for (int m = 0; m < NLA; ++m) ga[m] = *reinterpret_cast<const opmode::f32x4 *>(pa + min(offA[m], hiA));
+#pragma unroll
+        for (int m = 0; m < NLB; ++m) gb[m] = *reinterpret_cast<const opmode::f32x4 *>(pbx + min(max(offB[m], loB), hiB));
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < NLA; ++m) *reinterpret_cast<opmode::f32x4 *>(&sA[buf][ldsA[m]]) = ga[m];
+#pragma unroll
+        for (int m = 0; m < NLB; ++m) *reinterpret_cast<opmode::f32x4 *>(&sB[buf][ldsB[m]]) = gb[m];
+    };
+    int x0 = (pb + 8 * kg) % g.W, y = (pb + 8 * kg) / g.W, pl = pb + 8 * kg;
+    auto consume = [&](int buf) __attribute__((always_inline)) {
+        const bool live = pl < pe;
+        const bool rok = (unsigned)(y + ky - 1) < (unsigned)g.H;
+        if (__any(live && rok)) {
+            uint4 aq[TO][3];
+#pragma unroll
+            for (int a = 0; a < TO; ++a) {
+                const float *src = &sA[buf][(16 * a + r16) * AP + 8 * kg];
+                const float4 v0 = *reinterpret_cast<const float4 *>(src), v1 = *reinterpret_cast<const float4 *>(src + 4);
+                float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) f[k] = live ? f[k] : 0.f;
+                opmode::split8<DT>(f, aq[a]);
+            }
+#pragma unroll
+            for (int j = 0; j < TI; ++j) {
+                const float *src = &sB[buf][(16 * j + r16) * BP + 8 * kg];        // window float 0 = pixel p - 4
+                float4 c0 = *reinterpret_cast<const float4 *>(src + 4), c1 = *reinterpret_cast<const float4 *>(src + 8);
+                if (!rok) c0 = c1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float left = (!rok || x0 == 0) ? 0.f : src[3];
+                const float right = (!rok || x0 + 8 == g.W) ? 0.f : src[12];
+                unsigned d[3][5];
+                opmode::split<DT>(left, c0.x, d[0][0], d[1][0], d[2][0]);
+                opmode::split<DT>(c0.y, c0.z, d[0][1], d[1][1], d[2][1]);
+                opmode::split<DT>(c0.w, c1.x, d[0][2], d[1][2], d[2][2]);
+                opmode::split<DT>(c1.y, c1.z, d[0][3], d[1][3], d[2][3]);
+                opmode::split<DT>(c1.w, right, d[0][4], d[1][4], d[2][4]);
+                uint4 bq[3][3];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    bq[0][q] = make_uint4(d[q][0], d[q][1], d[q][2], d[q][3]);
+                    bq[2][q] = make_uint4(d[q][1], d[q][2], d[q][3], d[q][4]);
+                    bq[1][q] = make_uint4(__builtin_amdgcn_alignbit(d[q][1], d[q][0], 16), __builtin_amdgcn_alignbit(d[q][2], d[q][1], 16),
+                                          __builtin_amdgcn_alignbit(d[q][3], d[q][2], 16), __builtin_amdgcn_alignbit(d[q][4], d[q][3], 16));
+                }
+#pragma unroll
+                for (int term = 0; term < NT; ++term)
+#pragma unroll
+                    for (int a = 0; a < TO; ++a)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+                            acc[a][j][kx] = opmode::mfma16<DT>(aq[a][opmode::Form<DT>::termA(term)], bq[kx][opmode::Form<DT>::termB(term)],
+                                                               acc[a][j][kx]);
+            }
+        }
+        pl += 32;
+        x0 += g.r32;
+        y += g.q32;
+        if (x0 >= g.W) {
+            x0 -= g.W;
+            ++y;
+        }
+    };
+    fetch(0);
+    stage(0);
+    fetch(1);
+    int blk = 0;
+#pragma unroll 1
+    for (; blk + 1 < nblk; blk += 2) {                            // pairs (buffer parity is static); the odd last block is peeled
+        consume(0);                                              // block blk; block blk + 1 is in flight
+        stage(1);
+        fetch(blk + 2);
+        consume(1);
+        stage(0);
+        fetch(blk + 3);
+    }
+    if (blk < nblk) consume(0);
     float *prow = part + (size_t)bs * ((size_t)9 * g.O * g.I) + (size_t)(3 * ky) * g.O * g.I;
 #pragma unroll
     for (int a = 0; a < TO; ++a)
@@ -575,13 +732,16 @@ int make_w16geom(W16Geom &g, int B, int O, int I, int H, int W, long dy_batch, l
 }
 
 // which form serves a 2-D layer: the 16-wide tiles unless a channel extent is small enough that the 32 x 32 x nine-tap form wastes less
-int w16_tiles(int O, int I, int &to, int &ti)
+int w16_tiles(int O, int I, int dt, int &to, int &ti)
 {
-    static const int mode = [] { const char *e = getenv("MLAGG_K19W16"); return e ? atoi(e) : 1; }();
+    // MLAGG_K19W16: 0 = the 32 x 32 form, 1 = fragment-shaped loads, 2 = LDS-staged lines, unset = by operand form.  Measured on the step's
+    // shapes (profiles/round4_h_conv3x3_wgrad_forms.log): the six-product form is bound by vector-instruction issue (operand
+    // splitting) and loses 5-10 % to the staging instructions; the one-product forms are bound by the loads and gain 20-35 % from them.
+    static const int mode = [] { const char *e = getenv("MLAGG_K19W16"); return e ? atoi(e) : -1; }();
     if (!mode) return 0;
     to = 3;
     ti = I <= 16 ? 1 : 3;
-    return 1;
+    return mode < 0 ? (dt == MLAGG_DTYPE_BF16X3 ? 1 : 2) : mode;
 }
 
 int make_w3geom(W3Geom &g, int B, int O, int I, int D, int H, int W, long dy_batch, long x_batch)
@@ -734,7 +894,7 @@ namespace {
 size_t wgrad_ws(int B, int O, int I, int D, int H, int W)
 {
     int to = 0, ti = 0;
-    if (D == 1 && w16_tiles(O, I, to, ti)) {
+    if (D == 1 && w16_tiles(O, I, MLAGG_DTYPE_BF16X3, to, ti)) {
         W16Geom g16;
         if (make_w16geom(g16, B, O, I, H, W, (long)O * H * W, (long)I * H * W, to, ti)) return 0;
         return (size_t)g16.nbs * 9 * O * I;
@@ -752,20 +912,27 @@ int wgrad3(const float *dy, long dy_batch, const float *x, long x_batch, float *
     if ((reinterpret_cast<uintptr_t>(dy) & 15) || (reinterpret_cast<uintptr_t>(x) & 3)) return MLAGG_E_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int to = 0, ti = 0;
-    if (D == 1 && w16_tiles(O, I, to, ti)) {
+    const int w16 = D == 1 ? w16_tiles(O, I, dt, to, ti) : 0;
+    // the LDS-staged form loads 16-byte chunks of x and addresses rows with 32-bit float offsets
+    const bool lds_ok = !(reinterpret_cast<uintptr_t>(x) & 15) && (long)max(O, I) * H * W < (1L << 30);
+    if (w16) {
         W16Geom g;
         if (int rc = make_w16geom(g, B, O, I, H, W, dy_batch, x_batch, to, ti)) return rc;
         MLAGG_TIMED(K_CONV3X3, st);
         const dim3 grid(24 * ((g.nbs + 7) / 8), (O + 16 * to - 1) / (16 * to), (I + 16 * ti - 1) / (16 * ti));
-#define K19W16_LAUNCH(TI_, DT_) hipLaunchKernelGGL((conv3x3_wgrad16_kernel<3, TI_, DT_>), grid, dim3(64), 0, st, dy, x, workspace, g)
+        const long dy_last = (long)(B - 1) * dy_batch + (long)O * H * W - 4;
+        const bool lds = w16 == 2 && lds_ok;
+#define K19W16_LAUNCH(TI_, DT_)                                                                                                       \
+    if (lds) hipLaunchKernelGGL((conv3x3_wgrad16_lds_kernel<3, TI_, DT_>), grid, dim3(64), 0, st, dy, x, workspace, g, dy_last);        \
+    else hipLaunchKernelGGL((conv3x3_wgrad16_kernel<3, TI_, DT_>), grid, dim3(64), 0, st, dy, x, workspace, g)
         if (ti == 1) {
-            if (dt == MLAGG_DTYPE_BF16) K19W16_LAUNCH(1, MLAGG_DTYPE_BF16);
-            else if (dt == MLAGG_DTYPE_F16) K19W16_LAUNCH(1, MLAGG_DTYPE_F16);
-            else K19W16_LAUNCH(1, MLAGG_DTYPE_BF16X3);
+            if (dt == MLAGG_DTYPE_BF16) { K19W16_LAUNCH(1, MLAGG_DTYPE_BF16); }
+            else if (dt == MLAGG_DTYPE_F16) { K19W16_LAUNCH(1, MLAGG_DTYPE_F16); }
+            else { K19W16_LAUNCH(1, MLAGG_DTYPE_BF16X3); }
         } else {
-            if (dt == MLAGG_DTYPE_BF16) K19W16_LAUNCH(3, MLAGG_DTYPE_BF16);
-            else if (dt == MLAGG_DTYPE_F16) K19W16_LAUNCH(3, MLAGG_DTYPE_F16);
-            else K19W16_LAUNCH(3, MLAGG_DTYPE_BF16X3);
+            if (dt == MLAGG_DTYPE_BF16) { K19W16_LAUNCH(3, MLAGG_DTYPE_BF16); }
+            else if (dt == MLAGG_DTYPE_F16) { K19W16_LAUNCH(3, MLAGG_DTYPE_F16); }
+            else { K19W16_LAUNCH(3, MLAGG_DTYPE_BF16X3); }
         }
 #undef K19W16_LAUNCH
         const int n = 9 * O * I;

@@ -19,6 +19,11 @@ for d in a.dirs:
         for r in csv.DictReader(open(f)):
             if re.search(a.match, r["Kernel_Name"]):
                 acc[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+# average duration of the same kernels from the kernel trace of the first pass directory (counters serialise kernels, not slow them)
+for f in glob.glob(a.dirs[0] + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if re.search(a.match, r["Kernel_Name"]) and r["Kernel_Name"][:70] in acc:
+            acc[r["Kernel_Name"][:70]]["duration_us"].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
 cols = sorted({c for v in acc.values() for c in v})
 print("| kernel | launches | " + " | ".join(cols) + " |")
 print("|---|---|" + "---|" * len(cols))

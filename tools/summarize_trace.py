@@ -21,7 +21,8 @@ def family(n):
                      ("conv_taps_kernel", "HIP K16 convolution forward / data gradient (tap GEMM)"),
                      ("dwconv", "HIP K2 depthwise conv"), ("gelu_pool", "HIP K17 GELU + window mean"),
                      ("conv1x1_", "HIP K18 1x1 convolution (split bf16)"), ("conv3x3_", "HIP K19 3x3 convolution (split bf16)"),
-                     ("linear_wgrad_x3", "HIP K5w linear weight-grad"), ("linear_lp_kernel<true, 2>", "HIP K5 projections (fwd, dx)"),
+                     ("linear_wgrad_x3", "HIP K5w linear weight-grad"), ("linear_x3_kernel", "HIP K5 projections (fwd, dx)"),
+                     ("weight_image", "HIP K5 projections (fwd, dx)"), ("linear_lp_kernel<true, 2>", "HIP K5 projections (fwd, dx)"),
                      ("linear_lp_kernel<false, 2>", "HIP K5 projections (fwd, dx)"),
                      ("conv_wgrad_", "HIP K15 convolution weight gradient (tap GEMM)"), ("volume_pad_kernel", "HIP K15/K16 padded copies"),
                      ("guard_zero_kernel", "HIP K15/K16 padded copies"), ("pooled_lp_", "HIP K4lp pooled diff-attention (16-bit MFMA)"),
