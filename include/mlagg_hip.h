@@ -297,6 +297,10 @@ int mlagg_conv1x1_fwd_lp(const float *x, long x_batch, const float *w, const flo
                          long P, int dtype, void *stream);
 int mlagg_conv1x1_wgrad_lp(const float *dy, long dy_batch, const float *x, long x_batch, float *dW, float *workspace, int B, int O,
                            int I, long P, int dtype, void *stream);
+/* Forward form with a ragged contraction: x has I_valid <= I channels, w is (O, I) with I % 16 == 0 and zero columns from I_valid on
+ * (the segmentation heads, nnUNetTrainer_MLAgg_2D_dt_MS.py:549-561 OutBlock: the data gradient of a 14-class head contracts over 14). */
+int mlagg_conv1x1_fwd_ragged(const float *x, long x_batch, const float *w, const float *bias, float *y, long y_batch, int B, int O, int I,
+                             int I_valid, long P, int dtype, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K19: dense 3 x 3 convolutions (stride 1, zero padding 1, groups 1) on channel-major maps as nine shifted GEMMs on the 16-bit matrix

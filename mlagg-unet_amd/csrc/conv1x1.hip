@@ -36,6 +36,7 @@ struct __attribute__((packed, aligned(4))) FVec {
 struct C1Geom {
     int B, O, I, P;
     long x_batch, y_batch;          // floats between consecutive samples
+    int I_valid;                    // channels x really has (<= I): the weight's columns beyond are zero, the rows beyond are not read
 };
 
 using opmode::split8;
@@ -56,7 +57,8 @@ conv1x1_fwd_kernel(const float *__restrict__ X, const float *__restrict__ W, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][j][r] = 0.f;
     const int pnat = p0 + TP * col, pc = min(pnat, g.P - TP);
-    const float *xb = X + (size_t)b * g.x_batch + (size_t)(8 * kh) * g.P + pc;       // + (16 blk + t) * P
+    const float *xb = X + (size_t)b * g.x_batch + pc;                                // + row * P
+    const int lastrow = g.I_valid - 1;                                               // ragged contraction: rows past it are the last row again
     const float *wb[TO];
 #pragma unroll
     for (int a = 0; a < TO; ++a) wb[a] = W + (size_t)min(o0 + 32 * a + col, g.O - 1) * g.I + 8 * kh;      // + 16 blk
@@ -66,7 +68,7 @@ conv1x1_fwd_kernel(const float *__restrict__ X, const float *__restrict__ W, con
     auto fetch = [&](float4 (&A)[TO][2], FVec<TP> (&Xv)[8], int blk) {
         const int kb = 16 * min(blk, nblk - 1);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) Xv[t] = *reinterpret_cast<const FVec<TP> *>(xb + (size_t)(kb + t) * g.P);
+        for (int t = 0; t < 8; ++t) Xv[t] = *reinterpret_cast<const FVec<TP> *>(xb + (size_t)min(kb + 8 * kh + t, lastrow) * g.P);
 #pragma unroll
         for (int a = 0; a < TO; ++a) {
             A[a][0] = *reinterpret_cast<const float4 *>(wb[a] + kb);
@@ -267,14 +269,14 @@ extern "C" int mlagg_conv1x1_supported(int O, int I, long P)
 
 // y = w . x in the operand form `dtype` (MLAGG_DTYPE_BF16X3: the fp32 layers; MLAGG_DTYPE_BF16 / _F16: the 16-bit modes -- operands rounded
 // once, one product, fp32 sums; x, w, y stay fp32 in memory)
-extern "C" int mlagg_conv1x1_fwd_lp(const float *x, long x_batch, const float *w, const float *bias, float *y, long y_batch, int B,
-                                    int O, int I, long P, int dtype, void *stream)
+extern "C" int mlagg_conv1x1_fwd_ragged(const float *x, long x_batch, const float *w, const float *bias, float *y, long y_batch, int B,
+                                        int O, int I, int I_valid, long P, int dtype, void *stream)
 {
     if (!x || !w || !y) return MLAGG_E_NULLPTR;
-    if (!opmode::valid(dtype)) return MLAGG_E_UNSUPPORTED;
+    if (!opmode::valid(dtype) || I_valid <= 0 || I_valid > I) return MLAGG_E_UNSUPPORTED;
     if (B <= 0 || B > 65535 || !mlagg_conv1x1_supported(O, I, P)) return MLAGG_E_UNSUPPORTED;
-    if (x_batch < (long)I * P || y_batch < (long)O * P || (reinterpret_cast<uintptr_t>(w) & 15)) return MLAGG_E_UNSUPPORTED;
-    C1Geom g{B, O, I, (int)P, x_batch, y_batch};
+    if (x_batch < (long)I_valid * P || y_batch < (long)O * P || (reinterpret_cast<uintptr_t>(w) & 15)) return MLAGG_E_UNSUPPORTED;
+    C1Geom g{B, O, I, (int)P, x_batch, y_batch, I_valid};
     hipStream_t st = static_cast<hipStream_t>(stream);
     MLAGG_TIMED(K_CONV1X1, st);
     // tile = (32 TO output channels) x (32 TP pixels) per wave.  MLAGG_K18_TILE="TO,TP" overrides (tuning only).
@@ -294,6 +296,12 @@ extern "C" int mlagg_conv1x1_fwd_lp(const float *x, long x_batch, const float *w
     default: launch_fwd<3, 3>(x, w, bias, y, g, dtype, st); break;
     }
     return (int)hipGetLastError();
+}
+
+extern "C" int mlagg_conv1x1_fwd_lp(const float *x, long x_batch, const float *w, const float *bias, float *y, long y_batch, int B,
+                                    int O, int I, long P, int dtype, void *stream)
+{
+    return mlagg_conv1x1_fwd_ragged(x, x_batch, w, bias, y, y_batch, B, O, I, I, P, dtype, stream);
 }
 
 extern "C" int mlagg_conv1x1_fwd(const float *x, long x_batch, const float *w, const float *bias, float *y, long y_batch, int B,

@@ -211,6 +211,30 @@ class ConvTranspose2d(_ConvMixin, nn.ConvTranspose2d):
     def _lib_conv(self, x, w):
         return F.conv_transpose2d(x, w, None, self.stride, self.padding, self.output_padding, self.groups, self.dilation)
 
+    def _pointwise(self):
+        """A 1 x 1, stride-1 transposed convolution IS the 1 x 1 convolution with the weight's first two axes exchanged (the segmentation
+        heads, T:549-561): it takes K18 like the other pointwise convolutions."""
+        return (tuple(self.kernel_size) == (1, 1) and tuple(self.stride) == (1, 1) and tuple(self.padding) == (0, 0)
+                and tuple(self.output_padding) == (0, 0) and self.groups == 1 and tuple(self.dilation) == (1, 1))
+
+    def _k18(self, x, form):
+        # only where all three products run on K18 (the heads on the 256 x 256 and 128 x 128 maps): on the small maps the library's
+        # transposed-convolution solvers are the faster ones
+        I, O = self.weight.shape[:2]
+        P = int(x.shape[2] * x.shape[3])
+        return (ops.K18_THIN and self._pointwise() and ops.conv1x1_supported(x, self.weight, (1, 1), (0, 0), (1, 1), 1, form)
+                and ops._k18_product(O, I, P, form) and ops._k18_product(I, O, P, form))
+
+    def _fp32_conv(self, x):
+        if self._k18(x, ops._DTYPE_BF16X3):
+            return ops.conv1x1(x, self.weight.permute(1, 0, 2, 3))
+        return self._lib_conv(x, self.weight)
+
+    def _lp_conv(self, x, form):
+        if self._k18(x, form):
+            return ops.conv1x1(x, self.weight.permute(1, 0, 2, 3), form)
+        return None
+
     def _eager(self, x):
         return nn.ConvTranspose2d.forward(self, x)
 

@@ -2085,11 +2085,34 @@ K18 = _os.environ.get("MLAGG_K18", "1") == "1"
 K18_FWD_MIN_PIXELS, K18_FWD_MIN_K, K18_WGRAD_MIN_PIXELS = 16384, 96, 4096
 
 
+K18_THIN = _os.environ.get("MLAGG_K18_THIN", "1") == "1"
+K18_THIN_CH = 32
+
+
 def _k18_product(O, I, P, form=_DTYPE_BF16X3):
-    """forward-form product y (O) = w (O, I) . x (I) on K18?  (the data gradient asks with O and I exchanged)"""
+    """forward-form product y (O) = w (O, I) . x (I) on K18?  (the data gradient asks with O and I exchanged.)  A contraction that is
+    not a multiple of 16 runs on zero-padded weight columns (mlagg_conv1x1_fwd_ragged)."""
+    I16 = -(-I // 16) * 16
+    if not bool(_lib.lib().mlagg_conv1x1_supported(O, I16, P)):
+        return False
     if form != _DTYPE_BF16X3:                # one product per block: a stream of the maps, ahead of cast + library + cast wherever it runs
-        return P >= LP_K_MIN_PIXELS and bool(_lib.lib().mlagg_conv1x1_supported(O, I, P))
-    return P >= K18_FWD_MIN_PIXELS and I >= K18_FWD_MIN_K and bool(_lib.lib().mlagg_conv1x1_supported(O, I, P))
+        return P >= LP_K_MIN_PIXELS and (I == I16 or K18_THIN)
+    if K18_THIN and P >= K18_FWD_MIN_PIXELS and min(O, I) <= K18_THIN_CH:
+        # a thin side (the 14-class heads and their data gradients): one pass over the wide map, where the library's GEMM kernels
+        # took 101 us forward / 261 us backward for 48 -> 14 channels at 256 x 256 (profiles/round4_i_library_convolutions_by_shape.md)
+        return True
+    return I == I16 and P >= K18_FWD_MIN_PIXELS and I >= K18_FWD_MIN_K
+
+
+def _conv1x1_k18(x, xb, w, y, B, O, I, P, form):
+    """y (B, O, P) = w (O, I) . x (B, I, P) on K18; a contraction that is not a multiple of 16 on zero-padded weight columns."""
+    I16 = -(-I // 16) * 16
+    if I16 != I:
+        wp = torch.zeros(O, I16, device=w.device, dtype=torch.float32)
+        wp[:, :I] = w
+        w = wp
+    _lib.check(_lib.lib().mlagg_conv1x1_fwd_ragged(_ptr(x), xb, _ptr(w), None, _ptr(y), O * P, B, O, I16, I, P, form, _stream()),
+               "mlagg_conv1x1_fwd_ragged")
 
 
 class Conv1x1Fn(torch.autograd.Function):
@@ -2106,8 +2129,7 @@ class Conv1x1Fn(torch.autograd.Function):
         if _k18_product(O, I, P, form):
             y = torch.empty((B, O) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
             _flop("K18", 2 * B * O * I * P)
-            _lib.check(_lib.lib().mlagg_conv1x1_fwd_lp(_ptr(x), xb, _ptr(w), None, _ptr(y), O * P, B, O, I, P, form, _stream()),
-                       "mlagg_conv1x1_fwd_lp")
+            _conv1x1_k18(x, xb, w, y, B, O, I, P, form)
         else:
             y = _lib_conv_fwd(x, weight, 0, form)
         ctx.save_for_backward(x, w)
@@ -2130,8 +2152,7 @@ class Conv1x1Fn(torch.autograd.Function):
                 wt = transpose_2d(w.unsqueeze(0))[0]                                   # (I, O): the contraction runs along its rows
                 dx = torch.empty((B, I) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
                 _flop("K18", 2 * B * O * I * P)
-                _lib.check(lib.mlagg_conv1x1_fwd_lp(_ptr(dy), dyb, _ptr(wt), None, _ptr(dx), I * P, B, I, O, P, form, _stream()),
-                           "mlagg_conv1x1_fwd_lp")
+                _conv1x1_k18(dy, dyb, wt, dx, B, I, O, P, form)
             else:
                 dx = _lib_conv_bwd(dy, x, w.view(ctx.wshape), 0, (True, False, False), form)[0]
         if ctx.needs_input_grad[1]:

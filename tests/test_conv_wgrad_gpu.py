@@ -101,12 +101,14 @@ def test_conv_taps_forward_and_gradients_match_torch(B, I, O, dims, k):
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,I,O,H,W,sliced", [(2, 96, 192, 32, 32, False), (3, 192, 96, 16, 24, True), (2, 48, 96, 24, 20, False),
                                               (1, 384, 768, 8, 12, False), (2, 96, 14, 16, 16, False), (2, 768, 384, 16, 7 * 16, True),
-                                              (2, 48, 40, 10, 16, False)])
+                                              (2, 48, 40, 10, 16, False), (2, 1, 48, 32, 32, False), (2, 24, 48, 16, 16, True),
+                                              (1, 14, 48, 12, 16, False)])
 def test_conv1x1_matches_float64(monkeypatch, B, I, O, H, W, sliced):
     """K18 (1 x 1 convolution on the 16-bit matrix instructions, fp32 operands as three bf16 pieces): output, data gradient and
     weight gradient against float64 conv2d, at the error of an fp32 GEMM.  Cases: channel counts off the 96-wide groups, pixel
     counts that are not multiples of 96 (clamped lanes), a channel-slice input (sample stride > C * P), and an output width (14,
-    40) whose data gradient has a contraction that is not a multiple of 16 (library fallback for that gradient only)."""
+    40) whose data gradient has a contraction that is not a multiple of 16, and inputs of 1 / 24 / 14 channels (the stem, a head's
+    data gradient): ragged contractions run on zero-padded weight columns (mlagg_conv1x1_fwd_ragged)."""
     from mlagg_unet_amd import ops
     for name, v in (("K18_FWD_MIN_PIXELS", 0), ("K18_FWD_MIN_K", 16), ("K18_WGRAD_MIN_PIXELS", 0)):      # every product on K18
         monkeypatch.setattr(ops, name, v)
@@ -136,7 +138,8 @@ def test_conv1x1_dispatch_rules_and_large_map():
     assert ops.conv1x1_supported(x, w, (1, 1), (0, 0), (1, 1), 1) and ops._k18_product(192, 96, 128 * 128) and ops._k18_product(96, 192, 128 * 128)
     assert not ops.conv1x1_supported(x, w, (2, 2), (0, 0), (1, 1), 1)                   # strided
     assert not ops.conv1x1_supported(x[:, :, :32, :32], w, (1, 1), (0, 0), (1, 1), 1)    # 1024 pixels: the library is faster
-    assert not ops._k18_product(48, 24, 128 * 128)                                      # contraction 24: not a multiple of 16
+    assert ops._k18_product(48, 24, 128 * 128) and ops._k18_product(14, 48, 256 * 256) and ops._k18_product(48, 14, 256 * 256)   # thin sides
+    assert not ops._k18_product(48, 48, 128 * 128) and not ops._k18_product(96, 72, 128 * 128)     # short contraction / not a multiple of 16
     gy = torch.randn(2, 192, 128, 128, device=DEV)
     xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
     yr = F.conv2d(xr, wr)
