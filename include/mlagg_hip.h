@@ -382,6 +382,10 @@ int mlagg_scaled_residual(const float *skip, const float *branch, const float *s
  * elements apart (0 = R * C; a channel slice of an NCHW map has a larger one): the NCHW <-> token-major flips
  * (`x.flatten(2).transpose(1, 2)` / its inverse at nnUNetTrainer_MLAgg_2D_dt_MS.py:878-880, 910; MambaSkip.py:727-733, 747-751). */
 int mlagg_transpose_2d(const float *src, long src_batch_stride, float *dst, int batch, int R, int C, void *stream);
+/* pixel_shuffle2: dst (B, O, 2 H, 2 W)[b][o][2 i + a][2 j + c] = src (B, 4 O, H, W)[b][(2 a + c) O + o][i][j]; inverse != 0: the other
+ * way round (src is the (B, O, 2 H, 2 W) map).  Around K18 this is the kernel-2 / stride-2 transposed convolution of UnetrUpBlock
+ * (nnUNetTrainer_MLAgg_2D_dt_MS.py:1340-1368) and its backward.  W even, both pointers 16-byte aligned, contiguous maps. */
+int mlagg_pixel_shuffle2(const float *src, float *dst, int B, int O, int H, int W, int inverse, void *stream);
 /* Bias gradients.  channel_sum: out[c] = sum over batch and pixels of an NCHW gradient map g (B, C, HW) -- the bias gradient of
  * the convolutions around the path (torch computes it with a generic reduction inside convolution_backward); workspace:
  * mlagg_channel_sum_workspace_floats(B, C) floats.  column_sum: out[c] = sum_r x[r][c], x (rows, cols) at row stride x_stride --

@@ -196,6 +196,60 @@ extern "C" int mlagg_transpose_2d(const float *src, long src_batch_stride, float
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Pixel shuffle by 2 (round 4): y[b][o][2 i + a][2 j + c] = z[b][(2 a + c) O + o][i][j] and its inverse -- what turns the
+// kernel-2 / stride-2 transposed convolution of the decoder (`get_conv_layer(..., kernel_size=2, stride=2, is_transposed=True)` in
+// UnetrUpBlock, nnUNetTrainer_MLAgg_2D_dt_MS.py:1340-1368 via MONAI) into ONE pointwise product with 4 O output channels on K18:
+// the taps of that convolution do not overlap, so output pixel (2 i + a, 2 j + c) is tap (a, c) applied to input pixel (i, j).
+// A thread owns two input pixels: four 8-byte reads (one per tap plane), two 16-byte writes (output rows 2 i and 2 i + 1).
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+template <bool INVERSE>
+__global__ void __launch_bounds__(256)
+pixel_shuffle2_kernel(const float *__restrict__ src, float *__restrict__ dst, int O, int H, int W)
+{
+    const int w2 = W >> 1;                                          // pixel pairs per input row
+    const long n = (long)O * H * w2;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int b = blockIdx.y;
+    const int jp = (int)(idx % w2), i = (int)((idx / w2) % H), o = (int)(idx / ((long)w2 * H));
+    const size_t plane = (size_t)H * W;
+    // z (B, 4 O, H, W), y (B, O, 2 H, 2 W)
+    const size_t zoff = ((size_t)b * 4 * O + o) * plane + (size_t)i * W + 2 * jp;
+    const size_t yoff = (((size_t)b * O + o) * 2 * H + 2 * i) * (2 * (size_t)W) + 4 * jp;
+    if (!INVERSE) {
+        float2 t[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = *reinterpret_cast<const float2 *>(src + zoff + (size_t)q * O * plane);
+        *reinterpret_cast<float4 *>(dst + yoff) = make_float4(t[0].x, t[1].x, t[0].y, t[1].y);
+        *reinterpret_cast<float4 *>(dst + yoff + 2 * (size_t)W) = make_float4(t[2].x, t[3].x, t[2].y, t[3].y);
+    } else {
+        const float4 r0 = *reinterpret_cast<const float4 *>(src + yoff), r1 = *reinterpret_cast<const float4 *>(src + yoff + 2 * (size_t)W);
+        *reinterpret_cast<float2 *>(dst + zoff) = make_float2(r0.x, r0.z);
+        *reinterpret_cast<float2 *>(dst + zoff + (size_t)O * plane) = make_float2(r0.y, r0.w);
+        *reinterpret_cast<float2 *>(dst + zoff + 2 * (size_t)O * plane) = make_float2(r1.x, r1.z);
+        *reinterpret_cast<float2 *>(dst + zoff + 3 * (size_t)O * plane) = make_float2(r1.y, r1.w);
+    }
+}
+}  // namespace
+
+extern "C" int mlagg_pixel_shuffle2(const float *src, float *dst, int B, int O, int H, int W, int inverse, void *stream)
+{
+    if (!src || !dst) return MLAGG_E_NULLPTR;
+    if (B <= 0 || B > 65535 || O <= 0 || H <= 0 || W <= 0 || (W & 1)) return MLAGG_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) return MLAGG_E_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MLAGG_TIMED(K_TRANSPOSE, st);
+    const long n = (long)O * H * (W >> 1);
+    const dim3 grid((unsigned)((n + 255) / 256), B);
+    if (inverse)
+        hipLaunchKernelGGL(pixel_shuffle2_kernel<true>, grid, dim3(256), 0, st, src, dst, O, H, W);
+    else
+        hipLaunchKernelGGL(pixel_shuffle2_kernel<false>, grid, dim3(256), 0, st, src, dst, O, H, W);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Bias gradients.  channel_sum: out[c] = sum_{b, p} g[b][c][p] of an NCHW map (what convolution backward needs for its bias;
 // ATen's generic reduction runs these at 1.3-2 TB/s: 49 us for 63 MB).  column_sum: out[c] = sum_r x[r][c] of a row-major
 // matrix (the bias gradient of the small-M Linear layers that go to the library GEMM).

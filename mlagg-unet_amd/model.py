@@ -225,14 +225,21 @@ class ConvTranspose2d(_ConvMixin, nn.ConvTranspose2d):
         return (ops.K18_THIN and self._pointwise() and ops.conv1x1_supported(x, self.weight, (1, 1), (0, 0), (1, 1), 1, form)
                 and ops._k18_product(O, I, P, form) and ops._k18_product(I, O, P, form))
 
+    def _t2(self, x, form):
+        return ops.conv_t2x2_supported(x, self.weight, self.stride, self.padding, self.output_padding, self.dilation, self.groups, form)
+
     def _fp32_conv(self, x):
         if self._k18(x, ops._DTYPE_BF16X3):
             return ops.conv1x1(x, self.weight.permute(1, 0, 2, 3))
+        if self._t2(x, ops._DTYPE_BF16X3):
+            return ops.conv_t2x2(x, self.weight)                     # K18 + pixel shuffle
         return self._lib_conv(x, self.weight)
 
     def _lp_conv(self, x, form):
         if self._k18(x, form):
             return ops.conv1x1(x, self.weight.permute(1, 0, 2, 3), form)
+        if self._t2(x, form):
+            return ops.conv_t2x2(x, self.weight, form)
         return None
 
     def _eager(self, x):

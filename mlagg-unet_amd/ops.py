@@ -2166,6 +2166,79 @@ class Conv1x1Fn(torch.autograd.Function):
         return dx, dW, None
 
 
+CONVT2 = _os.environ.get("MLAGG_CONVT2", "1") == "1"
+
+
+def _pixel_shuffle2(src, B, O, H, W, inverse):
+    """(B, 4 O, H, W) -> (B, O, 2 H, 2 W), or back (inverse)."""
+    src = _require(src.contiguous(), "src")
+    dst = torch.empty((B, 4 * O, H, W) if inverse else (B, O, 2 * H, 2 * W), device=src.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mlagg_pixel_shuffle2(_ptr(src), _ptr(dst), B, O, H, W, int(inverse), _stream()), "mlagg_pixel_shuffle2")
+    return dst
+
+
+class ConvT2x2Fn(torch.autograd.Function):
+    """y = conv_transpose2d(x, W (I, O, 2, 2), stride 2): the taps do not overlap, so it is the pointwise product with the (4 O, I) matrix
+    [tap (a, c)][o][i] = W[i][o][a][c] on K18 followed by a pixel shuffle; backward: the inverse shuffle of dy, then K18's data
+    gradient (contraction 4 O) and weight gradient.  (The library ran this layer of the 256 x 256 step in 215 us forward + 350 us
+    backward: profiles/round4_i_library_convolutions_by_shape.md.)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, form=_DTYPE_BF16X3):
+        x, xb, P = _planes(x, "x")
+        B, I, H, W = x.shape
+        O = weight.shape[1]
+        w4 = _require(weight.permute(2, 3, 1, 0).reshape(4 * O, I).contiguous(), "weight")
+        z = torch.empty(B, 4 * O, H, W, device=x.device, dtype=torch.float32)
+        _flop("K18", 2 * B * 4 * O * I * P)
+        _conv1x1_k18(x, xb, w4, z, B, 4 * O, I, P, form)
+        ctx.save_for_backward(x, w4)
+        ctx.form, ctx.O = form, O
+        ctx.leaf, ctx.leaf_params = _leaf_ok(weight), [weight]
+        note_leaf_use(weight)
+        return _pixel_shuffle2(z, B, O, H, W, False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w4 = ctx.saved_tensors
+        B, I, H, W = x.shape
+        O, form, P = ctx.O, ctx.form, H * W
+        lib = _lib.lib()
+        dyu = _pixel_shuffle2(dy, B, O, H, W, True)                                   # (B, 4 O, H, W)
+        dx = dW = None
+        if ctx.needs_input_grad[0]:
+            wt = transpose_2d(w4.unsqueeze(0))[0]                                      # (I, 4 O)
+            dx = torch.empty(B, I, H, W, device=x.device, dtype=torch.float32)
+            _flop("K18", 2 * B * 4 * O * I * P)
+            _conv1x1_k18(dyu, 4 * O * P, wt, dx, B, I, 4 * O, P, form)
+        if ctx.needs_input_grad[1]:
+            with _LeafStream(dyu, x, ok=ctx.leaf and leaf_single_use(ctx.leaf_params)):
+                dW4 = torch.empty(4 * O, I, device=x.device, dtype=torch.float32)
+                ws = torch.empty(lib.mlagg_conv1x1_wgrad_workspace_floats(B, 4 * O, I, P), device=x.device, dtype=torch.float32)
+                _flop("K18", 2 * B * 4 * O * I * P)
+                _lib.check(lib.mlagg_conv1x1_wgrad_lp(_ptr(dyu), 4 * O * P, _ptr(x), x.stride(0), _ptr(dW4), _ptr(ws), B, 4 * O, I, P, form,
+                                                      _stream()), "mlagg_conv1x1_wgrad_lp")
+                dW = dW4.view(2, 2, O, I).permute(3, 2, 0, 1).contiguous()
+        return dx, dW, None
+
+
+def conv_t2x2_supported(x, weight, stride, padding, output_padding, dilation, groups, form=_DTYPE_BF16X3):
+    """A kernel-2 / stride-2 transposed convolution (no padding) on an fp32 device map whose three products K18 takes."""
+    if not (CONVT2 and K18 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and groups == 1):
+        return False
+    if tuple(weight.shape[2:]) != (2, 2) or any(int(v) != 2 for v in stride) or any(int(v) != 0 for v in padding) or \
+            any(int(v) != 0 for v in output_padding) or any(int(v) != 1 for v in dilation):
+        return False
+    I, O = int(weight.shape[0]), int(weight.shape[1])
+    H, W = int(x.shape[2]), int(x.shape[3])
+    P = H * W
+    return W % 2 == 0 and P % 16 == 0 and _k18_product(4 * O, I, P, form) and _k18_product(I, 4 * O, P, form)
+
+
+def conv_t2x2(x, weight, form=_DTYPE_BF16X3):
+    return ConvT2x2Fn.apply(x, weight, form)
+
+
 def conv1x1_supported(x, weight, stride, padding, dilation, groups, form=_DTYPE_BF16X3):
     """A 1 x 1, stride-1, dense convolution on an fp32 device map whose weight gradient (at least) runs on K18 in operand form `form`."""
     if not (K18 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and groups == 1):

@@ -182,6 +182,32 @@ def test_conv3x3_matches_float64(monkeypatch, B, I, O, H, W, sliced):
         assert err < tol, (name, err)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,I,O,H,W", [(2, 96, 48, 32, 32), (1, 48, 20, 16, 24), (3, 32, 8, 8, 16)])
+def test_transposed_2x2_stride2_convolution_on_k18(monkeypatch, B, I, O, H, W):
+    """ops.conv_t2x2 (K18 on the (4 O, I) tap matrix + pixel shuffle; UnetrUpBlock's transposed convolution, T:1340-1368) against
+    float64 conv_transpose2d: output, data gradient, weight gradient."""
+    from mlagg_unet_amd import ops
+    for name, v in (("K18_FWD_MIN_PIXELS", 0), ("K18_FWD_MIN_K", 16)):
+        monkeypatch.setattr(ops, name, v)
+    g = torch.Generator().manual_seed(B * I + O)
+    x = torch.randn(B, I, H, W, generator=g).to(DEV)
+    w = (torch.randn(I, O, 2, 2, generator=g) * I ** -0.5).to(DEV)
+    gy = torch.randn(B, O, 2 * H, 2 * W, generator=g).to(DEV)
+    assert ops.conv_t2x2_supported(x, w, (2, 2), (0, 0), (0, 0), (1, 1), 1)
+    assert not ops.conv_t2x2_supported(x, w, (2, 2), (1, 1), (0, 0), (1, 1), 1) and not ops.conv_t2x2_supported(x, w[..., :1], (2, 2), (0, 0), (0, 0), (1, 1), 1)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, None, 2)
+    yr.backward(gy.double())
+    xp, wp = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yp = ops.conv_t2x2(xp, wp)
+    yp.backward(gy)
+    for name, got, want in (("y", yp, yr), ("dx", xp.grad, xr.grad), ("dW", wp.grad, wr.grad)):
+        assert got.shape == want.shape, name
+        err = float((got.detach().double() - want.detach()).abs().max() / want.detach().abs().max())
+        assert err < 2e-6, (name, err)
+
+
 def _rounded_products(x, w, gy, pad, t):
     """The three products of a stride-1 convolution as the reference's autocast step computes them (nnUNetTrainer.py:848): operands
     rounded to the 16-bit type `t`, exact sums (float64 here; the kernels sum in fp32)."""
