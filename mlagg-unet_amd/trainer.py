@@ -339,7 +339,7 @@ class BucketedGradSync:
     ``finish()`` -- called by ``train_step`` after backward -- waits for the exchanges and points every ``p.grad`` at its slice of
     the averaged buffer (no scatter copy: the optimizer reads the gradients where the collective left them)."""
 
-    def __init__(self, module, bucket_cap_mb=25, first_bucket_mb=1, group=None):
+    def __init__(self, module, bucket_cap_mb=25, first_bucket_mb=1, group=None, last_bucket_mb=2):
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.world = dist.get_world_size(group)
@@ -356,16 +356,25 @@ class BucketedGradSync:
             for p in params:
                 p.copy_(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
-        self._caps = (int(first_bucket_mb * (1 << 20)) // 4, int(bucket_cap_mb * (1 << 20)) // 4)
+        self._caps = (int(first_bucket_mb * (1 << 20)) // 4, int(bucket_cap_mb * (1 << 20)) // 4, int(last_bucket_mb * (1 << 20)) // 4)
         self._arrival, self._rebuilt = [], False
         self._plan(list(reversed(params)))
         for p in params:
             p.register_post_accumulate_grad_hook(self._on_grad)
 
     def _plan(self, ordered):
-        """Cut ``ordered`` (parameters in the order their gradients arrive) into buckets."""
+        """Cut ``ordered`` (parameters in the order their gradients arrive) into buckets.  The gradients that arrive LAST -- the stem
+        and the first encoder stage -- get a small bucket of their own: the exchange of the final bucket is the part of the
+        collective that no backward kernel can hide, and with 25 MB buckets it carried whatever arrived in the last third of
+        backward (enqueued at 97 % of it: profiles/round4_j_ddp_bucket_timeline.md)."""
         self.buckets, cur, n = [], [], 0
         cap = self._caps[0]
+        tail, tn = [], 0
+        tail_cap = min(self._caps[2], self._caps[1] // 4)
+        while len(ordered) > 1 and tn + ordered[-1].numel() <= tail_cap:
+            tail.insert(0, ordered[-1])
+            tn += ordered[-1].numel()
+            ordered = ordered[:-1]
         for p in ordered:
             cur.append(p)
             n += p.numel()
@@ -374,6 +383,8 @@ class BucketedGradSync:
                 cur, n, cap = [], 0, self._caps[1]
         if cur:
             self._close(cur, n)
+        if tail:
+            self._close(tail, tn)
         self._where = {}
         for bi, b in enumerate(self.buckets):
             for p in b["params"]:
