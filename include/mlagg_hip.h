@@ -386,6 +386,8 @@ int mlagg_transpose_2d(const float *src, long src_batch_stride, float *dst, int 
  * way round (src is the (B, O, 2 H, 2 W) map).  Around K18 this is the kernel-2 / stride-2 transposed convolution of UnetrUpBlock
  * (nnUNetTrainer_MLAgg_2D_dt_MS.py:1340-1368) and its backward.  W even, both pointers 16-byte aligned, contiguous maps. */
 int mlagg_pixel_shuffle2(const float *src, float *dst, int B, int O, int H, int W, int inverse, void *stream);
+/* ... the inverse with the (B, O, 2 H, 2 W) source a channel slice of a wider map: src_batch floats between samples (0: contiguous) */
+int mlagg_pixel_unshuffle2_strided(const float *src, long src_batch, float *dst, int B, int O, int H, int W, void *stream);
 /* Bias gradients.  channel_sum: out[c] = sum over batch and pixels of an NCHW gradient map g (B, C, HW) -- the bias gradient of
  * the convolutions around the path (torch computes it with a generic reduction inside convolution_backward); workspace:
  * mlagg_channel_sum_workspace_floats(B, C) floats.  column_sum: out[c] = sum_r x[r][c], x (rows, cols) at row stride x_stride --
@@ -540,6 +542,11 @@ size_t mlagg_plane_norm_bwd_workspace_floats(int B, int C, long HW);
 int mlagg_plane_norm_bwd(const void *x, const void *dy, const float *gamma, const float *beta, const void *res, const float *stats,
                          void *dx, void *dres, float *dgamma, float *dbeta, float *workspace, int B, int C, long HW, int act,
                          float slope, int x_dtype, int dy_dtype, int res_dtype, void *stream);
+/* ... with dy a channel slice of a wider map (the halves of `torch.cat([up, skip], 1)`'s gradient, T:1360-1366): dy_batch elements
+ * between samples, a multiple of HW (0: contiguous) -- no copy of the slice in front of the kernel. */
+int mlagg_plane_norm_bwd_strided(const void *x, const void *dy, long dy_batch, const float *gamma, const float *beta, const void *res,
+                                 const float *stats, void *dx, void *dres, float *dgamma, float *dbeta, float *workspace, int B, int C,
+                                 long HW, int act, float slope, int x_dtype, int dy_dtype, int res_dtype, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K4lp: pooled differential attention on the 16-bit matrix cores (fp32 tensors in memory; q * scale, k, v, the softmax weights and

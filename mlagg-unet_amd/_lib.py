@@ -86,6 +86,7 @@ SIGNATURES = {
     "mlagg_plane_norm_fwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _I, _I, ctypes.c_long, ctypes.c_float, _I, ctypes.c_float, _I, _I, _I, _S]),
     "mlagg_plane_norm_bwd_workspace_floats": (_SZ, [_I, _I, ctypes.c_long]),
     "mlagg_plane_norm_bwd": (_I, [_F] * 11 + [_I, _I, ctypes.c_long, _I, ctypes.c_float, _I, _I, _I, _S]),
+    "mlagg_plane_norm_bwd_strided": (_I, [_F, _F, ctypes.c_long] + [_F] * 9 + [_I, _I, ctypes.c_long, _I, ctypes.c_float, _I, _I, _I, _S]),
     "mlagg_adamw_chunk_elements": (_I, []),
     "mlagg_adamw_clip_step": (_I, [_F, _F, _I, _F] + [ctypes.c_float] * 6 + [_I, _S]),
     "mlagg_adamw_clip_step_dev": (_I, [_F, _F, _I, _F, _F, _F] + [ctypes.c_float] * 5 + [_S]),
@@ -104,6 +105,7 @@ SIGNATURES = {
     "mlagg_conv3x3_wgrad": (_I, [_F, ctypes.c_long, _F, ctypes.c_long, _F, _F, _I, _I, _I, _I, _I, _S]),
     "mlagg_conv3x3_fwd_lp": (_I, [_F, ctypes.c_long, _F, _I, _F, _F, ctypes.c_long, _F, _I, _I, _I, _I, _I, _I, _S]),
     "mlagg_conv3x3_wgrad_lp": (_I, [_F, ctypes.c_long, _F, ctypes.c_long, _F, _F, _I, _I, _I, _I, _I, _I, _S]),
+    "mlagg_pixel_unshuffle2_strided": (_I, [_F, ctypes.c_long, _F, _I, _I, _I, _I, _S]),
     "mlagg_pixel_shuffle2": (_I, [_F, _F, _I, _I, _I, _I, _I, _S]),
     "mlagg_conv1x1_fwd_ragged": (_I, [_F, ctypes.c_long, _F, _F, _F, ctypes.c_long, _I, _I, _I, _I, ctypes.c_long, _I, _S]),
     "mlagg_conv1x1_fwd_lp": (_I, [_F, ctypes.c_long, _F, _F, _F, ctypes.c_long, _I, _I, _I, ctypes.c_long, _I, _S]),

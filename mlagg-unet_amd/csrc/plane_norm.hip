@@ -74,6 +74,7 @@ struct PNB {                 // backward operands
     int xdt, gdt, rdt, C, act;
     long HW;
     float slope;
+    long dy_skip;            // planes between the last channel of a sample of dy and the first of the next (dy = a channel slice of a wider map)
 };
 
 // streaming forward: three passes over the plane (the second and third from L2); VEC: HW % 4 == 0 and aligned planes
@@ -128,7 +129,7 @@ plane_norm_bwd_kernel(PNB a)
     const long plane = blockIdx.x, HW = a.HW;
     const int c = (int)(plane % a.C), act = a.act;
     const float slope = a.slope;
-    const void *xp = plane_ptr(a.x, plane, HW, a.xdt), *gp = plane_ptr(a.dy, plane, HW, a.gdt);
+    const void *xp = plane_ptr(a.x, plane, HW, a.xdt), *gp = plane_ptr(a.dy, plane + (plane / a.C) * a.dy_skip, HW, a.gdt);
     void *dp = plane_ptr(a.dx, plane, HW, a.xdt);
     const void *rp = RES ? plane_ptr(a.res, plane, HW, a.rdt) : nullptr;
     void *drp = (RES && a.dres) ? plane_ptr(a.dres, plane, HW, a.rdt) : nullptr;
@@ -374,7 +375,7 @@ plane_split_bwd_kernel(PNB a, float *__restrict__ partial, int S)
     const float slope = a.slope;
     const float mean = a.stats[2 * plane], rstd = a.stats[2 * plane + 1];
     const float ga = a.gamma ? a.gamma[c] : 1.f, be = a.beta ? a.beta[c] : 0.f;
-    const void *xp = plane_ptr(a.x, plane, HW, a.xdt), *gp = plane_ptr(a.dy, plane, HW, a.gdt);
+    const void *xp = plane_ptr(a.x, plane, HW, a.xdt), *gp = plane_ptr(a.dy, plane + (plane / a.C) * a.dy_skip, HW, a.gdt);
     const void *rp = RES ? plane_ptr(a.res, plane, HW, a.rdt) : xp;
     void *dxp = plane_ptr(a.dx, plane, HW, a.xdt);
     void *drp = (RES && a.dres) ? plane_ptr(a.dres, plane, HW, a.rdt) : nullptr;
@@ -485,14 +486,26 @@ extern "C" int mlagg_plane_norm_bwd(const void *x, const void *dy, const float *
                                     const float *stats, void *dx, void *dres, float *dgamma, float *dbeta, float *workspace,
                                     int B, int C, long HW, int act, float slope, int x_dtype, int dy_dtype, int res_dtype, void *stream)
 {
+    return mlagg_plane_norm_bwd_strided(x, dy, 0, gamma, beta, res, stats, dx, dres, dgamma, dbeta, workspace, B, C, HW, act, slope, x_dtype,
+                                        dy_dtype, res_dtype, stream);
+}
+
+// the same with dy a channel slice of a wider map: dy_batch elements between samples (0 or C * HW: contiguous), a multiple of HW
+extern "C" int mlagg_plane_norm_bwd_strided(const void *x, const void *dy, long dy_batch, const float *gamma, const float *beta,
+                                            const void *res, const float *stats, void *dx, void *dres, float *dgamma, float *dbeta,
+                                            float *workspace, int B, int C, long HW, int act, float slope, int x_dtype, int dy_dtype,
+                                            int res_dtype, void *stream)
+{
     if (!x || !dy || !stats || !dx || ((dgamma || dbeta) && !workspace)) return MLAGG_E_NULLPTR;
     if (int rc = check(B, C, HW, act)) return rc;
+    if (dy_batch == 0) dy_batch = (long)C * HW;
+    if (dy_batch < (long)C * HW || dy_batch % HW) return MLAGG_E_UNSUPPORTED;
     if (!dtype_ok(x_dtype) || !dtype_ok(dy_dtype) || (res && !dtype_ok(res_dtype))) return MLAGG_E_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool vec = (HW & 3) == 0 && aligned(x, x_dtype) && aligned(dy, dy_dtype) && aligned(dx, x_dtype) &&
                      (!res || aligned(res, res_dtype)) && (!dres || aligned(dres, res_dtype));
     float *part = (dgamma || dbeta) ? workspace : nullptr;
-    PNB a{x, dy, res, dx, dres, gamma, beta, stats, part, x_dtype, dy_dtype, res_dtype, C, act, HW, slope};
+    PNB a{x, dy, res, dx, dres, gamma, beta, stats, part, x_dtype, dy_dtype, res_dtype, C, act, HW, slope, dy_batch / HW - C};
     const int S = vec ? split_segments(HW) : 0;
     if (S > 0) {
         if (!workspace) return MLAGG_E_WORKSPACE;

@@ -205,7 +205,7 @@ extern "C" int mlagg_transpose_2d(const float *src, long src_batch_stride, float
 namespace {
 template <bool INVERSE>
 __global__ void __launch_bounds__(256)
-pixel_shuffle2_kernel(const float *__restrict__ src, float *__restrict__ dst, int O, int H, int W)
+pixel_shuffle2_kernel(const float *__restrict__ src, float *__restrict__ dst, int O, int H, int W, long y_batch)
 {
     const int w2 = W >> 1;                                          // pixel pairs per input row
     const long n = (long)O * H * w2;
@@ -216,7 +216,7 @@ pixel_shuffle2_kernel(const float *__restrict__ src, float *__restrict__ dst, in
     const size_t plane = (size_t)H * W;
     // z (B, 4 O, H, W), y (B, O, 2 H, 2 W)
     const size_t zoff = ((size_t)b * 4 * O + o) * plane + (size_t)i * W + 2 * jp;
-    const size_t yoff = (((size_t)b * O + o) * 2 * H + 2 * i) * (2 * (size_t)W) + 4 * jp;
+    const size_t yoff = (size_t)b * y_batch + ((size_t)o * 2 * H + 2 * i) * (2 * (size_t)W) + 4 * jp;      // y_batch: floats between samples of y
     if (!INVERSE) {
         float2 t[4];
 #pragma unroll
@@ -242,10 +242,25 @@ extern "C" int mlagg_pixel_shuffle2(const float *src, float *dst, int B, int O, 
     MLAGG_TIMED(K_TRANSPOSE, st);
     const long n = (long)O * H * (W >> 1);
     const dim3 grid((unsigned)((n + 255) / 256), B);
+    const long yb = (long)O * 4 * H * W;
     if (inverse)
-        hipLaunchKernelGGL(pixel_shuffle2_kernel<true>, grid, dim3(256), 0, st, src, dst, O, H, W);
+        hipLaunchKernelGGL(pixel_shuffle2_kernel<true>, grid, dim3(256), 0, st, src, dst, O, H, W, yb);
     else
-        hipLaunchKernelGGL(pixel_shuffle2_kernel<false>, grid, dim3(256), 0, st, src, dst, O, H, W);
+        hipLaunchKernelGGL(pixel_shuffle2_kernel<false>, grid, dim3(256), 0, st, src, dst, O, H, W, yb);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mlagg_pixel_unshuffle2_strided(const float *src, long src_batch, float *dst, int B, int O, int H, int W, void *stream)
+{
+    if (!src || !dst) return MLAGG_E_NULLPTR;
+    const long yb = (long)O * 4 * H * W;
+    if (src_batch == 0) src_batch = yb;
+    if (B <= 0 || B > 65535 || O <= 0 || H <= 0 || W <= 0 || (W & 1) || src_batch < yb || (src_batch & 3)) return MLAGG_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) return MLAGG_E_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MLAGG_TIMED(K_TRANSPOSE, st);
+    const long n = (long)O * H * (W >> 1);
+    hipLaunchKernelGGL(pixel_shuffle2_kernel<true>, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, st, src, dst, O, H, W, src_batch);
     return (int)hipGetLastError();
 }
 

@@ -1965,6 +1965,26 @@ def _require_map(t, name, shape=None):
     return t
 
 
+SLICE_GRADS = _os.environ.get("MLAGG_SLICE_GRADS", "1") == "1"     # 0: copy channel-slice gradients before the kernels (the round-3 form)
+
+
+def _map_slice(t, name):
+    """A gradient map as the K10 / shuffle kernels can read it without a copy: (tensor, elements between samples) -- dense, or a channel
+    slice of a wider dense map (what ``torch.cat([a, b], 1)``'s backward hands to the producers of a and b); anything else is copied."""
+    if SLICE_GRADS and t.is_cuda and t.dim() >= 3 and not t.is_contiguous():
+        inner, want = 1, []
+        for v in reversed(t.shape[1:]):
+            want.append(inner)
+            inner *= int(v)
+        want.reverse()
+        plane = inner // int(t.shape[1])
+        if tuple(t.stride()[1:]) == tuple(want) and t.stride(0) >= inner and t.stride(0) % plane == 0 and t.stride(0) % 4 == 0 and \
+                t.data_ptr() % 16 == 0 and t.dtype in _DT_CODE:
+            return t, t.stride(0)
+    t = _require_map(t.contiguous(), name)
+    return t, 0
+
+
 class PlaneNormFn(torch.autograd.Function):
     """K10: per-(batch, channel)-plane normalisation of an NCHW map fused with what follows it: y = act(norm(x) + res)
     (GroupNorm(C, C); InstanceNorm2d + LeakyReLU; InstanceNorm2d(affine) + SiLU; the residual sum of the UnetResBlock).
@@ -1993,7 +2013,7 @@ class PlaneNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, gamma, beta, res, stats = ctx.saved_tensors
         act, slope = ctx.meta
-        dy = _require_map(dy.contiguous(), "dy")
+        dy, dyb = _map_slice(dy, "dy")
         B, C = x.shape[:2]
         hw = x.numel() // (B * C)
         lib = _lib.lib()
@@ -2004,9 +2024,10 @@ class PlaneNormFn(torch.autograd.Function):
         segmented = lib.mlagg_plane_norm_fwd_workspace_floats(B, C, hw) > 0
         ws = torch.empty(lib.mlagg_plane_norm_bwd_workspace_floats(B, C, hw), device=x.device, dtype=torch.float32) \
             if (dg is not None or db is not None or segmented) else None
-        _lib.check(lib.mlagg_plane_norm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(res), _ptr(stats), _ptr(dx), _ptr(dres),
-                                            _ptr(dg), _ptr(db), _ptr(ws), B, C, hw, act, slope, _DT_CODE[x.dtype], _DT_CODE[dy.dtype],
-                                            0 if res is None else _DT_CODE[res.dtype], _stream()), "mlagg_plane_norm_bwd")
+        _lib.check(lib.mlagg_plane_norm_bwd_strided(_ptr(x), _ptr(dy), dyb, _ptr(gamma), _ptr(beta), _ptr(res), _ptr(stats), _ptr(dx),
+                                                    _ptr(dres), _ptr(dg), _ptr(db), _ptr(ws), B, C, hw, act, slope, _DT_CODE[x.dtype],
+                                                    _DT_CODE[dy.dtype], 0 if res is None else _DT_CODE[res.dtype], _stream()),
+                   "mlagg_plane_norm_bwd_strided")
         return dx, dg, db, dres, None, None, None, None
 
 
@@ -2204,7 +2225,11 @@ class ConvT2x2Fn(torch.autograd.Function):
         B, I, H, W = x.shape
         O, form, P = ctx.O, ctx.form, H * W
         lib = _lib.lib()
-        dyu = _pixel_shuffle2(dy, B, O, H, W, True)                                   # (B, 4 O, H, W)
+        dy, dyb = _map_slice(dy, "dy")                                                # a half of cat([up, skip])'s gradient: read in place
+        if dy.dtype != torch.float32:
+            dy, dyb = dy.float(), 0
+        dyu = torch.empty(B, 4 * O, H, W, device=x.device, dtype=torch.float32)        # (B, 4 O, H, W)
+        _lib.check(lib.mlagg_pixel_unshuffle2_strided(_ptr(dy), dyb, _ptr(dyu), B, O, H, W, _stream()), "mlagg_pixel_unshuffle2_strided")
         dx = dW = None
         if ctx.needs_input_grad[0]:
             wt = transpose_2d(w4.unsqueeze(0))[0]                                      # (I, 4 O)

@@ -208,6 +208,35 @@ def test_transposed_2x2_stride2_convolution_on_k18(monkeypatch, B, I, O, H, W):
         assert err < 2e-6, (name, err)
 
 
+@pytest.mark.gpu
+def test_channel_slice_gradients_are_read_in_place():
+    """The halves of `torch.cat([up, skip], 1)`'s gradient (T:1360-1366) are channel slices of one map: K10's backward
+    (mlagg_plane_norm_bwd_strided) and the inverse pixel shuffle of the kernel-2 transposed convolution read them where they are;
+    results equal those from contiguous copies, bit for bit."""
+    from mlagg_unet_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, C, H, W = 2, 48, 16, 24
+    wide = torch.randn(B, 2 * C, 2 * H, 2 * W, generator=g).to(DEV)
+    x = torch.randn(B, C, 2 * H, 2 * W, generator=g).to(DEV)
+    gamma, beta = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    outs = []
+    for sl in (wide[:, C:], wide[:, C:].contiguous()):
+        xs, gs, bs = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        y = ops.plane_norm(xs, gs, bs, 1e-5, ops.ACT_LEAKY, 0.01)
+        y.backward(sl)
+        outs.append((xs.grad, gs.grad, bs.grad))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    xi = torch.randn(B, 96, H, W, generator=g).to(DEV)
+    wt = (torch.randn(96, C, 2, 2, generator=g) * 0.1).to(DEV)
+    outs = []
+    for sl in (wide[:, :C], wide[:, :C].contiguous()):
+        xs, ws = xi.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+        ops.conv_t2x2(xs, ws).backward(sl)
+        outs.append((xs.grad, ws.grad))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    assert ops._map_slice(wide[:, C:], "dy")[1] == wide.stride(0) and ops._map_slice(wide[:, :, ::2], "dy")[1] == 0     # rows skipped: copied
+
+
 def _rounded_products(x, w, gy, pad, t):
     """The three products of a stride-1 convolution as the reference's autocast step computes them (nnUNetTrainer.py:848): operands
     rounded to the 16-bit type `t`, exact sums (float64 here; the kernels sum in fp32)."""
