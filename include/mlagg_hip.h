@@ -382,6 +382,10 @@ int mlagg_scaled_residual(const float *skip, const float *branch, const float *s
  * elements apart (0 = R * C; a channel slice of an NCHW map has a larger one): the NCHW <-> token-major flips
  * (`x.flatten(2).transpose(1, 2)` / its inverse at nnUNetTrainer_MLAgg_2D_dt_MS.py:878-880, 910; MambaSkip.py:727-733, 747-751). */
 int mlagg_transpose_2d(const float *src, long src_batch_stride, float *dst, int batch, int R, int C, void *stream);
+/* ... with the results dst_batch_stride floats apart (0 = R * C): the gradient of a channel slice of an NCHW map written where the
+ * map's gradient lives (the halves of `x.split([48, C - 48], dim=1)` in MambaSkip.py:727-733 share one gradient buffer). */
+int mlagg_transpose_2d_into(const float *src, long src_batch_stride, float *dst, long dst_batch_stride, int batch, int R, int C,
+                            void *stream);
 /* pixel_shuffle2: dst (B, O, 2 H, 2 W)[b][o][2 i + a][2 j + c] = src (B, 4 O, H, W)[b][(2 a + c) O + o][i][j]; inverse != 0: the other
  * way round (src is the (B, O, 2 H, 2 W) map).  Around K18 this is the kernel-2 / stride-2 transposed convolution of UnetrUpBlock
  * (nnUNetTrainer_MLAgg_2D_dt_MS.py:1340-1368) and its backward.  W even, both pointers 16-byte aligned, contiguous maps. */

@@ -91,6 +91,7 @@ SIGNATURES = {
     "mlagg_adamw_clip_step": (_I, [_F, _F, _I, _F] + [ctypes.c_float] * 6 + [_I, _S]),
     "mlagg_adamw_clip_step_dev": (_I, [_F, _F, _I, _F, _F, _F] + [ctypes.c_float] * 5 + [_S]),
     "mlagg_transpose_2d": (_I, [_F, ctypes.c_long, _F, _I, _I, _I, _S]),
+    "mlagg_transpose_2d_into": (_I, [_F, ctypes.c_long, _F, ctypes.c_long, _I, _I, _I, _S]),
     "mlagg_conv3x3_supported": (_I, [_I, _I, _I, _I]),
     "mlagg_conv3x3_workspace_bytes": (_SZ, [_I, _I]),
     "mlagg_conv3x3_fwd": (_I, [_F, ctypes.c_long, _F, _I, _F, _F, ctypes.c_long, _F, _I, _I, _I, _I, _I, _S]),

@@ -129,13 +129,13 @@ constexpr int TT = 64;             // tile side
 constexpr int TTP = TT + 1;        // LDS pitch (conflict-free column reads)
 
 __global__ void __launch_bounds__(256)
-transpose_tile_kernel(const float *__restrict__ src, float *__restrict__ dst, int R, int Cc, long src_bstride)
+transpose_tile_kernel(const float *__restrict__ src, float *__restrict__ dst, int R, int Cc, long src_bstride, long dst_bstride)
 {
     __shared__ float tile[TT * TTP];
     const int b = blockIdx.z;
     const int r0 = blockIdx.y * TT, c0 = blockIdx.x * TT;
     const float *s = src + (size_t)b * src_bstride;
-    float *d = dst + (size_t)b * R * Cc;
+    float *d = dst + (size_t)b * dst_bstride;
     const int tid = threadIdx.x;
     const bool v_in = (Cc & 3) == 0, v_out = (R & 3) == 0;
     // load: 64 rows x 16 float4
@@ -181,9 +181,18 @@ transpose_tile_kernel(const float *__restrict__ src, float *__restrict__ dst, in
 
 extern "C" int mlagg_transpose_2d(const float *src, long src_batch_stride, float *dst, int batch, int R, int C, void *stream)
 {
+    return mlagg_transpose_2d_into(src, src_batch_stride, dst, 0, batch, R, C, stream);
+}
+
+// ... with the (C, R) results dst_batch_stride floats apart (0 = R * C): the transposed matrices land in a channel slice of a wider map
+extern "C" int mlagg_transpose_2d_into(const float *src, long src_batch_stride, float *dst, long dst_batch_stride, int batch, int R, int C,
+                                       void *stream)
+{
     if (!src || !dst) return MLAGG_E_NULLPTR;
     if (batch <= 0 || R <= 0 || C <= 0 || batch > 65535 || (R + TT - 1) / TT > 65535) return MLAGG_E_UNSUPPORTED;
     if (src_batch_stride == 0) src_batch_stride = (long)R * C;
+    if (dst_batch_stride == 0) dst_batch_stride = (long)R * C;
+    if (dst_batch_stride < (long)R * C || ((R & 3) == 0 && (dst_batch_stride & 3))) return MLAGG_E_UNSUPPORTED;
     // 16-byte row loads are used when C % 4 == 0: the batch stride must then keep rows 16-byte aligned
     if ((((uintptr_t)src | (uintptr_t)dst) & 15) != 0 || src_batch_stride < (long)R * C ||
         ((C & 3) == 0 && (src_batch_stride & 3)))
@@ -191,7 +200,7 @@ extern "C" int mlagg_transpose_2d(const float *src, long src_batch_stride, float
     hipStream_t st = static_cast<hipStream_t>(stream);
     MLAGG_TIMED(K_TRANSPOSE, st);
     hipLaunchKernelGGL(transpose_tile_kernel, dim3((C + TT - 1) / TT, (R + TT - 1) / TT, batch), dim3(256), 0, st, src, dst, R, C,
-                       src_batch_stride);
+                       src_batch_stride, dst_batch_stride);
     return (int)hipGetLastError();
 }
 

@@ -595,15 +595,21 @@ class _MapToTokens(torch.autograd.Function):
     114 us adds per use at stage 0."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, slot=None):
         B, C, h, w = x.shape
-        ctx.hw = (h, w)
+        ctx.hw, ctx.slot = (h, w), slot
         return _flip(x.reshape(B, C, h * w))
 
     @staticmethod
     def backward(ctx, g):
         B, N, C = g.shape
-        return _flip(g).view(B, C, *ctx.hw)
+        if ctx.slot is not None and g.is_cuda:
+            return ops.transpose_2d_into(g, ctx.slot.view()), None          # a piece of ops.split_planes: into the map's gradient buffer
+        return _flip(g).view(B, C, *ctx.hw), None
+
+
+def _map_to_tokens(x):
+    return _MapToTokens.apply(x, ops._claim(x) if x.is_cuda else None)
 
 
 class _TokensToMap(torch.autograd.Function):
@@ -921,8 +927,8 @@ class VSS_Conv_Block(nn.Module):  # reference M:669-753
         Ls = [h * w for h, w in HW]
         hd = self.hidden_dim
         # (B, L_cat, 48) token-major concatenation of the first 48 channels of every scale
-        halves = [t.split([hd, t.shape[1] - hd], dim=1) for t in inputs]       # (mamba 48 | conv rest) per scale
-        m = torch.cat([_MapToTokens.apply(mh) for mh, _ in halves], dim=1)
+        halves = [ops.split_planes(t, (hd, t.shape[1] - hd)) for t in inputs]  # (mamba 48 | conv rest) per scale; one gradient buffer per map
+        m = torch.cat([_map_to_tokens(mh) for mh, _ in halves], dim=1)
         m = self.drop_path.residual(m, self.self_attention(self.ln_1(m), HW, Ls))
         m = self.norm2(m)
         outs = []

@@ -487,13 +487,13 @@ class _GradSlot:
     total), so the split's backward hands that buffer on as it is instead of concatenating the pieces
     (``CatArrayBatchedCopy``: 40 launches, 0.79 ms of the 256 x 256 step in profiles/round2_d_kernel_trace_timed_region.md)."""
 
-    __slots__ = ("arena", "col0", "width", "claimed")
+    __slots__ = ("arena", "col0", "width", "claimed", "dim")
 
-    def __init__(self, arena, col0, width):
-        self.arena, self.col0, self.width, self.claimed = arena, col0, width, False
+    def __init__(self, arena, col0, width, dim=-1):
+        self.arena, self.col0, self.width, self.claimed, self.dim = arena, col0, width, False, dim
 
     def view(self):
-        return self.arena.buffer()[..., self.col0:self.col0 + self.width]
+        return self.arena.buffer().narrow(self.dim, self.col0, self.width)
 
 
 class _GradArena:
@@ -547,7 +547,62 @@ class SplitColsFn(torch.autograd.Function):
         return (buf, None) + (None,) * len(sizes)
 
 
+class SplitPlanesFn(torch.autograd.Function):
+    """``t.split(sizes, dim=1)`` of an NCHW map with ONE gradient buffer for the pieces (see split_planes)."""
+
+    @staticmethod
+    def forward(ctx, t, arena, *sizes):
+        ctx.arena, ctx.sizes = arena, sizes
+        return t.split(list(sizes), dim=1)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        arena, sizes = ctx.arena, ctx.sizes
+        buf = arena.buffer()
+        c0 = 0
+        for g, w in zip(grads, sizes):
+            dst = buf.narrow(1, c0, w)
+            if g is None:
+                dst.zero_()
+            elif g.data_ptr() != dst.data_ptr() or g.stride() != dst.stride():
+                dst.copy_(g)
+            c0 += w
+        arena.buf = None
+        return (buf, None) + (None,) * len(sizes)
+
+
 GRAD_ARENA = _os.environ.get("MLAGG_GRAD_ARENA", "1") == "1"
+PLANE_ARENA = _os.environ.get("MLAGG_PLANE_ARENA", "1") == "1"
+
+
+def split_planes(t, sizes):
+    """``t.split(sizes, dim=1)`` of an NCHW map whose pieces feed this package's kernels (the (mamba | conv) halves of the MSMM inputs,
+    MambaSkip.py:727-733): the same views, and the kernels' backward passes -- the token transpose, K19's data gradient -- write their
+    results into ONE (B, C, H, W) gradient buffer, which the split's backward hands on instead of concatenating the pieces
+    (``CatArrayBatchedCopy`` behind SplitWithSizesBackward: 163 us of the step).  A piece whose consumer cannot is copied into place."""
+    if not (PLANE_ARENA and GRAD_ARENA and t.is_cuda and t.requires_grad and torch.is_grad_enabled() and t.dim() == 4 and t.is_contiguous()
+            and t.dtype == torch.float32 and (t.shape[2] * t.shape[3]) % 4 == 0):
+        return t.split(list(sizes), dim=1)
+    arena = _GradArena(t.shape, t.device)
+    pieces = SplitPlanesFn.apply(t, arena, *sizes)
+    c0 = 0
+    for p_, w in zip(pieces, sizes):
+        p_._mlagg_slot = _GradSlot(arena, c0, w, dim=1)
+        c0 += w
+    return pieces
+
+
+def transpose_2d_into(src, dst):
+    """(B, R, C) -> dst (B, C, R...) whose samples are dense (C, R) blocks at any sample stride (a channel slice of an NCHW map)."""
+    _require(src, "src")
+    B, R, C = src.shape
+    if not (src.stride(2) == 1 and src.stride(1) == C and src.stride(0) >= R * C and src.data_ptr() % 16 == 0
+            and (C % 4 or src.stride(0) % 4 == 0)):
+        src = src.contiguous()
+    _lib.check(_lib.lib().mlagg_transpose_2d_into(_ptr(src), src.stride(0), _ptr(dst), dst.stride(0), B, R, C, _stream()),
+               "mlagg_transpose_2d_into")
+    return dst
+
 FUSED_RESIDUAL_NORM = _os.environ.get("MLAGG_FUSED_RESIDUAL_NORM", "1") == "1"
 
 
@@ -2307,13 +2362,13 @@ def _k19_product(O, I, H, W, form=_DTYPE_BF16X3):
     return K19 and H * W >= floor and bool(_lib.lib().mlagg_conv3x3_supported(O, I, H, W))
 
 
-def _conv3x3_k19(x, xb, w, transposed, O, I, H, W, form=_DTYPE_BF16X3):
+def _conv3x3_k19(x, xb, w, transposed, O, I, H, W, form=_DTYPE_BF16X3, out=None):
     lib = _lib.lib()
     B = x.shape[0]
-    y = torch.empty(B, O, H, W, device=x.device, dtype=torch.float32)
+    y = torch.empty(B, O, H, W, device=x.device, dtype=torch.float32) if out is None else out
     ws = torch.empty(lib.mlagg_conv3x3_workspace_bytes(O, I), device=x.device, dtype=torch.uint8)
     _flop("K19", 2 * 9 * B * O * I * H * W)
-    _lib.check(lib.mlagg_conv3x3_fwd_lp(_ptr(x), xb, _ptr(w), int(transposed), None, _ptr(y), O * H * W, _ptr(ws), B, O, I, H, W, form,
+    _lib.check(lib.mlagg_conv3x3_fwd_lp(_ptr(x), xb, _ptr(w), int(transposed), None, _ptr(y), y.stride(0), _ptr(ws), B, O, I, H, W, form,
                                         _stream()), "mlagg_conv3x3_fwd_lp")
     return y
 
@@ -2323,7 +2378,8 @@ class Conv3x3Fn(torch.autograd.Function):
     split-bf16 GEMMs straight on the NCHW maps) where it beats the library's Winograd kernels, the weight gradient on the library."""
 
     @staticmethod
-    def forward(ctx, x, weight, form=_DTYPE_BF16X3):
+    def forward(ctx, x, weight, form=_DTYPE_BF16X3, slot=None):
+        ctx.slot = slot
         x, xb, P = _planes(x, "x")
         B, I, H, W = x.shape
         O = weight.shape[0]
@@ -2348,7 +2404,8 @@ class Conv3x3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if _k19_product(I, O, H, W, form):
                 dy, dyb, _ = _planes(dy, "dy")
-                dx = _conv3x3_k19(dy, dyb, w, True, I, O, H, W, form)
+                out = ctx.slot.view() if ctx.slot is not None else None          # a piece of split_planes: written where the map's gradient lives
+                dx = _conv3x3_k19(dy, dyb, w, True, I, O, H, W, form, out)
             else:
                 dx = _lib_conv_bwd(dy, x, w, 1, (True, False, False), form)[0]
         if ctx.needs_input_grad[1]:
@@ -2365,7 +2422,7 @@ class Conv3x3Fn(torch.autograd.Function):
                 dyc = dy.contiguous()
                 with _LeafStream(dyc, x, w, ok=ctx.leaf and leaf_single_use(ctx.leaf_params)):
                     dW = _lib_conv_bwd(dyc, x, w, 1, (False, True, False), form)[1]
-        return dx, dW, None
+        return dx, dW, None, None
 
 
 def conv3x3_supported(x, weight, stride, padding, dilation, groups, form=_DTYPE_BF16X3):
@@ -2382,7 +2439,7 @@ def conv3x3_supported(x, weight, stride, padding, dilation, groups, form=_DTYPE_
 
 
 def conv3x3(x, weight, form=_DTYPE_BF16X3):
-    return Conv3x3Fn.apply(x, weight, form)
+    return Conv3x3Fn.apply(x, weight, form, _claim(x))
 
 
 K19_3D = _os.environ.get("MLAGG_K19_3D", "1") == "1"

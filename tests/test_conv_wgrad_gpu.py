@@ -237,6 +237,39 @@ def test_channel_slice_gradients_are_read_in_place():
     assert ops._map_slice(wide[:, C:], "dy")[1] == wide.stride(0) and ops._map_slice(wide[:, :, ::2], "dy")[1] == 0     # rows skipped: copied
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(32, 32), (8, 12)])
+def test_split_planes_hands_on_one_gradient_buffer(monkeypatch, H, W):
+    """ops.split_planes (the (mamba | conv) halves of the MSMM inputs, MambaSkip.py:727-733): the token transpose's and K19's backward
+    write into ONE (B, C, H, W) buffer, which is the split's gradient -- equal, bit for bit, to the concatenation autograd would build;
+    a piece whose consumer is a plain torch op is copied into place."""
+    from mlagg_unet_amd import model, ops
+    monkeypatch.setattr(ops, "K19_MIN_PIXELS", 0)
+    g = torch.Generator().manual_seed(H)
+    B, C, hd = 2, 96, 48
+    x0 = torch.randn(B, C, H, W, generator=g).to(DEV)
+    w = (torch.randn(C - hd, C - hd, 3, 3, generator=g) * 0.05).to(DEV)
+    gt, gy = torch.randn(B, H * W, hd, generator=g).to(DEV), torch.randn(B, C - hd, H, W, generator=g).to(DEV)
+    grads = []
+    for mode in ("arena", "plain", "torch consumer"):
+        xs, ws = x0.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        t = xs * 1.0
+        if mode == "plain":
+            a, b = t.split([hd, C - hd], dim=1)
+            tok, y = model._MapToTokens.apply(a), ops.Conv3x3Fn.apply(b, ws)
+        else:
+            a, b = ops.split_planes(t, (hd, C - hd))
+            assert a._mlagg_slot.dim == 1 and not a._mlagg_slot.claimed
+            tok = model._map_to_tokens(a)
+            y = ops.conv3x3(b, ws) if mode == "arena" else torch.nn.functional.conv2d(b, ws, None, 1, 1)
+            assert a._mlagg_slot.claimed and b._mlagg_slot.claimed == (mode == "arena")
+        ((tok * gt).sum() + (y * gy).sum()).backward()
+        grads.append((xs.grad, ws.grad))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    assert torch.equal(grads[2][0][:, :hd], grads[1][0][:, :hd])
+    assert float((grads[2][0][:, hd:] - grads[1][0][:, hd:]).abs().max()) < 1e-4 * float(grads[1][0].abs().max())
+
+
 def _rounded_products(x, w, gy, pad, t):
     """The three products of a stride-1 convolution as the reference's autocast step computes them (nnUNetTrainer.py:848): operands
     rounded to the 16-bit type `t`, exact sums (float64 here; the kernels sum in fp32)."""
