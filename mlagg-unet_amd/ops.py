@@ -2158,7 +2158,11 @@ def _planes(t, name):
 # (few, long-K tiles); the weight gradient wins from 64 x 64 up (80 vs 142, 70 vs 88, 150 vs 252 us).  Each of the three products
 # of a layer goes to the faster side.
 K18 = _os.environ.get("MLAGG_K18", "1") == "1"
-K18_FWD_MIN_PIXELS, K18_FWD_MIN_K, K18_WGRAD_MIN_PIXELS = 16384, 96, 4096
+# round 4: 64 x 64 maps too (a tie with the library in the step -- 34.61 vs 34.60 ms, profiles/round4_k_k18_thresholds_ab.log -- and no NHWC transposes);
+# 32 x 32 maps lose 0.3 ms
+K18_FWD_MIN_PIXELS = int(_os.environ.get("MLAGG_K18_FWD_MIN_PIXELS", "4096"))
+K18_FWD_MIN_K = int(_os.environ.get("MLAGG_K18_FWD_MIN_K", "96"))
+K18_WGRAD_MIN_PIXELS = int(_os.environ.get("MLAGG_K18_WGRAD_MIN_PIXELS", "4096"))
 
 
 K18_THIN = _os.environ.get("MLAGG_K18_THIN", "1") == "1"

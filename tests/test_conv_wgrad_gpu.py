@@ -156,7 +156,7 @@ def test_conv1x1_dispatch_rules_and_large_map():
 @pytest.mark.parametrize("B,I,O,H,W,sliced", [(2, 48, 48, 16, 16, False), (2, 96, 48, 12, 20, True), (1, 144, 144, 10, 10, False),
                                               (2, 16, 40, 9, 13, False), (1, 48, 96, 3, 32, False), (2, 32, 14, 24, 5, False),
                                               (1, 48, 48, 128, 128, False), (3, 48, 33, 6, 16, True), (2, 16, 16, 2, 48, False),
-                                              (2, 80, 48, 7, 64, False)])
+                                              (2, 80, 48, 7, 64, False), (1, 48, 48, 256, 256, False), (1, 96, 48, 256, 256, False)])
 def test_conv3x3_matches_float64(monkeypatch, B, I, O, H, W, sliced):
     """K19 (3 x 3 convolution as nine shifted split-bf16 GEMMs): output and data gradient against float64 conv2d at the error of an
     fp32 convolution.  Cases: widths that are not multiples of the lanes' pixel runs (runs straddle image rows), three-row images,

@@ -45,7 +45,8 @@ def test_weight_gradient_policy_reads_only_shapes():
     assert not ops._k19_wgrad(32, 32, 256, 256)          # below 48 channels: the library in fp32 ...
     assert ops._k19_wgrad(32, 32, 256, 256, 1)           # ... K19's one-product form in the 16-bit modes
     assert not ops._k19_wgrad(720, 720, 16, 16)          # 256 pixels
-    assert ops._k18_product(192, 96, 128 * 128) and not ops._k18_product(192, 96, 64 * 64) and not ops._k18_product(96, 48, 256 * 256)
+    assert ops._k18_product(192, 96, 128 * 128) and ops._k18_product(192, 96, 64 * 64) and not ops._k18_product(192, 96, 32 * 32)
+    assert not ops._k18_product(96, 48, 256 * 256)        # contraction 48 between two wide sides: the library's GEMM kernels
 
 
 def test_residual_norm_off_the_device_is_residual_then_norm():
