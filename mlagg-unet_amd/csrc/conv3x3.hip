@@ -104,17 +104,22 @@ conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ W
         row_ok[r] = (unsigned)(z0 + kz - 1) < (unsigned)g.D && (unsigned)(y0 + ky - 1) < (unsigned)g.H;
     }
     const bool left_ok = x0 > 0, right_ok = x0 + TP < g.W;
-    // addresses: wave-uniform base (sample, channel row) + per-lane 32-bit byte offset.  The pixel part is clamped into the plane:
-    // whenever a clamp is active the value is padding (source row outside the image, or the neighbour beyond the row's end)
-    const float *xb = X + (size_t)b * g.x_batch;                                     // + (16 blk + r) * P   (uniform)
+    // addresses: BUFFER loads (round 4) -- resource = the sample (base X + b x_batch, 2 GB of range), scalar offset = the channel row
+    // (16 blk + r) P (uniform), vector offset = the lane's 8 kh P + pixel part, fixed per kernel row.  Zero padding costs nothing in the
+    // loop: a lane whose source element is padding (source row outside the image, the neighbour beyond the row's end) carries an
+    // out-of-range vector offset for that kernel row, and the buffer load returns 0 for it.  (With global loads the loop spent 29 64-bit
+    // address additions and 24 selects per stage beside the 132 instructions of the split: 5.2 vector instructions per MFMA, matrix pipe
+    // 47 % busy on 96 -> 96 @ 128 x 128: profiles/round4_k_pmc_conv3x3_forward_96.md.)
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X + (size_t)b * g.x_batch), 0, 0x7fffffff, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
     unsigned offc[NR], offl[NR], offr[NR];                                            // run / left / right neighbour per kernel row
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int kz = NR == 9 ? r / 3 : 1, ky = NR == 9 ? r % 3 : r;
         const int q = pc + (kz - 1) * g.H * g.W + (ky - 1) * g.W;
-        offc[r] = 4u * (unsigned)(8 * kh * g.P + min(max(q, 0), g.P - TP));
-        offl[r] = 4u * (unsigned)(8 * kh * g.P + min(max(q - 1, 0), g.P - 1));
-        offr[r] = 4u * (unsigned)(8 * kh * g.P + min(max(q + TP, 0), g.P - 1));
+        offc[r] = row_ok[r] ? 4u * (unsigned)(8 * kh * g.P + q) : OOB;
+        offl[r] = (row_ok[r] && left_ok) ? 4u * (unsigned)(8 * kh * g.P + q - 1) : OOB;
+        offr[r] = (row_ok[r] && right_ok) ? 4u * (unsigned)(8 * kh * g.P + q + TP) : OOB;
     }
     const size_t img = (size_t)(3 * NR) * g.O * g.I;                                  // elements per weight image (piece)
     const size_t tstride = (size_t)g.O * g.I;
@@ -145,29 +150,31 @@ conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ W
     // x rows of stage s (= iteration s): buffer s & 1; the fetch of s + 1 is in flight while s is consumed
     auto xfetch = [&](FVec<TP> (&C)[8], float (&L)[8], float (&R)[8], int blk_, int ky) __attribute__((always_inline)) {
         const int blk = min(blk_, nblk - 1);                    // past the end: the last block again, dropped
-        const char *src = reinterpret_cast<const char *>(xb + (size_t)(16 * blk) * g.P);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const char *rowp = src + (size_t)r * 4u * (size_t)g.P;
-            C[r] = *reinterpret_cast<const FVec<TP> *>(rowp + (size_t)offc[ky]);
-            L[r] = *reinterpret_cast<const float *>(rowp + (size_t)offl[ky]);
-            R[r] = *reinterpret_cast<const float *>(rowp + (size_t)offr[ky]);
+            const unsigned so = 4u * (unsigned)((16 * blk + r) * g.P);               // bytes, uniform
+            if constexpr (TP == 1) {
+                C[r].v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, offc[ky], so, 0));
+            } else {
+                static_assert(TP == 2, "pixel runs of one or two");
+                // two dword loads (the second at instruction offset 4): this toolchain's __builtin_amdgcn_raw_buffer_load_b64 emits ONE
+                // buffer_load_dword and copies it into both halves (ROCm 7.2 hipcc; found by a structured-input test, round 4)
+                C[r].v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, offc[ky], so, 0));
+                C[r].v[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, offc[ky] + 4u, so, 0));
+            }
+            L[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, offl[ky], so, 0));
+            R[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, offr[ky], so, 0));
         }
     };
     auto consume = [&](const u32x4 *wst, const FVec<TP> (&C)[8], const float (&L)[8], const float (&R)[8], int ky)
                        __attribute__((always_inline)) {
         // source elements m = 0 .. TP + 1 (left neighbour, the run, right neighbour), three bf16 pieces each
         uint4 src[TP + 2][3];
-        const bool rok = row_ok[ky];
 #pragma unroll
         for (int m = 0; m < TP + 2; ++m) {
-            const bool ok = rok && (m == 0 ? left_ok : (m == TP + 1 ? right_ok : true));
-            float f[8];
+            float f[8];                                          // padding arrives as 0 (out-of-range buffer offsets)
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const float v = m == 0 ? L[r] : (m == TP + 1 ? R[r] : C[r].v[(m >= 1 && m <= TP) ? m - 1 : 0]);
-                f[r] = ok ? v : 0.f;
-            }
+            for (int r = 0; r < 8; ++r) f[r] = m == 0 ? L[r] : (m == TP + 1 ? R[r] : C[r].v[(m >= 1 && m <= TP) ? m - 1 : 0]);
             opmode::split8<DT>(f, src[m]);
         }
 #if K19_INTERLEAVE
@@ -799,6 +806,7 @@ int conv_fwd(const float *x, long x_batch, const float *w, int transposed, const
     if (B <= 0 || B > 65535 || O <= 0 || I <= 0 || (I % 16) || D <= 0 || H <= 0 || W <= 0 || P < 96 || P > K19_MAX_PLANE)
         return MLAGG_E_UNSUPPORTED;
     if (x_batch < (long)I * P || y_batch < (long)O * P || (reinterpret_cast<uintptr_t>(workspace) & 15)) return MLAGG_E_UNSUPPORTED;
+    if ((long)I * P * 4 >= (1L << 31) - 64) return MLAGG_E_UNSUPPORTED;      // a sample is one buffer resource: 2 GB of range
     C3Geom g{B, O, I, D, H, W, (int)P, x_batch, y_batch};
     hipStream_t st = static_cast<hipStream_t>(stream);
     MLAGG_TIMED(K_CONV3X3, st);
@@ -843,7 +851,9 @@ int conv_fwd(const float *x, long x_batch, const float *w, int transposed, const
 
 extern "C" int mlagg_conv3x3_supported(int O, int I, int H, int W)
 {
-    return O > 0 && I > 0 && (I % 16) == 0 && H > 0 && W > 0 && (long)H * W >= 96 && (long)H * W <= (1LL << 32) / 36 - 1;
+    // a sample of the input (I planes) is one buffer resource: under 2 GB
+    return O > 0 && I > 0 && (I % 16) == 0 && H > 0 && W > 0 && (long)H * W >= 96 && (long)H * W <= (1LL << 32) / 36 - 1 &&
+           (long)I * H * W * 4 < (1L << 31) - 64;
 }
 
 // bytes of the weight image: 3 pieces x 9 taps x O x I bf16
@@ -868,7 +878,8 @@ extern "C" int mlagg_conv3x3_fwd_lp(const float *x, long x_batch, const float *w
 // the same for 3 x 3 x 3 kernels on (B, C, D, H, W) volumes (nine kernel rows (kz, ky) of three taps each)
 extern "C" int mlagg_conv3x3x3_supported(int O, int I, int D, int H, int W)
 {
-    return O > 0 && I > 0 && (I % 16) == 0 && D > 0 && H > 0 && W > 0 && (long)D * H * W >= 96 && (long)D * H * W <= (1LL << 32) / 36 - 1;
+    return O > 0 && I > 0 && (I % 16) == 0 && D > 0 && H > 0 && W > 0 && (long)D * H * W >= 96 && (long)D * H * W <= (1LL << 32) / 36 - 1 &&
+           (long)I * D * H * W * 4 < (1L << 31) - 64;
 }
 
 extern "C" size_t mlagg_conv3x3x3_workspace_bytes(int O, int I) { return O > 0 && I > 0 ? (size_t)3 * 27 * O * I * 2 : 0; }

@@ -29,10 +29,12 @@ def test_convolution_kernels_decline_host_tensors_and_unsupported_geometries():
     assert lib.mlagg_conv3x3_supported(48, 48, 16, 16) and not lib.mlagg_conv3x3_supported(48, 1, 256, 256)            # the one-channel stem
     assert lib.mlagg_conv3x3_wgrad_supported(96, 48, 32, 32) and not lib.mlagg_conv3x3_wgrad_supported(96, 48, 30, 30)  # W % 8
     assert lib.mlagg_conv3x3x3_supported(32, 32, 8, 16, 16) and not lib.mlagg_conv3x3x3_supported(32, 1, 8, 16, 16)
-    # 32-bit lane offsets of up to 36 bytes per plane element: planes beyond 2^32 / 36 - 1 elements are refused, not wrapped
-    pmax = (1 << 32) // 36 - 1
+    # a sample of the input is one buffer resource with 32-bit byte offsets: I planes under 2 GB (and planes under 2^32 / 36 elements);
+    # larger ones are refused, not wrapped
+    pmax = ((1 << 29) - 17) // 16
     assert lib.mlagg_conv3x3_supported(16, 16, 1, pmax) and not lib.mlagg_conv3x3_supported(16, 16, 1, pmax + 1)
-    assert lib.mlagg_conv3x3x3_supported(16, 16, 492, 492, 492) and not lib.mlagg_conv3x3x3_supported(16, 16, 493, 493, 493)
+    assert lib.mlagg_conv3x3_supported(48, 16, 1, pmax) and not lib.mlagg_conv3x3_supported(16, 32, 1, pmax)
+    assert lib.mlagg_conv3x3x3_supported(16, 16, 320, 320, 320) and not lib.mlagg_conv3x3x3_supported(16, 16, 324, 324, 324)
     assert lib.mlagg_conv3x3x3_wgrad_supported(32, 32, 8, 16, 40) and not lib.mlagg_conv3x3x3_wgrad_supported(32, 32, 8, 16, 20)
     assert lib.mlagg_conv3x3_workspace_bytes(48, 96) == 3 * 9 * 48 * 96 * 2 and lib.mlagg_conv3x3x3_workspace_bytes(32, 32) == 3 * 27 * 32 * 32 * 2
     assert lib.mlagg_column_sum_workspace_floats(100, 64) == 0 and lib.mlagg_column_sum_workspace_floats(7840, 384) > 0
