@@ -70,7 +70,7 @@ constexpr int WAVES = 4;            // pixel groups per workgroup: they share th
 #endif
 // three workgroups per CU (three waves per SIMD, 168 registers) for the tiles that fit: the 64-row x 2-pixel tile sat at 169
 template <int TO, int TP, int NR, int DT>
-__global__ void __launch_bounds__(64 * WAVES, (K19_OCC3 && NR == 3 && TO * TP <= 4) ? 3 : 2)
+__global__ void __launch_bounds__(64 * WAVES, (K19_OCC3 && NR == 3 && TO <= 2 && TO * TP <= 4) ? 3 : 2)
 conv3x3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Wimg, const float *__restrict__ bias,
                float *__restrict__ Y, C3Geom g)
 {
