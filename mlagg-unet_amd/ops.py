@@ -1027,7 +1027,10 @@ def _mfma_rows(t, name):
 # nobody registered, on the fly.  MLAGG_K5_V2=0: the round-3 kernels + the library GEMM for short token counts.
 # ------------------------------------------------------------------------------------------------
 K5_V2 = _os.environ.get("MLAGG_K5_V2", "1") == "1"
-X3_MIN_ROWS = int(_os.environ.get("MLAGG_X3_MIN_ROWS", "16384"))     # below: the TUNED library GEMM (gemm_db) is still ahead in the step
+# end of round 4: stages 2 / 3 (10 240 / 2 560 tokens) too -- against the TUNED library GEMMs the kernel wins 11 of 16 products there
+# (tools/bench_linear_x3.py with BENCH_TUNED_GEMM=1) and the step 0.1-0.3 ms on two boxes (profiles/round4_m_x3_min_rows_ab.log); mid-round,
+# before the fused Mlp epilogues and the per-network image set, the same switch had lost 0.2 ms
+X3_MIN_ROWS = int(_os.environ.get("MLAGG_X3_MIN_ROWS", "2048"))
 _IMAGE_EPOCH = [0]              # bumped by whatever rewrites parameters behind autograd's back (ClipAdamW's raw-pointer update)
 
 

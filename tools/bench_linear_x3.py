@@ -36,6 +36,9 @@ def timeit(fn, iters=20):
 
 
 def main():
+    if os.environ.get("BENCH_TUNED_GEMM", "0") == "1":         # the step's library side: the committed TunableOp table
+        from mlagg_unet_amd import gemm_tuning
+        gemm_tuning.use_tuned_gemms(enabled=True)
     lib = _lib.lib()
     st = torch.cuda.current_stream().cuda_stream
     p = lambda t: t.data_ptr()                                                                      # noqa: E731
