@@ -259,6 +259,10 @@ int mlagg_dwconv3x3_nchw_fwd(const float *x, const float *w, const float *bias, 
 size_t mlagg_dwconv3x3_nchw_bwd_workspace_floats(int B, int C, int H, int W, int stride);
 int mlagg_dwconv3x3_nchw_bwd(const float *x, const float *w, const float *dy, float *dx, float *dw, float *dbias,
                              float *workspace, int B, int C, int H, int W, int stride, void *stream);
+/* ... dx = data gradient + dres (NULL: none): the gradient of the block's residual connection on the same map (`x1 = x + ...`,
+ * T:256-300) summed inside the kernel; needs stride 1 and W % 4 == 0. */
+int mlagg_dwconv3x3_nchw_bwd_res(const float *x, const float *w, const float *dy, const float *dres, float *dx, float *dw, float *dbias,
+                                 float *workspace, int B, int C, int H, int W, int stride, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K1': cross-scan / cross-merge of SS2D_skip.forward_corev0 (MambaSkip.py:414-422 and 455-471 + 534).

@@ -69,6 +69,7 @@ SIGNATURES = {
     "mlagg_dwconv3x3_nchw_fwd": (_I, [_F, _F, _F, _F, _I, _I, _I, _I, _I, _S]),
     "mlagg_dwconv3x3_nchw_bwd_workspace_floats": (_SZ, [_I, _I, _I, _I, _I]),
     "mlagg_dwconv3x3_nchw_bwd": (_I, [_F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _S]),
+    "mlagg_dwconv3x3_nchw_bwd_res": (_I, [_F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _S]),
     "mlagg_cross_scan": (_I, [_F, _I, _I, _F, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), _I, _I, _S]),
     "mlagg_cross_merge": (_I, [_F, _F, _I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), _I, _I, _S]),
     "mlagg_diff_lambda_fwd": (_I, [_F, _F, _F, _F, ctypes.c_float, _I, _F, _F, _S]),

@@ -83,7 +83,7 @@ dwconv_nchw_bwd_data_kernel(const float *__restrict__ dy, const float *__restric
 template <bool FLIP>
 __global__ void __launch_bounds__(256)
 dwconv_nchw_s1_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-                      float *__restrict__ y, G g)
+                      float *__restrict__ y, G g, const float *__restrict__ add = nullptr)
 {
     const int c = blockIdx.y, b = blockIdx.z;
     const int W4 = g.W >> 2;
@@ -96,6 +96,11 @@ dwconv_nchw_s1_kernel(const float *__restrict__ x, const float *__restrict__ w, 
     for (int j = 0; j < 9; ++j) wk[j] = w[c * 9 + (FLIP ? 8 - j : j)];
     const float bv = (!FLIP && bias) ? bias[c] : 0.f;
     float acc[4] = {bv, bv, bv, bv};
+    const size_t out = ((size_t)b * g.C + c) * g.H * g.W + (size_t)oy * g.W + x0;
+    if (add) {                                                   // a second gradient of the same map (the block's residual): summed here
+        const float4 a = *reinterpret_cast<const float4 *>(add + out);
+        acc[0] = a.x; acc[1] = a.y; acc[2] = a.z; acc[3] = a.w;
+    }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
         const int iy = oy + ky - 1;
@@ -109,8 +114,7 @@ dwconv_nchw_s1_kernel(const float *__restrict__ x, const float *__restrict__ w, 
         for (int o = 0; o < 4; ++o)
             acc[o] += wk[3 * ky] * v[o] + wk[3 * ky + 1] * v[o + 1] + wk[3 * ky + 2] * v[o + 2];
     }
-    *reinterpret_cast<float4 *>(y + ((size_t)b * g.C + c) * g.H * g.W + (size_t)oy * g.W + x0) =
-        make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4 *>(y + out) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
 // Stride-1 weight gradient, same 4-pixel strips: dw[ky][kx] += dy[p] * x[p + (ky-1, kx-1)], dbias += dy[p]
@@ -269,16 +273,25 @@ extern "C" int mlagg_dwconv3x3_nchw_bwd(const float *x, const float *w, const fl
                                         float *dbias, float *workspace, int B, int C, int H, int W, int stride,
                                         void *stream)
 {
+    return mlagg_dwconv3x3_nchw_bwd_res(x, w, dy, nullptr, dx, dw, dbias, workspace, B, C, H, W, stride, stream);
+}
+
+// ... with dx = data gradient + dres: the block's residual path (`x1 = x + conv3(...)`, T:256-300) hands its gradient of the same map
+// to this kernel instead of to an add_ kernel behind it.  dres != NULL needs the stride-1 strip kernel (W % 4 == 0).
+extern "C" int mlagg_dwconv3x3_nchw_bwd_res(const float *x, const float *w, const float *dy, const float *dres, float *dx, float *dw,
+                                            float *dbias, float *workspace, int B, int C, int H, int W, int stride, void *stream)
+{
     if (!x || !w || !dy || !dx || !dw || !workspace) return MLAGG_E_NULLPTR;
     G g;
     if (int rc = make_g(g, B, C, H, W, stride)) return rc;
+    if (dres && !(stride == 1 && (W & 3) == 0)) return MLAGG_E_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     {
         MLAGG_TIMED(K_DWCONV_NCHW_BWD, st);
         const bool strips = stride == 1 && (W & 3) == 0;
         if (strips)
             hipLaunchKernelGGL(dwconv_nchw_s1_kernel<true>, dim3((H * (W >> 2) + 255) / 256, C, B), dim3(256), 0, st, dy, w,
-                               nullptr, dx, g);
+                               nullptr, dx, g, dres);
         else if (stride == 2)
             hipLaunchKernelGGL(dwconv_nchw_bwd_data_kernel<2>, dim3((H * W + 255) / 256, C, B), dim3(256), 0, st, dy, w, dx, g);
         else

@@ -687,7 +687,11 @@ class MedNeXtBlock(nn.Module):  # reference T:230-324
     def body(self, x, res=None):
         # conv1 is depthwise 3x3 (stride 1, or 2 in the down block): K2n instead of MIOpen's naive fallback; the bias,
         # GELU and residual behind the two 1x1 convolutions are one K13 pass each
-        x1 = ops.dwconv3x3_nchw(x, self.conv1.weight, self.conv1.bias, self.conv1.stride[0])
+        pair = ops.dwconv3x3_nchw_res(x, self.conv1.weight, self.conv1.bias) if (res is x and self.conv1.stride[0] == 1) else None
+        if pair is not None:
+            x1, res = pair                       # the residual's gradient is summed inside K2n's data-gradient kernel
+        else:
+            x1 = ops.dwconv3x3_nchw(x, self.conv1.weight, self.conv1.bias, self.conv1.stride[0])
         # 16-bit modes: the maps between the norm and the two 1x1 convolutions are read only by 16-bit convolutions and stay 16-bit
         ct = _chain_dtype(x1)
         return self.conv3.fused(self.conv2.fused(self.norm(x1, ct), act=ops.EPI_GELU, dtype=ct), res=res)

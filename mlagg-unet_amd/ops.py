@@ -1460,6 +1460,57 @@ def dwconv3x3_nchw(x, weight, bias, stride=1):
     return DWConv3x3NCHWFn.apply(x, weight, bias, stride)
 
 
+DWC_RES = _os.environ.get("MLAGG_DWC_RES", "1") == "1"
+
+
+class DWConvResNCHWFn(torch.autograd.Function):
+    """(conv1(x), x) of a residual MedNeXtBlock (T:256-300: ``x1 = conv1(x) ... x1 = x + x1``): the block input goes through K2n and, as
+    the second output, on to the residual sum.  Backward receives both gradients of x and K2n's data-gradient kernel sums them
+    (mlagg_dwconv3x3_nchw_bwd_res) -- autograd's add_ kernel over the map (three per stage, 161 us of the step) is gone."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _require(x.contiguous(), "x")
+        B, C, H, W = x.shape
+        w = _require(weight.reshape(C, 9).contiguous(), "weight")
+        y = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mlagg_dwconv3x3_nchw_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, C, H, W, 1, _stream()),
+                   "mlagg_dwconv3x3_nchw_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.meta = (bias is not None, weight.shape)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x, w = ctx.saved_tensors
+        has_bias, wshape = ctx.meta
+        B, C, H, W = x.shape
+        if dy is None:                                            # only the residual path carried a gradient
+            return dres, None, None
+        dy = _require(dy.contiguous(), "dy")
+        if dres is not None:
+            dres = _require(dres.contiguous(), "dres")
+            if dres.dtype != torch.float32:
+                dres = dres.float()
+        lib = _lib.lib()
+        dx = torch.empty_like(x)
+        dw = torch.empty(C, 9, device=x.device, dtype=torch.float32)
+        db = torch.empty(C, device=x.device, dtype=torch.float32) if has_bias else None
+        ws = torch.empty(lib.mlagg_dwconv3x3_nchw_bwd_workspace_floats(B, C, H, W, 1), device=x.device, dtype=torch.float32)
+        _lib.check(lib.mlagg_dwconv3x3_nchw_bwd_res(_ptr(x), _ptr(w), _ptr(dy), _ptr(dres), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws), B, C, H,
+                                                    W, 1, _stream()), "mlagg_dwconv3x3_nchw_bwd_res")
+        return dx, dw.reshape(wshape), db
+
+
+def dwconv3x3_nchw_res(x, weight, bias):
+    """(conv(x), x): the depthwise convolution and the map itself for the block's residual sum; None when the fused backward does not
+    apply (the caller keeps the plain form)."""
+    if not (DWC_RES and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[3] % 4 == 0 and x.requires_grad
+            and torch.is_grad_enabled()):
+        return None
+    return DWConvResNCHWFn.apply(x, weight, bias)
+
+
 def _int_array(vals):
     import ctypes
     return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
