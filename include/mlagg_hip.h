@@ -305,6 +305,10 @@ int mlagg_conv1x1_wgrad_lp(const float *dy, long dy_batch, const float *x, long 
  * (the segmentation heads, nnUNetTrainer_MLAgg_2D_dt_MS.py:549-561 OutBlock: the data gradient of a 14-class head contracts over 14). */
 int mlagg_conv1x1_fwd_ragged(const float *x, long x_batch, const float *w, const float *bias, float *y, long y_batch, int B, int O, int I,
                              int I_valid, long P, int dtype, void *stream);
+/* ... accumulate != 0: y += w . x.  The data gradient of the second convolution that reads a map (UnetResBlock's conv3 beside conv1 on the
+ * same input, MONAI structure behind T:1340-1368) is added to the first one's inside the kernel instead of by an add_ over the map. */
+int mlagg_conv1x1_fwd_acc(const float *x, long x_batch, const float *w, const float *bias, float *y, long y_batch, int B, int O, int I,
+                          int I_valid, long P, int dtype, int accumulate, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K19: dense 3 x 3 convolutions (stride 1, zero padding 1, groups 1) on channel-major maps as nine shifted GEMMs on the 16-bit matrix

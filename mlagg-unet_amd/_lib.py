@@ -109,6 +109,7 @@ SIGNATURES = {
     "mlagg_conv3x3_wgrad_lp": (_I, [_F, ctypes.c_long, _F, ctypes.c_long, _F, _F, _I, _I, _I, _I, _I, _I, _S]),
     "mlagg_pixel_unshuffle2_strided": (_I, [_F, ctypes.c_long, _F, _I, _I, _I, _I, _S]),
     "mlagg_pixel_shuffle2": (_I, [_F, _F, _I, _I, _I, _I, _I, _S]),
+    "mlagg_conv1x1_fwd_acc": (_I, [_F, ctypes.c_long, _F, _F, _F, ctypes.c_long, _I, _I, _I, _I, ctypes.c_long, _I, _I, _S]),
     "mlagg_conv1x1_fwd_ragged": (_I, [_F, ctypes.c_long, _F, _F, _F, ctypes.c_long, _I, _I, _I, _I, ctypes.c_long, _I, _S]),
     "mlagg_conv1x1_fwd_lp": (_I, [_F, ctypes.c_long, _F, _F, _F, ctypes.c_long, _I, _I, _I, ctypes.c_long, _I, _S]),
     "mlagg_conv1x1_wgrad_lp": (_I, [_F, ctypes.c_long, _F, ctypes.c_long, _F, _F, _I, _I, _I, ctypes.c_long, _I, _S]),

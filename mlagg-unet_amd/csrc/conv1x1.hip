@@ -37,6 +37,7 @@ struct C1Geom {
     int B, O, I, P;
     long x_batch, y_batch;          // floats between consecutive samples
     int I_valid;                    // channels x really has (<= I): the weight's columns beyond are zero, the rows beyond are not read
+    int accumulate;                 // y += result (a second gradient of the same map: the other convolution of a two-branch block)
 };
 
 using opmode::split8;
@@ -113,11 +114,16 @@ conv1x1_fwd_kernel(const float *__restrict__ X, const float *__restrict__ W, con
                 FVec<TP> v;
 #pragma unroll
                 for (int j = 0; j < TP; ++j) v.v[j] = acc[a][j][r] + bv;
+                if (g.accumulate) {
+                    const FVec<TP> old = *reinterpret_cast<const FVec<TP> *>(dst);
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) v.v[j] += old.v[j];
+                }
                 *reinterpret_cast<FVec<TP> *>(dst) = v;
             } else {
 #pragma unroll
                 for (int j = 0; j < TP; ++j)
-                    if (pc + j >= pnat) dst[j] = acc[a][j][r] + bv;
+                    if (pc + j >= pnat) dst[j] = acc[a][j][r] + bv + (g.accumulate ? dst[j] : 0.f);
             }
         }
     }
@@ -272,11 +278,18 @@ extern "C" int mlagg_conv1x1_supported(int O, int I, long P)
 extern "C" int mlagg_conv1x1_fwd_ragged(const float *x, long x_batch, const float *w, const float *bias, float *y, long y_batch, int B,
                                         int O, int I, int I_valid, long P, int dtype, void *stream)
 {
+    return mlagg_conv1x1_fwd_acc(x, x_batch, w, bias, y, y_batch, B, O, I, I_valid, P, dtype, 0, stream);
+}
+
+// ... accumulate != 0: y += w . x (+ bias) -- the data gradient of the SECOND convolution that reads a map is added to the first one's
+extern "C" int mlagg_conv1x1_fwd_acc(const float *x, long x_batch, const float *w, const float *bias, float *y, long y_batch, int B,
+                                     int O, int I, int I_valid, long P, int dtype, int accumulate, void *stream)
+{
     if (!x || !w || !y) return MLAGG_E_NULLPTR;
     if (!opmode::valid(dtype) || I_valid <= 0 || I_valid > I) return MLAGG_E_UNSUPPORTED;
     if (B <= 0 || B > 65535 || !mlagg_conv1x1_supported(O, I, P)) return MLAGG_E_UNSUPPORTED;
     if (x_batch < (long)I_valid * P || y_batch < (long)O * P || (reinterpret_cast<uintptr_t>(w) & 15)) return MLAGG_E_UNSUPPORTED;
-    C1Geom g{B, O, I, (int)P, x_batch, y_batch, I_valid};
+    C1Geom g{B, O, I, (int)P, x_batch, y_batch, I_valid, accumulate ? 1 : 0};
     hipStream_t st = static_cast<hipStream_t>(stream);
     MLAGG_TIMED(K_CONV1X1, st);
     // tile = (32 TO output channels) x (32 TP pixels) per wave.  MLAGG_K18_TILE="TO,TP" overrides (tuning only).

@@ -762,10 +762,16 @@ class UnetResBlock(nn.Module):
         # 16-bit modes: every map of the block is written by / read by 16-bit convolutions only (the block output feeds the
         # transposed / 1x1 convolutions of decoder0 and the head): all of them stay 16-bit in memory, K10 converts on the fly
         ct = _chain_dtype(x) if x.is_cuda else None
-        c1 = self.conv1.conv.raw(x) if x.is_cuda else self.conv1(x)
+        pair = None
+        if hasattr(self, "conv3") and x.is_cuda and x.dtype == torch.float32 and (ops.conv_dtype() == torch.float32 or ops.LP_K):
+            form = ops.conv_form()
+            if ops.conv_pair_supported(x, self.conv1.conv, self.conv3.conv, form):
+                pair = ops.conv_pair(x, self.conv1.conv.weight, self.conv3.conv.weight, form)   # one input gradient from both (K18 adds to K19's)
+        c1 = pair[0] if pair is not None else (self.conv1.conv.raw(x) if x.is_cuda else self.conv1(x))
         out = _instance_norm_act(self.norm1, c1, ops.ACT_LEAKY, 0.01, None, ct)
         if hasattr(self, "conv3"):
-            res = _instance_norm_act(self.norm3, self.conv3.conv.raw(x) if x.is_cuda else self.conv3(x), out_dtype=ct)
+            c3 = pair[1] if pair is not None else (self.conv3.conv.raw(x) if x.is_cuda else self.conv3(x))
+            res = _instance_norm_act(self.norm3, c3, out_dtype=ct)
         else:
             res = x
         c2 = self.conv2.conv.raw(out) if x.is_cuda else self.conv2(out)

@@ -2238,15 +2238,15 @@ def _k18_product(O, I, P, form=_DTYPE_BF16X3):
     return I == I16 and P >= K18_FWD_MIN_PIXELS and I >= K18_FWD_MIN_K
 
 
-def _conv1x1_k18(x, xb, w, y, B, O, I, P, form):
-    """y (B, O, P) = w (O, I) . x (B, I, P) on K18; a contraction that is not a multiple of 16 on zero-padded weight columns."""
+def _conv1x1_k18(x, xb, w, y, B, O, I, P, form, accumulate=False):
+    """y (B, O, P) (+)= w (O, I) . x (B, I, P) on K18; a contraction that is not a multiple of 16 on zero-padded weight columns."""
     I16 = -(-I // 16) * 16
     if I16 != I:
         wp = torch.zeros(O, I16, device=w.device, dtype=torch.float32)
         wp[:, :I] = w
         w = wp
-    _lib.check(_lib.lib().mlagg_conv1x1_fwd_ragged(_ptr(x), xb, _ptr(w), None, _ptr(y), O * P, B, O, I16, I, P, form, _stream()),
-               "mlagg_conv1x1_fwd_ragged")
+    _lib.check(_lib.lib().mlagg_conv1x1_fwd_acc(_ptr(x), xb, _ptr(w), None, _ptr(y), O * P, B, O, I16, I, P, form, int(accumulate), _stream()),
+               "mlagg_conv1x1_fwd_acc")
 
 
 class Conv1x1Fn(torch.autograd.Function):
@@ -2554,6 +2554,97 @@ class Conv3x3x3Fn(torch.autograd.Function):
             else:                                               # widths that are not multiples of 8: K15 on padded copies
                 dW = conv_weight_grad(x if x.is_contiguous() else x.contiguous(), dy, 3, 1).view(w.shape)
         return dx, dW
+
+
+# measured and NOT adopted (off): on every two-branch block 35.18 vs 35.10 ms, only where K18 runs the 1 x 1 data gradient anyway 35.14 vs 35.11
+# (profiles/round4_m_conv_pair_ab.log) -- the accumulate's extra read of the map costs what the add_ kernel cost
+CONV_PAIR = _os.environ.get("MLAGG_CONV_PAIR", "0") == "1"
+CONV_PAIR_ALWAYS = _os.environ.get("MLAGG_CONV_PAIR_ALWAYS", "0") == "1"
+
+
+class ConvPairFn(torch.autograd.Function):
+    """(conv3x3(x, W3, padding 1), conv1x1(x, W1)) of ONE input map: conv1 and conv3 of a UnetResBlock whose channel count changes (MONAI
+    structure behind T:1340-1368, M:581-667).  Forward products as in Conv3x3Fn / Conv1x1Fn; backward: K19 writes the 3 x 3 data gradient
+    and K18 ADDS the 1 x 1 data gradient to it (mlagg_conv1x1_fwd_acc) -- autograd's add_ over the (B, I, H, W) map (114 us at 256 x 256)
+    is gone, which pays for K18 on contractions it otherwise leaves to the library."""
+
+    @staticmethod
+    def forward(ctx, x, w3, w1, form=_DTYPE_BF16X3):
+        x, xb, P = _planes(x, "x")
+        B, I, H, W = x.shape
+        O3, O1 = w3.shape[0], w1.shape[0]
+        w3c = _require(w3.contiguous(), "w3")
+        w1c = _require(w1.reshape(O1, I).contiguous(), "w1")
+        c3 = _conv3x3_k19(x, xb, w3c, False, O3, I, H, W, form) if _k19_product(O3, I, H, W, form) else _lib_conv_fwd(x, w3c, 1, form)
+        if _k18_product(O1, I, P, form):
+            c1 = torch.empty(B, O1, H, W, device=x.device, dtype=torch.float32)
+            _flop("K18", 2 * B * O1 * I * P)
+            _conv1x1_k18(x, xb, w1c, c1, B, O1, I, P, form)
+        else:
+            c1 = _lib_conv_fwd(x, w1, 0, form)
+        ctx.save_for_backward(x, w3c, w1c)
+        ctx.form, ctx.w1shape = form, w1.shape
+        ctx.leaf, ctx.leaf_params = _leaf_ok(w3, w1), [w3, w1]
+        note_leaf_use(w3, w1)
+        return c3, c1
+
+    @staticmethod
+    def backward(ctx, d3, d1):
+        x, w3, w1 = ctx.saved_tensors
+        B, I, H, W = x.shape
+        O3, O1, P, form = w3.shape[0], w1.shape[0], H * W, ctx.form
+        lib = _lib.lib()
+        d3, d3b, _ = _planes(d3, "d3")
+        d1, d1b, _ = _planes(d1, "d1")
+        dx = dW3 = dW1 = None
+        if ctx.needs_input_grad[0]:
+            dx = _conv3x3_k19(d3, d3b, w3, True, I, O3, H, W, form) if _k19_product(I, O3, H, W, form) else \
+                _lib_conv_bwd(d3, x, w3, 1, (True, False, False), form)[0].contiguous()
+            if bool(lib.mlagg_conv1x1_supported(I, -(-O1 // 16) * 16, P)):
+                wt = transpose_2d(w1.unsqueeze(0))[0]                                  # (I, O1)
+                _flop("K18", 2 * B * O1 * I * P)
+                _conv1x1_k18(d1, d1b, wt, dx, B, I, O1, P, form, accumulate=True)
+            else:
+                dx += _lib_conv_bwd(d1, x, w1.view(ctx.w1shape), 0, (True, False, False), form)[0]
+        ok = ctx.leaf and leaf_single_use(ctx.leaf_params)
+        if ctx.needs_input_grad[1]:
+            if _k19_wgrad(O3, I, H, W, form):
+                with _LeafStream(d3, x, ok=ok):
+                    dW3 = torch.empty(O3, I, 3, 3, device=x.device, dtype=torch.float32)
+                    ws = torch.empty(lib.mlagg_conv3x3_wgrad_workspace_floats(B, O3, I, H, W), device=x.device, dtype=torch.float32)
+                    _flop("K19", 2 * 9 * B * O3 * I * P)
+                    _lib.check(lib.mlagg_conv3x3_wgrad_lp(_ptr(d3), d3b, _ptr(x), x.stride(0), _ptr(dW3), _ptr(ws), B, O3, I, H, W, form,
+                                                          _stream()), "mlagg_conv3x3_wgrad_lp")
+            else:
+                dW3 = _lib_conv_bwd(d3.contiguous(), x, w3, 1, (False, True, False), form)[1]
+        if ctx.needs_input_grad[2]:
+            with _LeafStream(d1, x, ok=ok):
+                dW1 = torch.empty(O1, I, device=x.device, dtype=torch.float32)
+                ws = torch.empty(lib.mlagg_conv1x1_wgrad_workspace_floats(B, O1, I, P), device=x.device, dtype=torch.float32)
+                _flop("K18", 2 * B * O1 * I * P)
+                _lib.check(lib.mlagg_conv1x1_wgrad_lp(_ptr(d1), d1b, _ptr(x), x.stride(0), _ptr(dW1), _ptr(ws), B, O1, I, P, form, _stream()),
+                           "mlagg_conv1x1_wgrad_lp")
+            dW1 = dW1.view(ctx.w1shape)
+        return dx, dW3, dW1, None
+
+
+def conv_pair_supported(x, conv3, conv1, form=_DTYPE_BF16X3):
+    """Both convolutions of the pair are bias-free stride-1 layers K19 / K18 take (at least their weight gradients) on this map, and the
+    input wants a gradient (else there is no sum to fuse)."""
+    if not (CONV_PAIR and x.is_cuda and x.requires_grad and torch.is_grad_enabled()):
+        return False
+    if not (conv3.bias is None and conv1.bias is None
+            and conv3x3_supported(x, conv3.weight, conv3.stride, conv3.padding, conv3.dilation, conv3.groups, form)
+            and conv1x1_supported(x, conv1.weight, conv1.stride, conv1.padding, conv1.dilation, conv1.groups, form)):
+        return False
+    # only where K18 runs the 1 x 1 data gradient anyway: forcing it onto a 48-deep contraction (96 -> 48 at 256 x 256: 110 vs the
+    # library's 88 us) cost more than the saved add_ (35.18 vs 35.10 ms, profiles/round4_m_conv_pair_ab.log)
+    O1, I = int(conv1.weight.shape[0]), int(conv1.weight.shape[1])
+    return CONV_PAIR_ALWAYS or _k18_product(I, O1, int(x.shape[2] * x.shape[3]), form)
+
+
+def conv_pair(x, w3, w1, form=_DTYPE_BF16X3):
+    return ConvPairFn.apply(x, w3, w1, form)
 
 
 def conv3x3x3_supported(x, weight, stride, padding):

@@ -85,7 +85,7 @@ def test_gated_dwconv3x3_matches_conv2d_times_gate(C, H, W, packed):
 def test_residual_block_gradient_is_summed_inside_the_depthwise_backward(monkeypatch):
     """MedNeXtBlock (T:256-300): the block input feeds conv1 and the residual sum; ops.dwconv3x3_nchw_res hands both gradients to
     K2n's data-gradient kernel.  Output, input gradient and all parameter gradients equal the plain form (autograd's add_ behind the
-    kernel) -- bit for bit except the input gradient, whose two terms are summed in the other order."""
+    kernel); the input gradient's two terms are summed in the other order."""
     from mlagg_unet_amd import model, ops
     torch.manual_seed(3)
     blk = model.MedNeXtBlock(96, 96, 2).to(DEV)
@@ -102,8 +102,8 @@ def test_residual_block_gradient_is_summed_inside_the_depthwise_backward(monkeyp
         outs.append((y.detach(), xs.grad, [p.grad.clone() for p in blk.parameters()]))
     assert torch.equal(outs[0][0], outs[1][0])
     assert float((outs[0][1] - outs[1][1]).abs().max()) < 1e-5 * float(outs[1][1].abs().max())
-    for a, b in zip(outs[0][2], outs[1][2]):
-        assert torch.equal(a, b)
+    for a, b in zip(outs[0][2], outs[1][2]):                   # (the library's 1 x 1 weight-gradient solvers at this size use atomics: no bit equality)
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
     assert ops.dwconv3x3_nchw_res(x, blk.conv1.weight, blk.conv1.bias) is None          # no gradient wanted: the plain form
 
 

@@ -270,6 +270,33 @@ def test_split_planes_hands_on_one_gradient_buffer(monkeypatch, H, W):
     assert float((grads[2][0][:, hd:] - grads[1][0][:, hd:]).abs().max()) < 1e-4 * float(grads[1][0].abs().max())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,I,O,H,W", [(2, 96, 48, 32, 32), (1, 192, 96, 16, 16), (2, 48, 40, 8, 16)])
+def test_convolution_pair_sums_the_input_gradient_in_the_kernel(monkeypatch, B, I, O, H, W):
+    """ops.conv_pair = (conv3x3(x, W3), conv1x1(x, W1)) of one map (UnetResBlock conv1 / conv3, M:581-667): outputs and weight gradients
+    equal the separate Functions bit for bit; the input gradient -- K18 adding its product to K19's -- equals float64's sum."""
+    from mlagg_unet_amd import ops
+    for name, v in (("K19_MIN_PIXELS", 0), ("K18_FWD_MIN_PIXELS", 0), ("K18_FWD_MIN_K", 16), ("K18_WGRAD_MIN_PIXELS", 0), ("K19_WGRAD_MIN_PIXELS", 0)):
+        monkeypatch.setattr(ops, name, v)
+    g = torch.Generator().manual_seed(I + O)
+    x = torch.randn(B, I, H, W, generator=g).to(DEV)
+    w3 = (torch.randn(O, I, 3, 3, generator=g) * (9 * I) ** -0.5).to(DEV)
+    w1 = (torch.randn(O, I, 1, 1, generator=g) * I ** -0.5).to(DEV)
+    g3, g1 = torch.randn(B, O, H, W, generator=g).to(DEV), torch.randn(B, O, H, W, generator=g).to(DEV)
+    res = []
+    for paired in (True, False):
+        xs, a3, a1 = x.clone().requires_grad_(True), w3.clone().requires_grad_(True), w1.clone().requires_grad_(True)
+        c3, c1 = ops.conv_pair(xs, a3, a1) if paired else (ops.conv3x3(xs, a3), ops.conv1x1(xs, a1))
+        torch.autograd.backward([c3, c1], [g3, g1])
+        res.append((c3.detach(), c1.detach(), a3.grad, a1.grad, xs.grad))
+    for a, b in zip(res[0][:4], res[1][:4]):
+        assert torch.equal(a, b)
+    xr, r3, r1 = x.double().requires_grad_(True), w3.double(), w1.double()
+    torch.autograd.backward([F.conv2d(xr, r3, None, 1, 1), F.conv2d(xr, r1)], [g3.double(), g1.double()])
+    err = float((res[0][4].double() - xr.grad).abs().max() / xr.grad.abs().max())
+    assert err < 2e-6, err
+
+
 def _rounded_products(x, w, gy, pad, t):
     """The three products of a stride-1 convolution as the reference's autocast step computes them (nnUNetTrainer.py:848): operands
     rounded to the 16-bit type `t`, exact sums (float64 here; the kernels sum in fp32)."""
