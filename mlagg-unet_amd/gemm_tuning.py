@@ -41,4 +41,6 @@ def use_tuned_gemms(enabled=True):
     if not ok or not tn.get_results():
         tn.enable(False)
         return None
+    from . import ops
+    ops.GEMM_TABLE_LOADED[0] = True                   # dispatch thresholds against the library were measured with this table (ops.wgrad_min_rows)
     return private

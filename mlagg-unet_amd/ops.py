@@ -998,7 +998,18 @@ def pooled_diff_attn(q, k_pool, v_pool, lam, subln_w, nh, scale):
 # products, fp32 accumulation -- as accurate against float64 as the fp32 instruction, tools/bench_linear.py).  MLAGG_K5_X3=0: K5 on
 # v_mfma_f32_32x32x2_f32.
 K5_X3 = _os.environ.get("MLAGG_K5_X3", "1") == "1"
-WGRAD_MIN_ROWS = int(_os.environ.get("MLAGG_WGRAD_MIN_ROWS", "8192"))      # below this many tokens the library GEMM is no longer the split-K corner case
+WGRAD_MIN_ROWS = int(_os.environ.get("MLAGG_WGRAD_MIN_ROWS", "0"))      # 0: by the state of the library (below); a number forces it
+# K5w against the library's weight-gradient GEMM at short token counts (2 560): with the TUNED table loaded (gemm_tuning: the headline
+# configuration) the library ties (35.88 vs 35.89 ms), so K5w starts at 8192 tokens; with the default heuristics (every other configuration)
+# K5w wins 0.4 ms of the 224 x 224 bf16 step (profiles/round4_n_lp_k5_min_rows_ab.log) and starts at 2048
+GEMM_TABLE_LOADED = [False]
+
+
+def wgrad_min_rows():
+    return WGRAD_MIN_ROWS if WGRAD_MIN_ROWS > 0 else (8192 if GEMM_TABLE_LOADED[0] else 2048)
+# 16-bit modes: the one-product K5 from this many tokens on (2048 measured slower than the library's 16-bit GEMM: 28.81 vs 28.62 ms on config 3,
+# profiles/round4_n_lp_k5_min_rows_ab.log)
+LP_K5_MIN_ROWS = int(_os.environ.get("MLAGG_LP_K5_MIN_ROWS", "8192"))
 K5_MIN_ROWS = int(_os.environ.get("MLAGG_K5_MIN_ROWS", "16384"))     # fp32 forward / dx: K5 from this many tokens on (at 10240 tokens the
 #                            library's split-K kernels win: 80-320 K5 workgroups do not fill 256 CUs evenly; A/B on the step: +0.9 %)
 
@@ -1154,7 +1165,7 @@ def _linear_wgrad(dy2, dys, x, O, I, has_bias):
     M = dy2.shape[0]
     x2, xs = _rows2d(x, "x")
     lib = _lib.lib()
-    if M >= WGRAD_MIN_ROWS:
+    if M >= wgrad_min_rows():
         # dW | db in one allocation (every entry is written by the reduction)
         buf = torch.empty(O * I + (O if has_bias else 0), device=dy2.device, dtype=torch.float32)
         dW = buf[:O * I].view(O, I)
@@ -1190,7 +1201,7 @@ class LinearFn(torch.autograd.Function):
             w = _require(weight.contiguous(), "weight")
             img, ctx.imgT = weight_images(w)
             return _x3(x2, xs, img, bias, M, O, I, out_shape=x.shape[:-1] + (O,))
-        if M >= (K5_MIN_ROWS if cdt == torch.float32 else WGRAD_MIN_ROWS) and I % 4 == 0 and x.is_cuda:
+        if M >= (K5_MIN_ROWS if cdt == torch.float32 else LP_K5_MIN_ROWS) and I % 4 == 0 and x.is_cuda:
             x2, xs = _mfma_rows(x, "x")
             w = _require(weight.contiguous(), "weight")
             y = torch.empty(x.shape[:-1] + (O,), device=x.device, dtype=torch.float32)
@@ -1217,7 +1228,6 @@ class LinearFn(torch.autograd.Function):
         cdt = ctx.cdt
         dy2, dys = _mfma_rows(dy, "dy")
         M = dy2.shape[0]
-        big = M >= WGRAD_MIN_ROWS
         lib = _lib.lib()
         if ctx.needs_input_grad[0]:
             if ctx.imgT is not None and _x3_ok(M, I, O):
@@ -1228,7 +1238,7 @@ class LinearFn(torch.autograd.Function):
                     _x3(dy2, dys, ctx.imgT, None, M, I, O, out=dx, out_stride=dxs)
                 else:
                     dx = _x3(dy2, dys, ctx.imgT, None, M, I, O, out_shape=x.shape)
-            elif big and (M >= K5_MIN_ROWS or cdt != torch.float32) and O % 4 == 0 and I % 4 == 0:
+            elif (M >= K5_MIN_ROWS if cdt == torch.float32 else M >= LP_K5_MIN_ROWS) and O % 4 == 0 and I % 4 == 0:
                 w = _require(weight.contiguous(), "weight")
                 dx = torch.empty(x.shape, device=dy.device, dtype=torch.float32)
                 _flop("K5", 2 * M * O * I)
